@@ -1,0 +1,74 @@
+"""Build libcogview_hip.so (gfx950) from the .hip sources in this directory with hipcc.
+
+No torch involvement: the library is a plain C-ABI shared object (see include/cogview_hip.h).
+Objects go to build/ (git-ignored); the .so is written in-tree to cogview_amd/lib/ so that it travels to
+the GPU box with the repo snapshot.
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+INCLUDE = os.path.join(ROOT, "include")
+OBJ_DIR = os.path.join(ROOT, "build", "obj")
+LIB_DIR = os.path.join(os.path.dirname(HERE), "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libcogview_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{HERE}"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libcogview_hip.so")
+
+
+def sources():
+    return sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".cuh", ".h"))]
+    hdrs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, obj):
+    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    return obj
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    dep_t = _deps_mtime()
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), dep_t):
+            jobs.append((src, obj))
+    if jobs:
+        if verbose:
+            print(f"[cogview_amd] hipcc {ARCH}: compiling {len(jobs)} file(s)", flush=True)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(lambda a: _compile(*a), jobs))
+    if jobs or not os.path.exists(LIB_PATH) or any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[cogview_amd] linked {LIB_PATH}", flush=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

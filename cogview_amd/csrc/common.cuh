@@ -1,0 +1,192 @@
+// Common device helpers for the CogView MI355X (gfx950 / CDNA4) hot-path library.
+// Wave = 64 lanes everywhere.  No CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define COGV_OK 0
+#define COGV_ERR_ARG 1      // bad argument (shape/alignment/dtype)
+#define COGV_ERR_LAUNCH 2   // hipGetLastError() after launch
+#define COGV_ERR_UNSUPPORTED 3
+
+#define COGV_F16 0
+#define COGV_BF16 1
+#define COGV_F32 2
+
+typedef _Float16 f16_t;
+typedef __bf16 bf16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+
+// ---------------------------------------------------------------- half traits
+template <typename T> struct HT;
+template <> struct HT<f16_t> {
+  typedef f16x8 v8;
+  static __device__ __forceinline__ float to_f(f16_t x) { return (float)x; }
+  static __device__ __forceinline__ f16_t from_f(float x) { return (f16_t)x; }
+  static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct HT<bf16_t> {
+  typedef bf16x8 v8;
+  static __device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }
+  static __device__ __forceinline__ bf16_t from_f(float x) { return (bf16_t)x; }
+  static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// 16-bit payload <-> float via raw bits (used on packed u32 words)
+template <typename T> __device__ __forceinline__ float bits_to_f(uint16_t b);
+template <> __device__ __forceinline__ float bits_to_f<f16_t>(uint16_t b) {
+  f16_t h; __builtin_memcpy(&h, &b, 2); return (float)h;
+}
+template <> __device__ __forceinline__ float bits_to_f<bf16_t>(uint16_t b) {
+  return __uint_as_float(((uint32_t)b) << 16);
+}
+template <typename T> __device__ __forceinline__ uint16_t f_to_bits(float x) {
+  T h = (T)x; uint16_t b; __builtin_memcpy(&b, &h, 2); return b;
+}
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)f_to_bits<T>(lo) | ((uint32_t)f_to_bits<T>(hi) << 16);
+}
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = bits_to_f<T>((uint16_t)(v[i] & 0xffffu));
+    f[2 * i + 1] = bits_to_f<T>((uint16_t)(v[i] >> 16));
+  }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack2<T>(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block reductions (blockDim.x multiple of 64, <= 1024); smem >= 16 floats
+__device__ __forceinline__ float block_sum(float v, float* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += smem[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  float r = smem[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, smem[i]);
+  return r;
+}
+
+// non-negative float atomic max through the integer ordering of IEEE-754
+__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
+  // NaN propagates as a huge positive pattern (0x7fc00000 > any finite) -> LN output becomes NaN,
+  // the same visible outcome as the reference's x.abs().max() with NaNs present.
+  atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// Dropout masks are a pure function of (seed, stream, element index) so that backward kernels (and
+// activation-checkpoint recompute) regenerate them instead of storing them.  Philox4x32-10 costs forty
+// quarter-rate 32-bit multiplies per call on CDNA; here one PCG output-permutation hash (2 multiplies) of the
+// group counter is expanded with xorshift32 steps (full-rate ops only).  Bit-parity with torch's generator
+// is impossible either way (reference mpu/random.py forks the CUDA Philox state); tests check statistics
+// and forward/backward mask consistency.
+__host__ __device__ __forceinline__ uint32_t pcg32(uint32_t x) {
+  const uint32_t state = x * 747796405u + 2891336453u;
+  const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+  return (word >> 22u) ^ word;
+}
+__host__ __device__ __forceinline__ uint32_t xorshift32(uint32_t x) {
+  x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t rng_key(uint64_t seed, uint64_t stream) {
+  uint32_t k = pcg32((uint32_t)(stream >> 32) + 0x9E3779B9u);
+  k = pcg32((uint32_t)stream ^ k);
+  k = pcg32((uint32_t)(seed >> 32) ^ k);
+  k = pcg32((uint32_t)seed ^ k);
+  return k;
+}
+struct Philox {   // name kept for call sites; see comment above
+  // 128 random bits for group counter `ctr`
+  static __device__ __forceinline__ u32x4 gen(uint64_t seed, uint64_t stream, uint64_t ctr) {
+    const uint32_t key = rng_key(seed, stream);
+    return gen_k(key, ctr);
+  }
+  static __device__ __forceinline__ u32x4 gen_k(uint32_t key, uint64_t ctr) {
+    u32x4 o;
+    o[0] = pcg32(((uint32_t)ctr ^ key) + (uint32_t)(ctr >> 32) * 0x85EBCA6Bu);
+    o[1] = xorshift32(o[0] ^ 0x68E31DA4u);
+    o[2] = xorshift32(o[1]);
+    o[3] = xorshift32(o[2]);
+    return o;
+  }
+  // 64 random bits (attention: one group = 1 query x 4 consecutive keys)
+  static __device__ __forceinline__ u32x2 gen64_k(uint32_t key, uint64_t ctr) {
+    u32x2 o;
+    o[0] = pcg32(((uint32_t)ctr ^ key) + (uint32_t)(ctr >> 32) * 0x85EBCA6Bu);
+    o[1] = xorshift32(o[0] ^ 0x68E31DA4u);
+    return o;
+  }
+};
+// Dropout convention used by every element-wise kernel / epilogue (forward and replay in backward):
+// element with linear index e belongs to group G = e >> 3; r = gen(seed, stream, G);
+// its 16 random bits are (r[(e&7)>>1] >> (16*(e&1))) & 0xffff; the element is KEPT iff bits >= thr16
+// where thr16 = round(p * 65536).  Kept elements are scaled by 65536 / (65536 - thr16).
+__device__ __forceinline__ uint32_t drop_bits16(const u32x4& r, int j) {
+  return (r[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+}
+
+// ---------------------------------------------------------------- misc
+__device__ __forceinline__ float gelu_f(float x) {
+  // OpenAI tanh approximation, reference mpu/sparse_transformer.py:172-176
+  const float u = 0.7978845608028654f * x * (1.0f + 0.044715f * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float x2 = x * x;
+  const float u = 0.7978845608028654f * x * (1.0f + 0.044715f * x2);
+  const float t = tanhf(u);
+  const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x2);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+
+static inline int cogv_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? COGV_OK : COGV_ERR_LAUNCH;
+}

@@ -1,0 +1,409 @@
+// MFMA GEMM family for the CogView GPT hot path (gfx950).
+//
+//   C[M,N] = epilogue( A_op[M,K] * B_op[N,K]^T )         fp16/bf16 inputs, fp32 accumulate
+//
+// Replaces the cuBLAS calls reached through F.linear in the reference:
+//   forward  Y = X W^T + b         mpu/layers.py:243 (ColumnParallelLinear), :319 (RowParallelLinear),
+//                                  model/gpt2_modeling.py:117 (tied logits)          -> transA=0, transB=0
+//   dgrad    dX = dY W             autograd of the above                            -> transA=0, transB=1
+//   wgrad    dW = dY^T X           autograd of the above                            -> transA=1, transB=1
+//
+// "trans" means the operand is stored with the contraction index as the SLOW dimension
+// (A stored [K][M], B stored [K][N]); such tiles are transposed in registers while being staged to LDS
+// so that every MFMA fragment read is one conflict-free ds_read_b128.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16.
+// LDS: 2 stages x (A 16 KiB + B 16 KiB) = 64 KiB (2 blocks / CU); the fp32 C tile reuses the same 64 KiB
+// for a coalesced, fused epilogue (bias, GeLU, dGeLU, dropout, accumulate, abs-max for Sandwich-LN).
+#include "common.cuh"
+#include "cogview_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NTHREADS = 256;
+
+struct GemmArgs {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  const void* bias;     // [N] (T)
+  void* aux;            // GELU: optional pre-activation out [M,ldaux]; DGELU: pre-activation in
+  int ldaux;
+  float* absmax;        // device scalar
+  int flags;
+  int out_f32;          // C is float (used by nothing but tests / future)
+  uint64_t seed, stream_id;
+  uint32_t thr16;       // dropout threshold (0 => keep all)
+  float keep_scale;
+  float* ws;            // split-K slabs [S][M][N] fp32
+  int splitk;
+  int ktiles_per_split;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
+
+// ---- staging: K-contiguous operand.  Tile rows = output index (m or n), 64 k per row.
+template <typename T>
+__device__ __forceinline__ void load_nat(const T* __restrict__ base, int ld, int row0, int nrows, int k0, int K,
+                                         u32x4 (&r)[4]) {
+  const int t = threadIdx.x;
+  const int chunk = t & 7;
+  const int kk = k0 + chunk * 8;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = (t >> 3) + 32 * p;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row0 + row < nrows && kk < K)
+      v = *reinterpret_cast<const u32x4*>(base + (size_t)(row0 + row) * ld + kk);
+    r[p] = v;
+  }
+}
+__device__ __forceinline__ void store_nat(char* lds, const u32x4 (&r)[4]) {
+  const int t = threadIdx.x;
+  const int chunk = t & 7;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = (t >> 3) + 32 * p;
+    *reinterpret_cast<u32x4*>(lds + row * 128 + ((chunk ^ swz(row)) << 4)) = r[p];
+  }
+}
+// ---- staging: K-strided operand stored [K][rows]; tile = 64 k-rows x 128 columns.
+template <typename T>
+__device__ __forceinline__ void load_tr(const T* __restrict__ base, int ld, int col0, int ncols, int k0, int K,
+                                        u32x4 (&r)[4]) {
+  const int t = threadIdx.x;
+  const int c = t & 15;          // 8-column chunk
+  const int kr = (t >> 4) * 4;   // first of 4 k-rows
+  const int col = col0 + c * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (k0 + kr + i < K && col < ncols)
+      v = *reinterpret_cast<const u32x4*>(base + (size_t)(k0 + kr + i) * ld + col);
+    r[i] = v;
+  }
+}
+__device__ __forceinline__ void store_tr(char* lds, const u32x4 (&r)[4]) {
+  const int t = threadIdx.x;
+  const int c = t & 15;
+  const int kr = (t >> 4) * 4;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    // even column 8c+2w : low halves ; odd column 8c+2w+1 : high halves
+    u32x2 lo, hi;
+    lo[0] = (r[0][w] & 0xffffu) | (r[1][w] << 16);
+    lo[1] = (r[2][w] & 0xffffu) | (r[3][w] << 16);
+    hi[0] = (r[0][w] >> 16) | (r[1][w] & 0xffff0000u);
+    hi[1] = (r[2][w] >> 16) | (r[3][w] & 0xffff0000u);
+    const int row_e = c * 8 + 2 * w, row_o = row_e + 1;
+    *reinterpret_cast<u32x2*>(lds + row_e * 128 + ((((kr >> 3)) ^ swz(row_e)) << 4) + ((kr & 4) << 1)) = lo;
+    *reinterpret_cast<u32x2*>(lds + row_o * 128 + ((((kr >> 3)) ^ swz(row_o)) << 4) + ((kr & 4) << 1)) = hi;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ typename HT<T>::v8 read_frag(const char* lds, int row, int chunk) {
+  return *reinterpret_cast<const typename HT<T>::v8*>(lds + row * 128 + ((chunk ^ swz(row)) << 4));
+}
+
+// ---- fused epilogue on 8 consecutive columns of one row (fp32 in registers)
+template <typename T>
+__device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, float (&v)[8]) {
+  if (p.flags & COGV_EPI_BIAS) {
+    u32x4 bv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
+    float b[8]; unpack8<T>(bv, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  if (p.flags & COGV_EPI_GELU) {
+    if (p.aux) {
+      *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n) = pack8<T>(v);
+      // the activation is evaluated on the rounded pre-activation, i.e. exactly what backward will read
+      u32x4 rv = pack8<T>(v); unpack8<T>(rv, v);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+  }
+  if (p.flags & COGV_EPI_DGELU) {
+    u32x4 uv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
+    float u[8]; unpack8<T>(uv, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(u[i]);
+  }
+  if ((p.flags & COGV_EPI_DROPOUT) && p.thr16) {
+    const uint64_t e = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;   // n % 8 == 0
+    const u32x4 r = Philox::gen(p.seed, p.stream_id, e >> 3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (drop_bits16(r, i) >= p.thr16) ? v[i] * p.keep_scale : 0.f;
+  }
+  if (p.flags & COGV_EPI_ACCUM) {
+    if (p.out_f32) {
+      const float* c = reinterpret_cast<const float*>(p.C) + (size_t)m * p.ldc + n;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += c[i];
+    } else {
+      u32x4 cv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n);
+      float c[8]; unpack8<T>(cv, c);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += c[i];
+    }
+  }
+  float amax = 0.f;
+  if (p.out_f32) {
+    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+    *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+  } else {
+    u32x4 o = pack8<T>(v);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = o;
+    if (p.flags & COGV_EPI_ABSMAX) {
+      float r[8]; unpack8<T>(o, r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(r[i]));   // NaN-ignoring max; NaNs handled below
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (r[i] != r[i]) amax = r[i];
+    }
+  }
+  return amax;
+}
+
+template <typename T, bool AT, bool BT>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // stage s: A at smem + s*32768, B at smem + s*32768 + 16384 (no static LDS: keeps the base 16-B aligned)
+
+  // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous run of tiles,
+  //      ordered in groups of 8 tile-rows so that neighbours share A row-panels / B column-panels in L2.
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  constexpr int GROUP_M = 8;
+  const int in_group = GROUP_M * p.tiles_n;
+  const int group_id = wgid / in_group;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tile_m = first_m + (wgid % in_group) % gsz;
+  const int tile_n = (wgid % in_group) / gsz;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt_begin = blockIdx.y * p.ktiles_per_split;
+  const int kt_end = min(nk_total, kt_begin + p.ktiles_per_split);
+
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* B = reinterpret_cast<const T*>(p.B);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int fr = lane & 31, fg = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  u32x4 ra[4], rb[4];
+  auto g_load = [&](int kt) {
+    const int k0 = kt * BK;
+    if (AT) load_tr<T>(A, p.lda, m0, p.M, k0, p.K, ra); else load_nat<T>(A, p.lda, m0, p.M, k0, p.K, ra);
+    if (BT) load_tr<T>(B, p.ldb, n0, p.N, k0, p.K, rb); else load_nat<T>(B, p.ldb, n0, p.N, k0, p.K, rb);
+  };
+  auto l_store = [&](int s) {
+    char* la = smem + s * 32768; char* lb = la + 16384;
+    if (AT) store_tr(la, ra); else store_nat(la, ra);
+    if (BT) store_tr(lb, rb); else store_nat(lb, rb);
+  };
+
+  if (kt_begin < kt_end) {
+    g_load(kt_begin);
+    l_store(0);
+  }
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    const bool more = (kt + 1 < kt_end);
+    if (more) g_load(kt + 1);
+    const char* la = smem + cur * 32768; const char* lb = la + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      typename HT<T>::v8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = read_frag<T>(la, wm + 32 * i + fr, 2 * ks + fg);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read_frag<T>(lb, wn + 32 * j + fr, 2 * ks + fg);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = HT<T>::mfma32(fa[i], fb[j], acc[i][j]);
+    }
+    if (more) l_store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- stage the fp32 C tile in LDS ([128][128] floats, 64 KiB) for a coalesced epilogue
+  float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fg;
+        const int col = wn + 32 * j + fr;
+        ct[row * BN + col] = acc[i][j][e];
+      }
+  __syncthreads();
+
+  float amax = 0.f;
+  bool nan = false;
+  const int cchunk = (threadIdx.x & 15) * 8;
+#pragma unroll 1
+  for (int pass = 0; pass < 8; ++pass) {
+    const int row = pass * 16 + (threadIdx.x >> 4);
+    const int m = m0 + row, n = n0 + cchunk;
+    if (m < p.M && n < p.N) {
+      float v[8];
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(ct + row * BN + cchunk);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(ct + row * BN + cchunk + 4);
+      v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
+      v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+      if (p.splitk > 1) {
+        float* w = p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n;
+        *reinterpret_cast<f32x4*>(w) = x0;
+        *reinterpret_cast<f32x4*>(w + 4) = x1;
+      } else {
+        const float a = epilogue8<T>(p, m, n, v);
+        if (a != a) nan = true; else amax = fmaxf(amax, a);
+      }
+    }
+  }
+  if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
+    // fmaxf drops NaNs, so a NaN anywhere in the tile is carried by a flag and published as a quiet-NaN
+    // bit pattern (larger than every finite value under the unsigned ordering used by the atomic)
+    float bm = block_max(amax, reinterpret_cast<float*>(smem));
+    const bool any_nan = __syncthreads_or(nan);
+    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, any_nan ? __uint_as_float(0x7fc00000u) : bm);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+  __shared__ float red[16];
+  const size_t nvec = (size_t)p.M * (p.N / 8);
+  float amax = 0.f; bool nan = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / (p.N / 8));
+    const int n = (int)(i % (p.N / 8)) * 8;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < p.splitk; ++s) {
+      const float* w = p.ws + ((size_t)s * p.M + m) * p.N + n;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(w);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(w + 4);
+      v[0] += x0[0]; v[1] += x0[1]; v[2] += x0[2]; v[3] += x0[3];
+      v[4] += x1[0]; v[5] += x1[1]; v[6] += x1[2]; v[7] += x1[3];
+    }
+    const float a = epilogue8<T>(p, m, n, v);
+    if (a != a) nan = true; else amax = fmaxf(amax, a);
+  }
+  if (p.flags & COGV_EPI_ABSMAX) {
+    float bm = block_max(amax, red);
+    const bool any_nan = __syncthreads_or(nan);
+    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, any_nan ? __uint_as_float(0x7fc00000u) : bm);
+  }
+}
+
+template <typename T>
+int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
+  dim3 grid(a.tiles_m * a.tiles_n, a.splitk), block(NTHREADS);
+  const size_t shmem = 65536;
+#define LAUNCH(AT_, BT_)                                                                                 \
+  do {                                                                                                   \
+    static bool attr_set = false;                                                                        \
+    if (!attr_set) {                                                                                     \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AT_, BT_>),                      \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                       \
+      attr_set = true;                                                                                   \
+    }                                                                                                    \
+    hipLaunchKernelGGL((gemm_kernel<T, AT_, BT_>), grid, block, shmem, st, a);                           \
+  } while (0)
+  if (!d->trans_a && !d->trans_b) LAUNCH(false, false);
+  else if (!d->trans_a && d->trans_b) LAUNCH(false, true);
+  else if (d->trans_a && d->trans_b) LAUNCH(true, true);
+  else LAUNCH(true, false);
+#undef LAUNCH
+  if (a.splitk > 1) {
+    const size_t nvec = (size_t)a.M * (a.N / 8);
+    int blocks = (int)((nvec + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, a);
+  }
+  return cogv_check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t cogv_gemm_workspace_bytes(const cogv_gemm_desc* d) {
+  if (!d || d->splitk <= 1) return 0;
+  return (size_t)d->splitk * (size_t)d->M * (size_t)d->N * sizeof(float);
+}
+
+// Heuristic used by the host side: split the contraction when the output has too few tiles to fill 256 CUs
+// (weight-gradient GEMMs of the 336M config: 64..256 tiles, contraction = b*1088 tokens).
+extern "C" int cogv_gemm_pick_splitk(int M, int N, int K) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int nk = (K + BK - 1) / BK;
+  if (tiles >= 512 || nk < 8) return 1;
+  int s = (1024 + tiles - 1) / tiles;
+  if (s > nk / 4) s = nk / 4;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int cogv_gemm(const cogv_gemm_desc* d, void* stream) {
+  if (!d) return COGV_ERR_ARG;
+  if (d->dtype != COGV_F16 && d->dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0) return COGV_ERR_ARG;
+  if ((d->N & 7) || (d->ldc & 7)) return COGV_ERR_ARG;
+  if ((d->lda & 7) || (d->ldb & 7)) return COGV_ERR_ARG;
+  if (!d->trans_a && (d->K & 7)) return COGV_ERR_ARG;   // K-contiguous operands are read in 16-byte chunks
+  if (!d->trans_b && (d->K & 7)) return COGV_ERR_ARG;
+  if (d->trans_a && (d->M & 7)) return COGV_ERR_ARG;
+  if (((uintptr_t)d->A | (uintptr_t)d->B | (uintptr_t)d->C) & 15) return COGV_ERR_ARG;
+  if ((d->flags & COGV_EPI_BIAS) && (!d->bias || ((uintptr_t)d->bias & 15))) return COGV_ERR_ARG;
+  if ((d->flags & COGV_EPI_DGELU) && !d->aux) return COGV_ERR_ARG;
+  if ((d->flags & (COGV_EPI_DGELU | COGV_EPI_GELU)) && d->aux && ((d->ldaux & 7) || ((uintptr_t)d->aux & 15)))
+    return COGV_ERR_ARG;
+  if ((d->flags & COGV_EPI_ABSMAX) && !d->absmax) return COGV_ERR_ARG;
+  if ((d->flags & COGV_EPI_DROPOUT) && !(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return COGV_ERR_ARG;
+
+  GemmArgs a;
+  a.A = d->A; a.B = d->B; a.C = d->C;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+  a.bias = d->bias; a.aux = d->aux; a.ldaux = d->ldaux; a.absmax = d->absmax;
+  a.flags = d->flags; a.out_f32 = d->out_f32;
+  a.seed = d->seed; a.stream_id = d->stream_id;
+  a.thr16 = (d->flags & COGV_EPI_DROPOUT) ? (uint32_t)(d->dropout_p * 65536.0f + 0.5f) : 0u;
+  a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
+  a.tiles_m = (d->M + BM - 1) / BM; a.tiles_n = (d->N + BN - 1) / BN;
+  const int nk = (d->K + BK - 1) / BK;
+  a.splitk = d->splitk > 1 ? d->splitk : 1;
+  if (a.splitk > nk) a.splitk = nk;
+  a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
+  a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;   // no empty splits
+  a.ws = reinterpret_cast<float*>(d->workspace);
+  if (a.splitk > 1) {
+    if (!a.ws || d->workspace_bytes < (size_t)a.splitk * a.M * a.N * sizeof(float)) return COGV_ERR_ARG;
+    if ((uintptr_t)a.ws & 15) return COGV_ERR_ARG;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == COGV_F16) return launch_gemm<f16_t>(d, a, st);
+  return launch_gemm<bf16_t>(d, a, st);
+}

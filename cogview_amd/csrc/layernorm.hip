@@ -1,0 +1,311 @@
+// Sandwich-LN primitive of CogView (reference mpu/sparse_transformer.py:40-44):
+//     LayerNorm(x) := FusedLayerNorm(x / (max|x| / 8)),   max over the WHOLE tensor, detached
+// Identity used here:  LN_eps(x / c) == (x - mean) / sqrt(var + eps * c^2) * gamma + beta,   c = max|x| / 8,
+// so the kernel never divides the tensor: it reads the global abs-max scalar that the PRODUCER of x left
+// behind (GEMM epilogue / residual kernels / cogv_absmax) and folds it into epsilon.
+//
+// One wave (64 lanes) per row, row cached in registers, wave-shuffle reductions (no LDS, no barriers).
+// HBM-bound: forward moves 2*h*2 B per row (+2*h*2 with the fused residual), backward 3*h*2 B.
+#include "common.cuh"
+#include "cogview_hip.h"
+
+namespace {
+
+struct LnFwdArgs {
+  const void* x; const void* gamma; const void* beta; const void* res;
+  void* y; float* mean; float* rstd;
+  const float* absmax_in; float* absmax_out;
+  int rows, h; float eps;
+};
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const T* X = reinterpret_cast<const T*>(p.x);
+  const T* R = reinterpret_cast<const T*>(p.res);
+  T* Y = reinterpret_cast<T*>(p.y);
+  float eps = p.eps;
+  if (p.absmax_in) { const float c = *p.absmax_in * 0.125f; eps = p.eps * c * c; }
+  const float inv_h = 1.0f / (float)p.h;
+
+  float g[NV][8], b[NV][8];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int col = (v * 64 + lane) * 8;
+    if (col < p.h) {
+      unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.gamma) + col), g[v]);
+      unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.beta) + col), b[v]);
+    }
+  }
+  float amax = 0.f; bool nan = false;
+  for (int row = wave_global; row < p.rows; row += nwaves) {
+    float x[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * 64 + lane) * 8;
+      if (col < p.h) {
+        unpack8<T>(*reinterpret_cast<const u32x4*>(X + (size_t)row * p.h + col), x[v]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += x[v][i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[v][i] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) * inv_h;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * 64 + lane) * 8;
+      if (col < p.h) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = x[v][i] - mean; q += d * d; }
+      }
+    }
+    const float var = wave_sum(q) * inv_h;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (lane == 0) { if (p.mean) p.mean[row] = mean; if (p.rstd) p.rstd[row] = rstd; }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * 64 + lane) * 8;
+      if (col < p.h) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (x[v][i] - mean) * rstd * g[v][i] + b[v][i];
+        if (R) {
+          // the reference rounds LN's output to the storage type before the residual add
+          // (mpu/sparse_transformer.py:326-329, :337-340); keep that rounding point
+          u32x4 lo = pack8<T>(o); unpack8<T>(lo, o);
+          float r[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(R + (size_t)row * p.h + col), r);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += r[i];
+        }
+        const u32x4 ov = pack8<T>(o);
+        *reinterpret_cast<u32x4*>(Y + (size_t)row * p.h + col) = ov;
+        if (p.absmax_out) {
+          float rr[8]; unpack8<T>(ov, rr);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { if (rr[i] != rr[i]) nan = true; else amax = fmaxf(amax, fabsf(rr[i])); }
+        }
+      }
+    }
+  }
+  if (p.absmax_out) {
+    amax = wave_max(amax);
+    const bool any_nan = __any(nan);
+    if (lane == 0) atomic_max_nonneg(p.absmax_out, any_nan ? __uint_as_float(0x7fc00000u) : amax);
+  }
+}
+
+struct LnBwdArgs {
+  const void* dy; const void* x; const void* gamma; const float* mean; const float* rstd;
+  const void* add_in;      // optional [rows,h] (T): dx_out = add_in + dx
+  void* dx;
+  float* partial;          // [gridDim.x][3][h] fp32: dgamma, dbeta, colsum(dx_out)
+  int rows, h;
+  int want_colsum;
+  uint64_t seed, stream_id; uint32_t thr16; float keep_scale;
+};
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);   // [4][h]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_global = blockIdx.x * 4 + wave;
+  const int nwaves = gridDim.x * 4;
+  const T* DY = reinterpret_cast<const T*>(p.dy);
+  const T* X = reinterpret_cast<const T*>(p.x);
+  const T* AD = reinterpret_cast<const T*>(p.add_in);
+  T* DX = reinterpret_cast<T*>(p.dx);
+  const float inv_h = 1.0f / (float)p.h;
+
+  float g[NV][8], dg[NV][8], db[NV][8], cs[NV][8];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int col = (v * 64 + lane) * 8;
+    if (col < p.h) unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.gamma) + col), g[v]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dg[v][i] = 0.f; db[v][i] = 0.f; cs[v][i] = 0.f; }
+  }
+  for (int row = wave_global; row < p.rows; row += nwaves) {
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    float xh[NV][8], gy[NV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * 64 + lane) * 8;
+      if (col < p.h) {
+        float dy[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(DY + (size_t)row * p.h + col), dy);
+        unpack8<T>(*reinterpret_cast<const u32x4*>(X + (size_t)row * p.h + col), xh[v]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          xh[v][i] = (xh[v][i] - mean) * rstd;
+          gy[v][i] = dy[i] * g[v][i];
+          s1 += gy[v][i];
+          s2 += gy[v][i] * xh[v][i];
+          dg[v][i] += dy[i] * xh[v][i];
+          db[v][i] += dy[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xh[v][i] = 0.f; gy[v][i] = 0.f; }
+      }
+    }
+    const float m1 = wave_sum(s1) * inv_h, m2 = wave_sum(s2) * inv_h;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * 64 + lane) * 8;
+      if (col < p.h) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rstd * (gy[v][i] - m1 - xh[v][i] * m2);
+        if (p.thr16) {
+          const uint64_t e = (uint64_t)row * (uint64_t)p.h + (uint64_t)col;
+          const u32x4 r = Philox::gen(p.seed, p.stream_id, e >> 3);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (drop_bits16(r, i) >= p.thr16) ? o[i] * p.keep_scale : 0.f;
+        }
+        if (AD) {
+          float a[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(AD + (size_t)row * p.h + col), a);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += a[i];
+        }
+        const u32x4 ov = pack8<T>(o);
+        *reinterpret_cast<u32x4*>(DX + (size_t)row * p.h + col) = ov;
+        if (p.want_colsum) {
+          float rr[8]; unpack8<T>(ov, rr);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cs[v][i] += rr[i];
+        }
+      }
+    }
+  }
+  // cross-wave reduction of the three column accumulators, one set at a time through LDS
+  for (int set = 0; set < 3; ++set) {
+    if (set == 2 && !p.want_colsum) break;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * 64 + lane) * 8;
+      if (col < p.h) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          red[wave * p.h + col + i] = (set == 0) ? dg[v][i] : (set == 1) ? db[v][i] : cs[v][i];
+      }
+    }
+    __syncthreads();
+    float* out = p.partial + ((size_t)blockIdx.x * 3 + set) * p.h;
+    for (int c = threadIdx.x; c < p.h; c += 256)
+      out[c] = red[c] + red[p.h + c] + red[2 * p.h + c] + red[3 * p.h + c];
+  }
+}
+
+// sums partial[nblk][3][h] over nblk and writes dgamma/dbeta/colsum in T (optionally accumulating)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial, int nblk, int h, void* dgamma,
+                                                           void* dbeta, void* colsum, int accumulate) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;   // 4 row-slices
+  const int set = blockIdx.y;
+  T* out = reinterpret_cast<T*>(set == 0 ? dgamma : set == 1 ? dbeta : colsum);
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (c < h && out)
+    for (int b = part; b < nblk; b += 4) s += partial[((size_t)b * 3 + set) * h + c];
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && c < h && out) {
+    float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (accumulate) t += HT<T>::to_f(out[c]);
+    out[c] = HT<T>::from_f(t);
+  }
+}
+
+template <typename T, int NV> void launch_fwd(const LnFwdArgs& a, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(blocks), dim3(256), 0, st, a);
+}
+template <typename T, int NV> void launch_bwd(const LnBwdArgs& a, int blocks, hipStream_t st) {
+  const size_t sh = (size_t)4 * a.h * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, NV>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * NV * (int)sizeof(float));
+    attr = true;
+  }
+  hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(blocks), dim3(256), sh, st, a);
+}
+
+#define NV_SWITCH(FN, T, nv, ...)                          \
+  switch (nv) {                                            \
+    case 1: FN<T, 1>(__VA_ARGS__); break;                  \
+    case 2: FN<T, 2>(__VA_ARGS__); break;                  \
+    case 3: FN<T, 3>(__VA_ARGS__); break;                  \
+    case 4: FN<T, 4>(__VA_ARGS__); break;                  \
+    case 5: FN<T, 5>(__VA_ARGS__); break;                  \
+    case 6: FN<T, 6>(__VA_ARGS__); break;                  \
+    case 7: FN<T, 7>(__VA_ARGS__); break;                  \
+    default: FN<T, 8>(__VA_ARGS__); break;                 \
+  }
+
+constexpr int LN_BWD_MAX_BLOCKS = 256;
+
+}  // namespace
+
+extern "C" int cogv_ln_bwd_num_blocks(int rows) {
+  int b = (rows + 3) / 4;
+  return b < 1 ? 1 : (b > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : b);
+}
+extern "C" size_t cogv_ln_bwd_workspace_bytes(int rows, int h) {
+  return (size_t)cogv_ln_bwd_num_blocks(rows) * 3 * (size_t)h * sizeof(float);
+}
+
+extern "C" int cogv_sandwich_ln_fwd(int dtype, const void* x, const void* gamma, const void* beta, const void* residual,
+                                    void* y, float* mean, float* rstd, const float* absmax_in, float* absmax_out,
+                                    int rows, int h, float eps, void* stream) {
+  if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
+  if (rows <= 0 || h <= 0 || (h & 7) || h > 4096) return COGV_ERR_ARG;
+  if (!x || !gamma || !beta || !y) return COGV_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)residual) & 15) return COGV_ERR_ARG;
+  LnFwdArgs a{x, gamma, beta, residual, y, mean, rstd, absmax_in, absmax_out, rows, h, eps};
+  int blocks = (rows + 3) / 4; if (blocks > 4096) blocks = 4096;
+  const int nv = (h + 511) / 512;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == COGV_F16) { NV_SWITCH(launch_fwd, f16_t, nv, a, blocks, st) } else { NV_SWITCH(launch_fwd, bf16_t, nv, a, blocks, st) }
+  return cogv_check_launch();
+}
+
+extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
+                                    const float* rstd, const void* add_in, void* dx, void* dgamma, void* dbeta,
+                                    void* colsum, int accumulate_param_grads, int rows, int h, float dropout_p,
+                                    uint64_t seed, uint64_t stream_id, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
+  if (rows <= 0 || h <= 0 || (h & 7) || h > 4096) return COGV_ERR_ARG;
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !workspace) return COGV_ERR_ARG;
+  if (workspace_bytes < cogv_ln_bwd_workspace_bytes(rows, h)) return COGV_ERR_ARG;
+  if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)add_in) & 15) return COGV_ERR_ARG;
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return COGV_ERR_ARG;
+  LnBwdArgs a;
+  a.dy = dy; a.x = x; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.add_in = add_in; a.dx = dx;
+  a.partial = reinterpret_cast<float*>(workspace); a.rows = rows; a.h = h; a.want_colsum = colsum ? 1 : 0;
+  a.seed = seed; a.stream_id = stream_id;
+  a.thr16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
+  a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
+  const int blocks = cogv_ln_bwd_num_blocks(rows);
+  const int nv = (h + 511) / 512;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == COGV_F16) { NV_SWITCH(launch_bwd, f16_t, nv, a, blocks, st) } else { NV_SWITCH(launch_bwd, bf16_t, nv, a, blocks, st) }
+  if (dgamma || dbeta || colsum) {
+    dim3 grid((h + 63) / 64, 3);
+    if (dtype == COGV_F16)
+      hipLaunchKernelGGL((ln_bwd_reduce_kernel<f16_t>), grid, dim3(256), 0, st, a.partial, blocks, h, dgamma, dbeta, colsum, accumulate_param_grads);
+    else
+      hipLaunchKernelGGL((ln_bwd_reduce_kernel<bf16_t>), grid, dim3(256), 0, st, a.partial, blocks, h, dgamma, dbeta, colsum, accumulate_param_grads);
+  }
+  return cogv_check_launch();
+}

@@ -1,0 +1,402 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per entry point of include/cogview_hip.h).
+
+torch is used for device memory, streams and shapes only; every FLOP / byte of the hot path happens inside
+libcogview_hip.so.  All functions require CUDA(HIP) tensors and raise otherwise -- there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float16: L.F16, torch.bfloat16: L.BF16, torch.float32: L.F32}
+
+
+def dt_code(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise L.CogviewHipError(f"unsupported dtype {t.dtype if isinstance(t, torch.Tensor) else t}")
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.CogviewHipError(
+                "cogview_amd ops run only on an MI355X (HIP) device: got a CPU tensor and there is no CPU fallback")
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------------ scratch
+_WS = {}
+
+
+def workspace(tag, nbytes, device):
+    """Stream-ordered scratch (one buffer per tag and device, grown geometrically)."""
+    key = (tag, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+class _ScalarPool:
+    """Zero-initialised fp32 device scalars (abs-max slots for Sandwich-LN).  Slots are never recycled:
+    a fresh zeroed slab (one memset) is allocated every `n` requests and kept alive by its views."""
+
+    def __init__(self, n=2048):
+        self.n, self.slab, self.i = n, {}, {}
+
+    def next(self, device):
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        if key not in self.slab or self.i[key] >= self.n:
+            self.slab[key] = torch.zeros(self.n, dtype=torch.float32, device=device)
+            self.i[key] = 0
+        s = self.slab[key][self.i[key]:self.i[key] + 1]
+        self.i[key] += 1
+        return s
+
+
+_scalars = _ScalarPool()
+
+
+def new_absmax_slot(device):
+    return _scalars.next(device)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, gelu_aux=None, dgelu_aux=None,
+         dropout=None, absmax=None, accumulate=False, splitk=None, out_dtype=None):
+    """C[M,N] = epilogue(A_op[M,K] . B_op[N,K]^T); a, b 2-D, last dim contiguous.
+    trans_a: `a` is stored [K, M];  trans_b: `b` is stored [K, N].
+    dropout = (p, seed, stream_id).  Returns C."""
+    _need_gpu(a, b)
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    if trans_a:
+        K, M = a.shape
+    else:
+        M, K = a.shape
+    if trans_b:
+        Kb, N = b.shape
+    else:
+        N, Kb = b.shape
+    assert K == Kb, f"contraction mismatch {K} vs {Kb}"
+    d = L.GemmDesc()
+    d.dtype = dt_code(a)
+    d.trans_a, d.trans_b = int(trans_a), int(trans_b)
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda = a.data_ptr(), a.stride(0)
+    d.B, d.ldb = b.data_ptr(), b.stride(0)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
+        assert not accumulate
+    assert out.shape == (M, N) and out.stride(1) == 1
+    d.C, d.ldc = out.data_ptr(), out.stride(0)
+    d.out_f32 = int(out.dtype == torch.float32)
+    flags = 0
+    if bias is not None:
+        flags |= L.EPI_BIAS
+        d.bias = bias.data_ptr()
+    if gelu:
+        flags |= L.EPI_GELU
+        if gelu_aux is not None:
+            d.aux, d.ldaux = gelu_aux.data_ptr(), gelu_aux.stride(0)
+    if dgelu_aux is not None:
+        flags |= L.EPI_DGELU
+        d.aux, d.ldaux = dgelu_aux.data_ptr(), dgelu_aux.stride(0)
+    if dropout is not None and dropout[0] > 0.0:
+        flags |= L.EPI_DROPOUT
+        d.dropout_p, d.seed, d.stream_id = float(dropout[0]), int(dropout[1]), int(dropout[2])
+    if absmax is not None:
+        flags |= L.EPI_ABSMAX
+        d.absmax = absmax.data_ptr()
+    if accumulate:
+        flags |= L.EPI_ACCUM
+    d.flags = flags
+    lib = L.lib()
+    if splitk is None:
+        splitk = lib.cogv_gemm_pick_splitk(M, N, K)
+    d.splitk = int(splitk)
+    if d.splitk > 1:
+        nbytes = lib.cogv_gemm_workspace_bytes(C.byref(d))
+        ws = workspace("gemm_splitk", nbytes, a.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(lib.cogv_gemm(C.byref(d), _stream()), "cogv_gemm")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ Sandwich-LN
+def sandwich_ln_fwd(x, gamma, beta, eps, absmax_in, residual=None, absmax_out=None, save_stats=True):
+    _need_gpu(x, gamma, beta)
+    h = x.shape[-1]
+    x2 = x.reshape(-1, h)
+    assert x2.is_contiguous()
+    rows = x2.shape[0]
+    y = torch.empty_like(x2)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, h)
+        assert r2.is_contiguous()
+    L.check(L.lib().cogv_sandwich_ln_fwd(dt_code(x), _p(x2), _p(gamma), _p(beta), _p(r2), _p(y), _p(mean), _p(rstd),
+                                         _p(absmax_in), _p(absmax_out), rows, h, float(eps), _stream()),
+            "cogv_sandwich_ln_fwd")
+    return y.view(x.shape), mean, rstd
+
+
+def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=None, dbeta=None, colsum=None,
+                    accumulate=False):
+    """dx = [add_in +] mask(LN'(dy)).  dgamma/dbeta/colsum: preallocated [h] tensors (or None)."""
+    _need_gpu(dy, x)
+    h = x.shape[-1]
+    dy2, x2 = dy.reshape(-1, h), x.reshape(-1, h)
+    assert dy2.is_contiguous() and x2.is_contiguous()
+    rows = x2.shape[0]
+    dx = torch.empty_like(x2)
+    a2 = None
+    if add_in is not None:
+        a2 = add_in.reshape(-1, h)
+        assert a2.is_contiguous()
+    lib = L.lib()
+    nbytes = lib.cogv_ln_bwd_workspace_bytes(rows, h)
+    ws = workspace("ln_bwd", nbytes, x.device)
+    p, seed, sid = (0.0, 0, 0) if dropout is None else dropout
+    L.check(lib.cogv_sandwich_ln_bwd(dt_code(x), _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(a2), _p(dx),
+                                     _p(dgamma), _p(dbeta), _p(colsum), int(accumulate), rows, h, float(p), int(seed),
+                                     int(sid), _p(ws), ws.numel(), _stream()), "cogv_sandwich_ln_bwd")
+    return dx.view(x.shape)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_strides(t):
+    # t: [b, s, heads, 64] view with d contiguous and heads packed (stride 64)
+    assert t.dim() == 4 and t.shape[-1] == 64 and t.stride(3) == 1 and (t.stride(2) == 64 or t.shape[2] == 1)
+    return t.stride(0), t.stride(1)
+
+
+def _attn_desc(q, k, v, o, sep, dropout):
+    d = L.AttnDesc()
+    d.dtype = dt_code(q)
+    d.B, d.s_q, d.H = q.shape[0], q.shape[1], q.shape[2]
+    d.s_k = k.shape[1]
+    d.head_dim = 64
+    d.sep = int(sep)
+    d.scale = 0.125
+    p, seed, sid = (0.0, 0, 0) if dropout is None else dropout
+    d.dropout_p, d.seed, d.stream_id = float(p), int(seed), int(sid)
+    d.q, d.k, d.v, d.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    d.q_bs, d.q_rs = _attn_strides(q)
+    d.k_bs, d.k_rs = _attn_strides(k)
+    d.v_bs, d.v_rs = _attn_strides(v)
+    d.o_bs, d.o_rs = _attn_strides(o)
+    return d
+
+
+def attention_fwd(q, k, v, sep=0, dropout=None):
+    """q [b,s_q,H,64], k/v [b,s_k,H,64] (strided views are fine).  Returns (o [b,s_q,H,64] contiguous, lse)."""
+    _need_gpu(q, k, v)
+    b, s_q, H, _ = q.shape
+    o = torch.empty((b, s_q, H, 64), dtype=q.dtype, device=q.device)
+    lse = torch.empty((b, H, s_q), dtype=torch.float32, device=q.device)
+    d = _attn_desc(q, k, v, o, sep, dropout)
+    d.lse = lse.data_ptr()
+    L.check(L.lib().cogv_attention_fwd(C.byref(d), _stream()), "cogv_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, dv=None):
+    _need_gpu(dout, q, k, v, o)
+    b, s_q, H, _ = q.shape
+    if dq is None:
+        dq = torch.empty((b, s_q, H, 64), dtype=q.dtype, device=q.device)
+    if dk is None:
+        dk = torch.empty((b, k.shape[1], H, 64), dtype=q.dtype, device=q.device)
+    if dv is None:
+        dv = torch.empty((b, k.shape[1], H, 64), dtype=q.dtype, device=q.device)
+    dvec = torch.empty((b, H, s_q), dtype=torch.float32, device=q.device)
+    d = _attn_desc(q, k, v, o, sep, dropout)
+    d.lse, d.dvec = lse.data_ptr(), dvec.data_ptr()
+    d.dout, d.dq, d.dk, d.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    d.do_bs, d.do_rs = _attn_strides(dout)
+    d.dq_bs, d.dq_rs = _attn_strides(dq)
+    d.dk_bs, d.dk_rs = _attn_strides(dk)
+    d.dv_bs, d.dv_rs = _attn_strides(dv)
+    L.check(L.lib().cogv_attention_bwd(C.byref(d), _stream()), "cogv_attention_bwd")
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------ embedding
+def embedding_fwd(ids, table, vocab_start, pos_ids=None, pos_table=None, dropout=None, absmax_out=None, x_in=None):
+    _need_gpu(table if table is not None else x_in)
+    src = table if table is not None else x_in
+    h = src.shape[-1]
+    if ids is not None:
+        ids_c = ids.contiguous()
+        n_tok, shape = ids_c.numel(), tuple(ids.shape) + (h,)
+    else:
+        ids_c = None
+        x_in = x_in.contiguous()
+        n_tok, shape = x_in.numel() // h, tuple(x_in.shape)
+    pos_c = None
+    if pos_table is not None:
+        pos_c = pos_ids.expand(shape[:-1]).contiguous()
+    out = torch.empty(shape, dtype=src.dtype, device=src.device)
+    p, seed, sid = (0.0, 0, 0) if dropout is None else dropout
+    vend = vocab_start + (table.shape[0] if table is not None else 0)
+    L.check(L.lib().cogv_embedding_fwd(dt_code(src), _p(ids_c), _p(table), int(vocab_start), int(vend), _p(x_in),
+                                       _p(pos_c), _p(pos_table), 0 if pos_table is None else pos_table.shape[0],
+                                       _p(out), _p(absmax_out), n_tok, h, float(p), int(seed), int(sid), _stream()),
+            "cogv_embedding_fwd")
+    return out
+
+
+def embedding_bwd(dout, ids, dtable, vocab_start, pos_ids=None, dpos=None, dropout=None, dx=None):
+    _need_gpu(dout)
+    h = dout.shape[-1]
+    dout_c = dout.contiguous()
+    n_tok = dout_c.numel() // h
+    ids_c = None if ids is None else ids.contiguous()
+    pos_c = None if pos_ids is None else pos_ids.expand(dout.shape[:-1]).contiguous()
+    p, seed, sid = (0.0, 0, 0) if dropout is None else dropout
+    vend = vocab_start + (dtable.shape[0] if dtable is not None else 0)
+    L.check(L.lib().cogv_embedding_bwd(dt_code(dout), _p(dout_c), _p(ids_c), _p(dtable), int(vocab_start), int(vend),
+                                       _p(pos_c), _p(dpos), 0 if dpos is None else dpos.shape[0], _p(dx), n_tok, h,
+                                       float(p), int(seed), int(sid), _stream()), "cogv_embedding_bwd")
+
+
+# ------------------------------------------------------------------------------------------ element-wise
+def _flat(t):
+    assert t.is_contiguous() and t.numel() % 8 == 0, "element-wise ops need contiguous tensors with numel % 8 == 0"
+    return t
+
+
+def gelu_fwd(x):
+    _need_gpu(x)
+    y = torch.empty_like(_flat(x))
+    L.check(L.lib().cogv_gelu_fwd(dt_code(x), _p(x), _p(y), x.numel(), _stream()), "cogv_gelu_fwd")
+    return y
+
+
+def gelu_bwd(dy, x):
+    _need_gpu(dy, x)
+    dx = torch.empty_like(_flat(x))
+    L.check(L.lib().cogv_gelu_bwd(dt_code(x), _p(_flat(dy)), _p(x), _p(dx), x.numel(), _stream()), "cogv_gelu_bwd")
+    return dx
+
+
+def dropout(x, p, seed, stream_id, absmax_out=None):
+    _need_gpu(x)
+    y = torch.empty_like(_flat(x))
+    L.check(L.lib().cogv_dropout(dt_code(x), _p(x), _p(y), x.numel(), float(p), int(seed), int(stream_id),
+                                 _p(absmax_out), _stream()), "cogv_dropout")
+    return y
+
+
+def add(a, b, absmax_out=None):
+    _need_gpu(a, b)
+    out = torch.empty_like(_flat(a))
+    L.check(L.lib().cogv_add(dt_code(a), _p(a), _p(_flat(b)), _p(out), a.numel(), _p(absmax_out), _stream()), "cogv_add")
+    return out
+
+
+def scale(x, s):
+    _need_gpu(x)
+    y = torch.empty_like(_flat(x))
+    L.check(L.lib().cogv_scale(dt_code(x), _p(x), _p(y), x.numel(), float(s), _stream()), "cogv_scale")
+    return y
+
+
+def absmax(x, out=None):
+    """atomicMax of |x| into `out` (a zeroed fp32 scalar; allocated when None)."""
+    _need_gpu(x)
+    assert x.is_contiguous()
+    if out is None:
+        out = new_absmax_slot(x.device)
+    L.check(L.lib().cogv_absmax(dt_code(x), _p(x), x.numel(), _p(out), _stream()), "cogv_absmax")
+    return out
+
+
+def colsum(dy, out=None, accumulate=False):
+    _need_gpu(dy)
+    assert dy.dim() == 2 and dy.stride(1) == 1
+    M, N = dy.shape
+    if out is None:
+        out = torch.empty(N, dtype=dy.dtype, device=dy.device)
+        assert not accumulate
+    lib = L.lib()
+    ws = workspace("colsum", lib.cogv_colsum_workspace_bytes(M, N), dy.device)
+    L.check(lib.cogv_colsum(dt_code(dy), _p(dy), M, N, dy.stride(0), _p(out), int(accumulate), _p(ws), ws.numel(),
+                            _stream()), "cogv_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ cross entropy
+def ce_fwd(logits2d, target1d, vocab_start, want_loss=True):
+    _need_gpu(logits2d, target1d)
+    assert logits2d.dim() == 2 and logits2d.is_contiguous() and target1d.is_contiguous()
+    rows, v = logits2d.shape
+    f = lambda: torch.empty(rows, dtype=torch.float32, device=logits2d.device)
+    rowmax, sumexp, pred = f(), f(), f()
+    loss = f() if want_loss else None
+    L.check(L.lib().cogv_ce_fwd(dt_code(logits2d), _p(logits2d), _p(target1d), int(vocab_start), rows, v, _p(rowmax),
+                                _p(sumexp), _p(pred), _p(loss), _stream()), "cogv_ce_fwd")
+    return rowmax, sumexp, pred, loss
+
+
+def ce_bwd(logits2d, target1d, vocab_start, gmax, gsum, grad, out=None):
+    _need_gpu(logits2d)
+    rows, v = logits2d.shape
+    if out is None:
+        out = torch.empty_like(logits2d)
+    L.check(L.lib().cogv_ce_bwd(dt_code(logits2d), _p(logits2d), _p(target1d), int(vocab_start), rows, v, _p(gmax),
+                                _p(gsum), _p(grad), _p(out), _stream()), "cogv_ce_bwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ optimizer
+def grad_stats(flat_grads, chunk_start, chunk_len, chunk_norm, stats):
+    _need_gpu(flat_grads)
+    L.check(L.lib().cogv_grad_stats(dt_code(flat_grads), _p(flat_grads), _p(chunk_start), _p(chunk_len),
+                                    _p(chunk_norm), chunk_start.numel(), _p(stats), _stream()), "cogv_grad_stats")
+
+
+def adamw_step(params, grads, master, exp_avg, exp_avg_sq, chunk_start, chunk_len, chunk_group, lrs, wds, beta1,
+               beta2, eps, step, inv_loss_scale=1.0, max_grad_norm=0.0, stats=None, sumsq_override=None,
+               bias_correction=True, adam_w_mode=True):
+    _need_gpu(params, grads, master)
+    d = L.AdamDesc()
+    d.dtype = dt_code(params)
+    d.params, d.grads = params.data_ptr(), grads.data_ptr()
+    d.master, d.exp_avg, d.exp_avg_sq = master.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr()
+    d.chunk_start, d.chunk_len, d.chunk_group = chunk_start.data_ptr(), chunk_len.data_ptr(), chunk_group.data_ptr()
+    d.nchunks = chunk_start.numel()
+    assert len(lrs) <= 8
+    for i, (lr, wd) in enumerate(zip(lrs, wds)):
+        d.lr[i], d.weight_decay[i] = float(lr), float(wd)
+    d.beta1, d.beta2, d.eps = float(beta1), float(beta2), float(eps)
+    d.step, d.bias_correction, d.adam_w_mode = int(step), int(bias_correction), int(adam_w_mode)
+    d.inv_loss_scale, d.max_grad_norm = float(inv_loss_scale), float(max_grad_norm)
+    d.stats = None if stats is None else stats.data_ptr()
+    d.norm_sumsq_override = None if sumsq_override is None else sumsq_override.data_ptr()
+    L.check(L.lib().cogv_adamw_step(C.byref(d), _stream()), "cogv_adamw_step")
+
+
+def cast_flat(src_half, dst_f32):
+    _need_gpu(src_half, dst_f32)
+    L.check(L.lib().cogv_cast_flat(dt_code(src_half), _p(src_half), _p(dst_f32), src_half.numel(), _stream()),
+            "cogv_cast_flat")
+
+
+def cast_flat_back(src_f32, dst_half):
+    _need_gpu(src_f32, dst_half)
+    L.check(L.lib().cogv_cast_flat_back(dt_code(dst_half), _p(src_f32), _p(dst_half), src_f32.numel(), _stream()),
+            "cogv_cast_flat_back")

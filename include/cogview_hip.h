@@ -1,0 +1,188 @@
+/*
+ * cogview_hip.h -- C ABI of libcogview_hip.so, the MI355X (gfx950) implementation of the CogView
+ * training/inference hot path.
+ *
+ * The reference (THUDM/CogView) has no FFI of its own: its hot path reaches native code through
+ * torch/apex/cuBLAS Python calls.  Each entry point below replaces one such call site; the citation
+ * (file:line under the reference tree) names the Python interface whose arithmetic it implements.  The
+ * Python package `cogview_amd` binds these symbols with ctypes and re-exposes the reference's own module
+ * surface (mpu.*, model.GPT2Model, fp16.*, vqvae.*) on top of them; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name says "host"; nothing is allocated inside;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and is stream-ordered;
+ *   - dtype codes: COGV_F16=0 (IEEE half), COGV_BF16=1, COGV_F32=2; "T" below is the 16-bit storage type;
+ *   - return value: 0 = ok, 1 = bad argument (shape / alignment / dtype), 2 = launch failure,
+ *     3 = unsupported combination.  No exceptions, no errno, no global state.
+ *   - row-major everywhere; leading dimensions are in ELEMENTS.
+ *   - dropout masks are a pure function of (seed, stream_id, element index): a counter-based generator
+ *     (PCG hash of the 8-element group counter, xorshift-expanded), 16 random bits per element, keep iff
+ *     bits >= round(p*65536), kept values scaled by 65536/(65536-round(p*65536)).  The backward kernels
+ *     regenerate masks from the same triple, so nothing is stored (and activation-checkpoint recompute
+ *     replays identical masks: reference mpu/random.py:308-310,353-355 does this by saving RNG states).
+ */
+#ifndef COGVIEW_HIP_H
+#define COGVIEW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COGV_F16 0
+#define COGV_BF16 1
+#define COGV_F32 2
+
+/* ------------------------------------------------------------------ library */
+int cogv_version(void);                 /* ABI version, currently 1 */
+const char* cogv_arch(void);            /* "gfx950" */
+
+/* ------------------------------------------------------------------ GEMM (MFMA)
+ * C[M,N] = epilogue(A_op[M,K] . B_op[N,K]^T), fp32 accumulation.
+ *   trans_a = 0: A stored [M][K] (lda >= K);  trans_a = 1: A stored [K][M] (lda >= M)
+ *   trans_b = 0: B stored [N][K] (ldb >= K);  trans_b = 1: B stored [K][N] (ldb >= N)
+ * replaces F.linear at mpu/layers.py:243 (ColumnParallelLinear.forward), mpu/layers.py:319
+ * (RowParallelLinear.forward), model/gpt2_modeling.py:117 (tied logits) and their autograd
+ * (dgrad: trans_b=1; wgrad: trans_a=trans_b=1).
+ * epilogue order: +bias -> [store pre-activation to aux] -> GeLU | x gelu'(aux) -> dropout -> +C -> round
+ * -> abs-max.   GeLU is the tanh form of mpu/sparse_transformer.py:172-176.
+ */
+#define COGV_EPI_BIAS 1     /* + bias[n]                                                             */
+#define COGV_EPI_GELU 2     /* out = gelu(x); if aux != NULL the rounded pre-activation is stored     */
+#define COGV_EPI_DGELU 4    /* out = x * gelu'(aux[m][n])                                             */
+#define COGV_EPI_DROPOUT 8  /* out = dropout(out), element index m*N+n                                */
+#define COGV_EPI_ABSMAX 16  /* atomicMax(*absmax, max|out|) -- feeds the Sandwich-LN scale            */
+#define COGV_EPI_ACCUM 32   /* out += C (gradient accumulation / tied embedding)                      */
+
+typedef struct cogv_gemm_desc {
+  int dtype;            /* COGV_F16 | COGV_BF16 : type of A, B, bias, aux and (unless out_f32) C */
+  int trans_a, trans_b;
+  int M, N, K;
+  const void* A; int lda;
+  const void* B; int ldb;
+  void* C; int ldc;
+  int out_f32;          /* 1: C is float */
+  int flags;            /* COGV_EPI_* */
+  const void* bias;     /* [N] */
+  void* aux; int ldaux; /* [M][ldaux] */
+  float* absmax;        /* device scalar, caller zeroes it */
+  float dropout_p; uint64_t seed; uint64_t stream_id;
+  int splitk;           /* >1: contraction split over this many workgroups + reduce pass */
+  void* workspace; size_t workspace_bytes;   /* >= cogv_gemm_workspace_bytes() when splitk > 1 */
+} cogv_gemm_desc;
+
+int cogv_gemm(const cogv_gemm_desc* d, void* stream);
+size_t cogv_gemm_workspace_bytes(const cogv_gemm_desc* d);
+int cogv_gemm_pick_splitk(int M, int N, int K);
+
+/* ------------------------------------------------------------------ Sandwich-LN
+ * y = [residual +] LayerNorm_{eps*(amax/8)^2}(x) * gamma + beta ; amax = *absmax_in (NULL: plain LN).
+ * replaces mpu/sparse_transformer.py:40-44 (LayerNorm = FusedLayerNorm(x / (x.abs().max()/8))) and the
+ * residual adds at :329 and :340.  mean/rstd ([rows] fp32, may be NULL) are saved for backward.
+ * absmax_out (may be NULL): atomicMax of |y| -- the next LayerNorm's scale.
+ */
+int cogv_sandwich_ln_fwd(int dtype, const void* x, const void* gamma, const void* beta, const void* residual,
+                         void* y, float* mean, float* rstd, const float* absmax_in, float* absmax_out,
+                         int rows, int h, float eps, void* stream);
+/* dx = [add_in +] dropout_mask( LN'(dy) ) ; dgamma/dbeta/colsum (T, [h], any may be NULL) get the column
+ * reductions (colsum = column sums of the written dx: the bias gradient of the Linear that produced x). */
+int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
+                         const float* rstd, const void* add_in, void* dx, void* dgamma, void* dbeta, void* colsum,
+                         int accumulate_param_grads, int rows, int h, float dropout_p, uint64_t seed,
+                         uint64_t stream_id, void* workspace, size_t workspace_bytes, void* stream);
+size_t cogv_ln_bwd_workspace_bytes(int rows, int h);
+int cogv_ln_bwd_num_blocks(int rows);
+
+/* ------------------------------------------------------------------ attention (head dim 64)
+ * replaces standard_attention, mpu/sparse_transformer.py:652-673, plus the head permutes at :112-120,:159.
+ * Tensor element (b, row, head, d) lives at base + b*bs + row*rs + head*64 + d.
+ * Mask: key j visible to query i iff j <= i + (s_k - s_q) or j < sep + (s_k - s_q) (sep = 0: causal);
+ * masked scores are exactly -10000 as in the reference.  lse/dvec: [B][H][s_q] fp32.
+ */
+typedef struct cogv_attn_desc {
+  int dtype; int B, H, s_q, s_k, head_dim; int sep;
+  float scale;                       /* 1/sqrt(head_dim), applied to QK^T */
+  float dropout_p; uint64_t seed; uint64_t stream_id;
+  const void* q; const void* k; const void* v; void* o;
+  const void* dout; void* dq; void* dk; void* dv;
+  float* lse; float* dvec;
+  long long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs;
+  int q_rs, k_rs, v_rs, o_rs, do_rs, dq_rs, dk_rs, dv_rs;
+} cogv_attn_desc;
+int cogv_attention_fwd(const cogv_attn_desc* d, void* stream);
+int cogv_attention_bwd(const cogv_attn_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ embedding
+ * out = dropout( table[ids - vocab_start] (0 outside the shard) [+ pos_table[pos_ids]] ), abs-max of out.
+ * replaces VocabParallelEmbedding.forward mpu/layers.py:117-133 and the position add + dropout at
+ * mpu/sparse_transformer.py:522-524.  ids == NULL: the word part is read from x_in (model-parallel path,
+ * after the all-reduce).  Backward scatter-adds into dtable / dpos with packed 16-bit atomics.
+ */
+int cogv_embedding_fwd(int dtype, const int64_t* ids, const void* table, int64_t vocab_start, int64_t vocab_end,
+                       const void* x_in, const int64_t* pos_ids, const void* pos_table, int64_t n_pos, void* out,
+                       float* absmax_out, int64_t n_tok, int h, float dropout_p, uint64_t seed, uint64_t stream_id,
+                       void* stream);
+int cogv_embedding_bwd(int dtype, const void* dout, const int64_t* ids, void* dtable, int64_t vocab_start,
+                       int64_t vocab_end, const int64_t* pos_ids, void* dpos, int64_t n_pos, void* dx,
+                       int64_t n_tok, int h, float dropout_p, uint64_t seed, uint64_t stream_id, void* stream);
+
+/* ------------------------------------------------------------------ element-wise (n % 8 == 0)
+ * gelu: mpu/sparse_transformer.py:172-179; dropout: torch.nn.Dropout call sites :167,:233,:524 */
+int cogv_gelu_fwd(int dtype, const void* x, void* y, size_t n, void* stream);
+int cogv_gelu_bwd(int dtype, const void* dy, const void* x, void* dx, size_t n, void* stream);
+int cogv_dropout(int dtype, const void* x, void* y, size_t n, float p, uint64_t seed, uint64_t stream_id,
+                 float* absmax_out, void* stream);
+int cogv_add(int dtype, const void* a, const void* b, void* out, size_t n, float* absmax_out, void* stream);
+int cogv_scale(int dtype, const void* x, void* y, size_t n, float scale, void* stream);
+int cogv_absmax(int dtype, const void* x, size_t n, float* out, void* stream);      /* atomicMax into *out */
+/* out[n] (+)= sum_m dy[m][n]  -- bias gradients of the Linear layers */
+int cogv_colsum(int dtype, const void* dy, int M, int N, int ld, void* out, int accumulate, void* workspace,
+                size_t workspace_bytes, void* stream);
+size_t cogv_colsum_workspace_bytes(int M, int N);
+
+/* ------------------------------------------------------------------ vocab-parallel cross entropy
+ * replaces _VocabParallelCrossEntropy, mpu/cross_entropy.py:25-104.  logits [rows][V_local] in
+ * logits_dtype (F16/BF16/F32), target int64 global ids, shard = [vocab_start, vocab_start+V_local).
+ * fwd writes per-row shard statistics: rowmax, sumexp (relative to rowmax), predicted logit (0 when the
+ * target is outside the shard) and, for a single shard, loss = log(sumexp) + rowmax - predicted.
+ * bwd writes dlogits = (exp(logit - gmax)/gsum - onehot) * grad[row] in logits_dtype (may alias logits).
+ */
+int cogv_ce_fwd(int logits_dtype, const void* logits, const int64_t* target, int64_t vocab_start, int rows,
+                int v_local, float* rowmax, float* sumexp, float* predicted, float* loss, void* stream);
+int cogv_ce_bwd(int logits_dtype, const void* logits, const int64_t* target, int64_t vocab_start, int rows,
+                int v_local, const float* gmax, const float* gsum, const float* grad, void* dlogits, void* stream);
+
+/* ------------------------------------------------------------------ optimizer (flat buffers, chunk table)
+ * One launch over the whole flat parameter space replaces FP16_Optimizer's per-tensor passes
+ * (fp16/fp16.py:399-453,556-567), the per-tensor overflow check (fp16/loss_scaler.py:107-145), the
+ * per-tensor norm of mpu/grads.py:59-73 and apex FusedAdam (call site pretrain_gpt2.py:139-140).
+ * Chunk c covers flat elements [chunk_start[c], chunk_start[c]+chunk_len[c]), belongs to hyper-parameter
+ * group chunk_group[c] (< 8) and counts toward the norm iff chunk_norm[c] != 0 (model-parallel dedup of
+ * mpu/grads.py:61).  chunk_start % 8 == 0.
+ */
+/* stats[0] += sum of squares of grads in counted chunks (double), stats[1] = 1.0 if any grad is inf/nan */
+int cogv_grad_stats(int dtype, const void* grads, const int64_t* chunk_start, const int32_t* chunk_len,
+                    const uint8_t* chunk_norm, int nchunks, double* stats, void* stream);
+typedef struct cogv_adam_desc {
+  int dtype;                       /* dtype of model params / grads (F16|BF16) */
+  void* params; const void* grads; /* flat model params (written) and their (scaled) grads */
+  float* master; float* exp_avg; float* exp_avg_sq;   /* flat fp32 */
+  const int64_t* chunk_start; const int32_t* chunk_len; const uint8_t* chunk_group; int nchunks;
+  float lr[8]; float weight_decay[8];
+  float beta1, beta2, eps; int step; int bias_correction; int adam_w_mode;
+  float inv_loss_scale;            /* grads are multiplied by this */
+  float max_grad_norm;             /* > 0: clip by global norm computed from stats */
+  const double* stats;             /* from cogv_grad_stats (device); stats[1] != 0 => whole step skipped */
+  const double* norm_sumsq_override; /* optional device scalar with the MP-reduced sum of squares */
+} cogv_adam_desc;
+int cogv_adamw_step(const cogv_adam_desc* d, void* stream);
+/* master[i] = (float)params[i]  /  params[i] = (T)master[i]  over the chunk table */
+int cogv_cast_flat(int dtype, const void* src_half, float* dst_f32, size_t n, void* stream);
+int cogv_cast_flat_back(int dtype, const float* src_f32, void* dst_half, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COGVIEW_HIP_H */
