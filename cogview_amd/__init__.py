@@ -1,0 +1,7 @@
+"""cogview_amd -- MI355X-native implementation of the CogView training / inference hot path.
+
+Sub-packages mirror the reference's module surface so that its training and sampling scripts can drive this
+package unchanged:  cogview_amd.mpu, cogview_amd.model, cogview_amd.fp16, cogview_amd.vqvae.
+All arithmetic runs in libcogview_hip.so (hand-written HIP for gfx950, include/cogview_hip.h); there is no
+CPU fallback."""
+__version__ = "0.1.0"

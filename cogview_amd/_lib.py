@@ -59,6 +59,7 @@ class AdamDesc(C.Structure):
         ("lr", C.c_float * 8), ("weight_decay", C.c_float * 8),
         ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("step", C.c_int), ("bias_correction", C.c_int), ("adam_w_mode", C.c_int),
+        ("beta1_d", C.c_double), ("beta2_d", C.c_double),
         ("inv_loss_scale", C.c_float), ("max_grad_norm", C.c_float),
         ("stats", C.c_void_p), ("norm_sumsq_override", C.c_void_p),
     ]

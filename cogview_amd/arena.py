@@ -1,0 +1,95 @@
+"""Flat parameter / gradient arena.
+
+MI355X-first memory layout: all parameters of a module live in ONE contiguous 16-bit buffer (each tensor
+256-byte aligned) and all gradients in a second buffer with the same offsets; `param.data` / `param.grad`
+are views.  288 GB of HBM3E per GPU makes the extra fp32 master / Adam-state copies (16 B per parameter,
+62.9 GB for the 4B model) resident without sharding, and the flat layout turns every per-tensor loop of the
+reference (772 tensors at 48 layers) into one kernel or one collective:
+    zero_grad            one memset
+    DP all-reduce        contiguous slices in layer order (overlappable with backward)
+    overflow + norm      cogv_grad_stats over a chunk table
+    AdamW + cast         cogv_adamw_step over the same chunk table
+"""
+import torch
+
+ALIGN = 128          # elements (256 B)
+CHUNK = 65536        # elements per optimizer chunk
+
+
+class ParamArena:
+    def __init__(self, params, dtype, device):
+        self.params = list(params)
+        self.offsets, total = [], 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = total
+        self.data = torch.zeros(total, dtype=dtype, device=device)
+        self.grad = torch.zeros(total, dtype=dtype, device=device)
+        for p, off in zip(self.params, self.offsets):
+            view = self.data[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[off:off + p.numel()].view(p.shape)
+            p._cogv_arena = (self, off)
+        self._tables = {}
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + off * self.grad.element_size():
+                p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+    def slice_of(self, params):
+        """(start, end) element range covering `params` (which must be contiguous in the arena)."""
+        want = {id(p) for p in params}
+        idx = [i for i, q in enumerate(self.params) if id(q) in want]
+        assert idx and idx == list(range(idx[0], idx[-1] + 1)), "parameters are not contiguous in the arena"
+        last = idx[-1]
+        return self.offsets[idx[0]], self.offsets[last] + (self.params[last].numel() + ALIGN - 1) // ALIGN * ALIGN
+
+    def chunk_table(self, group_of, norm_of):
+        """Device chunk table for cogv_grad_stats / cogv_adamw_step.
+        group_of(param) -> hyper-parameter group index; norm_of(param) -> bool (counted in the global norm)."""
+        starts, lens, groups, norms = [], [], [], []
+        for p, off in zip(self.params, self.offsets):
+            g, n = group_of(p), norm_of(p)
+            for c0 in range(0, p.numel(), CHUNK):
+                starts.append(off + c0)
+                lens.append(min(CHUNK, p.numel() - c0))
+                groups.append(g)
+                norms.append(1 if n else 0)
+        dev = self.data.device
+        return (torch.tensor(starts, dtype=torch.int64, device=dev), torch.tensor(lens, dtype=torch.int32, device=dev),
+                torch.tensor(groups, dtype=torch.uint8, device=dev), torch.tensor(norms, dtype=torch.uint8, device=dev))
+
+
+def flatten_module(module, dtype=None):
+    """Move every parameter of `module` (already on the GPU, already in its 16-bit dtype) into one arena.
+    Tied parameters appear once.  Returns the arena (also stored as module._cogv_arena)."""
+    params, seen = [], set()
+    for p in module.parameters():
+        if id(p) not in seen:
+            seen.add(id(p))
+            params.append(p)
+    assert params, "module has no parameters"
+    dtype = dtype or params[0].dtype
+    assert all(p.dtype == dtype for p in params), "arena needs a single parameter dtype"
+    assert all(p.is_cuda for p in params), "arena needs GPU parameters"
+    arena = ParamArena(params, dtype, params[0].device)
+    module._cogv_arena = arena
+    return arena
+
+
+def arena_of(params):
+    """The arena that holds exactly these parameters (None if they are not all in one arena)."""
+    a = None
+    for p in params:
+        e = getattr(p, "_cogv_arena", None)
+        if e is None:
+            return None
+        if a is None:
+            a = e[0]
+        elif a is not e[0]:
+            return None
+    return a

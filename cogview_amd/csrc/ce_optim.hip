@@ -114,7 +114,7 @@ struct AdamArgs {
   void* params; const void* grads; float* master; float* m; float* v;
   const int64_t* chunk_start; const int32_t* chunk_len; const uint8_t* chunk_group; int nchunks;
   float lr[8]; float wd[8];
-  float beta1, beta2, eps, bc1, bc2; int adam_w_mode;
+  float beta1, beta2, omb1, omb2, eps, bc1, bc2; int adam_w_mode;
   float inv_scale, max_norm;
   const double* stats; const double* sumsq_override;
 };
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs p) {
       for (int k = 0; k < 8; ++k) {
         float gr = g[k] * gscale;
         if (!p.adam_w_mode) gr += wd * w[k];                       // L2 mode
-        m[k] = p.beta1 * m[k] + (1.f - p.beta1) * gr;
-        v[k] = p.beta2 * v[k] + (1.f - p.beta2) * gr * gr;
+        m[k] = p.beta1 * m[k] + p.omb1 * gr;
+        v[k] = p.beta2 * v[k] + p.omb2 * gr * gr;
         const float denom = sqrtf(v[k]) * inv_sqrt_bc2 + p.eps;
         float upd = (m[k] * inv_bc1) / denom;
         if (p.adam_w_mode) upd += wd * w[k];                       // decoupled weight decay (apex adam_w_mode=1)
@@ -259,9 +259,11 @@ extern "C" int cogv_adamw_step(const cogv_adam_desc* d, void* stream) {
   a.chunk_start = d->chunk_start; a.chunk_len = d->chunk_len; a.chunk_group = d->chunk_group; a.nchunks = d->nchunks;
   for (int i = 0; i < 8; ++i) { a.lr[i] = d->lr[i]; a.wd[i] = d->weight_decay[i]; }
   a.beta1 = d->beta1; a.beta2 = d->beta2; a.eps = d->eps; a.adam_w_mode = d->adam_w_mode;
+  // 1-beta evaluated in double then rounded once (what torch.optim.AdamW / the oracle do)
+  a.omb1 = (float)(1.0 - (double)d->beta1_d); a.omb2 = (float)(1.0 - (double)d->beta2_d);
   if (d->bias_correction) {
-    a.bc1 = 1.0f - (float)pow((double)d->beta1, (double)d->step);
-    a.bc2 = 1.0f - (float)pow((double)d->beta2, (double)d->step);
+    a.bc1 = (float)(1.0 - pow(d->beta1_d, (double)d->step));
+    a.bc2 = (float)(1.0 - pow(d->beta2_d, (double)d->step));
   } else { a.bc1 = 1.f; a.bc2 = 1.f; }
   a.inv_scale = d->inv_loss_scale; a.max_norm = d->max_grad_norm;
   a.stats = d->stats; a.sumsq_override = d->norm_sumsq_override;

@@ -112,11 +112,18 @@ __device__ __forceinline__ float block_max(float v, float* smem) {
   return r;
 }
 
-// non-negative float atomic max through the integer ordering of IEEE-754
+// non-negative float atomic max through the integer ordering of IEEE-754.
+// Same-address atomics serialise at L2 (~90 per microsecond on MI355X), and a launch has thousands of
+// workgroups, so the current value is read first (relaxed, agent scope -> served by L2) and the atomic is
+// issued only by workgroups that would raise it.  A stale read can only be SMALLER than the true value
+// (the cell is monotonic within a launch), i.e. it costs a redundant atomic, never a missed update.
+// NaN is published as the quiet-NaN pattern 0x7fc00000, which is larger than every finite pattern, so the
+// consumer's LayerNorm goes NaN exactly as the reference's x.abs().max() would make it.
 __device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
-  // NaN propagates as a huge positive pattern (0x7fc00000 > any finite) -> LN output becomes NaN,
-  // the same visible outcome as the reference's x.abs().max() with NaNs present.
-  atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+  const unsigned int vi = __float_as_uint(v);
+  unsigned int* a = reinterpret_cast<unsigned int*>(addr);
+  const unsigned int cur = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (vi > cur) atomicMax(a, vi);
 }
 
 // ---------------------------------------------------------------- counter-based dropout RNG

@@ -118,11 +118,11 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, floa
     for (int i = 0; i < 8; ++i) v[i] += b[i];
   }
   if (p.flags & COGV_EPI_GELU) {
-    if (p.aux) {
-      *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n) = pack8<T>(v);
-      // the activation is evaluated on the rounded pre-activation, i.e. exactly what backward will read
-      u32x4 rv = pack8<T>(v); unpack8<T>(rv, v);
-    }
+    // the activation is evaluated on the pre-activation ROUNDED to the storage type -- exactly what backward
+    // (or a checkpoint recompute that does store it) reads -- whether or not it is stored now
+    const u32x4 rv = pack8<T>(v);
+    if (p.aux) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n) = rv;
+    unpack8<T>(rv, v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
   }

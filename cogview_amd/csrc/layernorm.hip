@@ -94,9 +94,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
     }
   }
   if (p.absmax_out) {
-    amax = wave_max(amax);
-    const bool any_nan = __any(nan);
-    if (lane == 0) atomic_max_nonneg(p.absmax_out, any_nan ? __uint_as_float(0x7fc00000u) : amax);
+    __shared__ float red[16];
+    const float bm = block_max(amax, red);
+    const bool any_nan = __syncthreads_or(nan);
+    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax_out, any_nan ? __uint_as_float(0x7fc00000u) : bm);
   }
 }
 
@@ -207,20 +208,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
 
 // sums partial[nblk][3][h] over nblk and writes dgamma/dbeta/colsum in T (optionally accumulating)
 template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* partial, int nblk, int h, void* dgamma,
-                                                           void* dbeta, void* colsum, int accumulate) {
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* partial, int nblk, int h, void* dgamma,
+                                                            void* dbeta, void* colsum, int accumulate) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;   // 4 row-slices
+  const int part = threadIdx.x >> 6;   // 16 row-slices
   const int set = blockIdx.y;
   T* out = reinterpret_cast<T*>(set == 0 ? dgamma : set == 1 ? dbeta : colsum);
-  __shared__ float red[4][64];
+  __shared__ float red[16][64];
   float s = 0.f;
   if (c < h && out)
-    for (int b = part; b < nblk; b += 4) s += partial[((size_t)b * 3 + set) * h + c];
+    for (int b = part; b < nblk; b += 16) s += partial[((size_t)b * 3 + set) * h + c];
   red[part][threadIdx.x & 63] = s;
   __syncthreads();
   if (part == 0 && c < h && out) {
-    float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
     if (accumulate) t += HT<T>::to_f(out[c]);
     out[c] = HT<T>::from_f(t);
   }
@@ -252,7 +255,7 @@ template <typename T, int NV> void launch_bwd(const LnBwdArgs& a, int blocks, hi
     default: FN<T, 8>(__VA_ARGS__); break;                 \
   }
 
-constexpr int LN_BWD_MAX_BLOCKS = 256;
+constexpr int LN_BWD_MAX_BLOCKS = 512;
 
 }  // namespace
 
@@ -303,9 +306,9 @@ extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, co
   if (dgamma || dbeta || colsum) {
     dim3 grid((h + 63) / 64, 3);
     if (dtype == COGV_F16)
-      hipLaunchKernelGGL((ln_bwd_reduce_kernel<f16_t>), grid, dim3(256), 0, st, a.partial, blocks, h, dgamma, dbeta, colsum, accumulate_param_grads);
+      hipLaunchKernelGGL((ln_bwd_reduce_kernel<f16_t>), grid, dim3(1024), 0, st, a.partial, blocks, h, dgamma, dbeta, colsum, accumulate_param_grads);
     else
-      hipLaunchKernelGGL((ln_bwd_reduce_kernel<bf16_t>), grid, dim3(256), 0, st, a.partial, blocks, h, dgamma, dbeta, colsum, accumulate_param_grads);
+      hipLaunchKernelGGL((ln_bwd_reduce_kernel<bf16_t>), grid, dim3(1024), 0, st, a.partial, blocks, h, dgamma, dbeta, colsum, accumulate_param_grads);
   }
   return cogv_check_launch();
 }

@@ -1,0 +1,483 @@
+"""Autograd plumbing over the HIP ops.
+
+Two tiers:
+  * op-level Functions (linear, Sandwich-LN, attention, embedding, GeLU, dropout, cross entropy): compose
+    freely -- this is what the individual `mpu` modules call, and it handles every shape the reference's modules
+    accept (memories, "sep" masks, model parallelism);
+  * `transformer_layer` -- one Function for a whole GPT2ParallelTransformerLayer (the 9-kernel forward /
+    15-kernel backward chain with fused epilogues).  This is the training hot path.
+
+Parameter gradients are ACCUMULATED IN PLACE into `param.grad` by the backward kernels (GEMM epilogue
+`+= C`, column-sum kernels with accumulate) instead of being returned to autograd: with the parameters living
+in one flat arena (cogview_amd/arena.py) `param.grad` is a view of one flat gradient buffer, so the
+data-parallel all-reduce, the overflow check, the norm and the Adam step are each ONE kernel / collective over
+that buffer (the reference does each per tensor: 388 tensors for the 24-layer model, 772 for 48 layers).
+"""
+import torch
+
+from . import ops
+from .mpu import mappings
+from .mpu import random as mpu_random
+from .mpu.initialize import get_model_parallel_group, mp_rank_or_0, mp_world_size_or_1
+
+
+def grad_buffer(p):
+    """The tensor backward kernels accumulate into (allocated zeroed on first use when no arena exists)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def _mp_allreduce(t):
+    if mp_world_size_or_1() > 1:
+        torch.distributed.all_reduce(t, group=get_model_parallel_group())
+    return t
+
+
+def _drop(p, training, attention=False):
+    """None or (p, seed, stream_id) drawn from the RNG tracker."""
+    if not training or p <= 0.0:
+        return None
+    seed, sid = mpu_random.attention_dropout_stream() if attention else mpu_random.next_dropout_stream()
+    return (p, seed, sid)
+
+
+# =============================================================================================== op level
+class _Linear(torch.autograd.Function):
+    """y = x W^T (+ b); W is [out, in] (F.linear convention, mpu/layers.py:243,319)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y = ops.gemm(x2, weight, bias=bias)
+        ctx.save_for_backward(x2, weight)
+        ctx.bias = bias
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dy2, weight, trans_b=True).view(ctx.xshape)
+        if weight.requires_grad:
+            ops.gemm(dy2, x2, trans_a=True, trans_b=True, out=grad_buffer(weight), accumulate=True)
+        if ctx.bias is not None and ctx.bias.requires_grad:
+            ops.colsum(dy2, out=grad_buffer(ctx.bias), accumulate=True)
+        return dx, None, None
+
+
+def linear(x, weight, bias=None):
+    return _Linear.apply(x, weight, bias)
+
+
+class _SandwichLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, absmax):
+        xc = x if x.is_contiguous() else x.contiguous()
+        if absmax is None:
+            absmax = ops.absmax(xc)
+        y, mean, rstd = ops.sandwich_ln_fwd(xc, weight, bias, eps, absmax)
+        ctx.save_for_backward(xc, weight, mean, rstd)
+        ctx.bias = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, weight, mean, rstd = ctx.saved_tensors
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        dg = grad_buffer(weight) if weight.requires_grad else None
+        db = grad_buffer(ctx.bias) if ctx.bias.requires_grad else None
+        dx = ops.sandwich_ln_bwd(dyc, xc, weight, mean, rstd, dgamma=dg, dbeta=db, accumulate=True)
+        return dx, None, None, None, None
+
+
+def sandwich_layer_norm(x, weight, bias, eps=1e-5):
+    """LayerNorm(x / (max|x| / 8)) -- mpu/sparse_transformer.py:40-44."""
+    return _SandwichLN.apply(x, weight, bias, eps, getattr(x, "_cogv_absmax", None))
+
+
+class _Attention(torch.autograd.Function):
+    """q [b,s_q,H,64], k/v [b,s_k,H,64] (strided views allowed) -> o [b,s_q,H,64]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, sep, dropout):
+        o, lse = ops.attention_fwd(q, k, v, sep=sep, dropout=dropout)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.sep, ctx.dropout = sep, dropout
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        doc = do if do.is_contiguous() else do.contiguous()
+        dq, dk, dv = ops.attention_bwd(doc, q, k, v, o, lse, sep=ctx.sep, dropout=ctx.dropout)
+        return dq, dk, dv, None, None
+
+
+def _as_bshd(t):
+    """[b, np, s, hn] (usually a permuted view of [b, s, np, hn]) -> [b, s, np, hn] with packed heads."""
+    u = t.permute(0, 2, 1, 3)
+    if u.stride(3) != 1 or (u.shape[2] > 1 and u.stride(2) != u.shape[3]):
+        u = u.contiguous()
+    return u
+
+
+def mask_to_sep(attention_mask, s_q, s_k):
+    """Translate the reference's mask argument into the kernel's `sep`:  an int is the reference's "sep" form
+    (mpu/sparse_transformer.py:477-489); a tensor must be the left-to-right mask (optionally with a visible
+    prefix), which is verified once per tensor object."""
+    if isinstance(attention_mask, int):
+        return attention_mask
+    if attention_mask.numel() == 1:
+        return int(attention_mask.item())
+    cached = getattr(attention_mask, "_cogv_sep", None)
+    if cached is not None and cached[0] == attention_mask._version:
+        return cached[1]
+    m = attention_mask.reshape(-1, s_q, s_k)[0] if attention_mask.numel() == s_q * s_k else None
+    if m is None:
+        raise NotImplementedError("per-sample attention masks are not supported by the HIP attention kernel")
+    off = s_k - s_q
+    n0 = int(m[0].sum().item())
+    sep = 0 if n0 <= off + 1 else n0 - off
+    ref = torch.ones(s_q, s_k, device=m.device, dtype=m.dtype)
+    ref[:, -s_q:] = torch.tril(ref[:, -s_q:])
+    if sep > 0:
+        ref[:, :sep + off] = 1
+    if not torch.equal(ref, m):
+        raise NotImplementedError(
+            "the HIP attention kernel implements the left-to-right mask with an optional fully visible prefix "
+            "(all masks the reference's training / generation paths build); got a different mask")
+    try:
+        attention_mask._cogv_sep = (attention_mask._version, sep)
+    except Exception:
+        pass
+    return sep
+
+
+def standard_attention(query_layer, key_layer, value_layer, attention_mask, attention_dropout=None):
+    """Drop-in for mpu/sparse_transformer.py:652-673; tensors are [b, np, s, hn] with hn = 64."""
+    s_q, s_k = query_layer.shape[2], key_layer.shape[2]
+    sep = mask_to_sep(attention_mask, s_q, s_k)
+    drop = None
+    if attention_dropout is not None:
+        drop = _drop(attention_dropout.p, attention_dropout.training, attention=True)
+    o = _Attention.apply(_as_bshd(query_layer), _as_bshd(key_layer), _as_bshd(value_layer), sep, drop)
+    return o.permute(0, 2, 1, 3)
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xc = x if x.is_contiguous() else x.contiguous()
+        ctx.save_for_backward(xc)
+        return ops.gelu_fwd(xc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        return ops.gelu_bwd(dy if dy.is_contiguous() else dy.contiguous(), x)
+
+
+def gelu(x):
+    return _Gelu.apply(x)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, drop):
+        ctx.drop = drop
+        return ops.dropout(x if x.is_contiguous() else x.contiguous(), *drop)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy if dy.is_contiguous() else dy.contiguous(), *ctx.drop), None
+
+
+def dropout(x, p, training=True):
+    drop = _drop(p, training)
+    return x if drop is None else _Dropout.apply(x, drop)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a if a.is_contiguous() else a.contiguous(), b if b.is_contiguous() else b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _Embedding(torch.autograd.Function):
+    """VocabParallelEmbedding (mpu/layers.py:117-133) optionally fused with the position add + embedding
+    dropout of GPT2ParallelTransformer.forward (mpu/sparse_transformer.py:522-524).
+    Returns (out, absmax slot)."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, vocab_start, pos_ids, pos_weight, drop):
+        mp = mp_world_size_or_1()
+        slot = ops.new_absmax_slot(weight.device)
+        if mp == 1:
+            out = ops.embedding_fwd(ids, weight, vocab_start, pos_ids, pos_weight, dropout=drop, absmax_out=slot)
+        else:
+            word = ops.embedding_fwd(ids, weight, vocab_start)
+            _mp_allreduce(word)
+            if pos_weight is not None or drop is not None:
+                out = ops.embedding_fwd(None, None, 0, pos_ids, pos_weight, dropout=drop, absmax_out=slot, x_in=word)
+            else:
+                out = word
+                ops.absmax(out, slot)
+        ctx.save_for_backward(ids, pos_ids if pos_weight is not None else None)
+        ctx.weight, ctx.pos_weight, ctx.vocab_start, ctx.drop = weight, pos_weight, vocab_start, drop
+        ctx.mark_non_differentiable(slot)
+        return out, slot
+
+    @staticmethod
+    def backward(ctx, dout, _):
+        ids, pos_ids = ctx.saved_tensors
+        w, pw = ctx.weight, ctx.pos_weight
+        dpos = grad_buffer(pw) if (pw is not None and pw.requires_grad) else None
+        dtab = grad_buffer(w) if w.requires_grad else None
+        ops.embedding_bwd(dout, ids, dtab, ctx.vocab_start, pos_ids, dpos, dropout=ctx.drop)
+        return None, None, None, None, None, None
+
+
+def embedding(ids, weight, vocab_start, pos_ids=None, pos_weight=None, drop=None):
+    out, slot = _Embedding.apply(ids, weight, vocab_start, pos_ids, pos_weight, drop)
+    out._cogv_absmax = slot
+    return out
+
+
+class _VocabParallelCrossEntropy(torch.autograd.Function):
+    """mpu/cross_entropy.py:25-104.  logits [..., V/p] in fp32 / fp16 / bf16 (read once, math in fp32);
+    the three model-parallel all-reduces (MAX, SUM, SUM) act on [rows] vectors of shard statistics."""
+
+    @staticmethod
+    def forward(ctx, logits, target, inplace_backward):
+        v = logits.shape[-1]
+        l2 = logits.reshape(-1, v)
+        if not l2.is_contiguous():
+            l2 = l2.contiguous()
+        t1 = target.reshape(-1).contiguous()
+        mp, rank = mp_world_size_or_1(), mp_rank_or_0()
+        vstart = rank * v
+        rowmax, sumexp, pred, loss = ops.ce_fwd(l2, t1, vstart, want_loss=(mp == 1))
+        if mp > 1:
+            group = get_model_parallel_group()
+            gmax = rowmax.clone()
+            torch.distributed.all_reduce(gmax, op=torch.distributed.ReduceOp.MAX, group=group)
+            packed = torch.stack((sumexp * torch.exp(rowmax - gmax), pred))
+            torch.distributed.all_reduce(packed, group=group)
+            gsum = packed[0].contiguous()
+            loss = torch.log(gsum) + gmax - packed[1]
+        else:
+            gmax, gsum = rowmax, sumexp
+        ctx.save_for_backward(l2, t1, gmax, gsum)
+        ctx.vstart, ctx.shape, ctx.inplace = vstart, logits.shape, inplace_backward
+        return loss.view(target.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        l2, t1, gmax, gsum = ctx.saved_tensors
+        gf = g.reshape(-1).float().contiguous()
+        d = ops.ce_bwd(l2, t1, ctx.vstart, gmax, gsum, gf, out=l2 if ctx.inplace else None)
+        return d.view(ctx.shape), None, None
+
+
+def vocab_parallel_cross_entropy(vocab_parallel_logits, target, inplace_backward=False):
+    return _VocabParallelCrossEntropy.apply(vocab_parallel_logits, target, inplace_backward)
+
+
+class _Logits(torch.autograd.Function):
+    """Tied output projection: logits = copy_to_mp(x) E^T (model/gpt2_modeling.py:115-118)."""
+
+    @staticmethod
+    def forward(ctx, x, emb_weight):
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, emb_weight)
+        ctx.xshape = x.shape
+        return ops.gemm(x2, emb_weight).view(*x.shape[:-1], emb_weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dl):
+        x2, w = ctx.saved_tensors
+        d2 = dl.reshape(-1, dl.shape[-1])
+        dx = _mp_allreduce(ops.gemm(d2, w, trans_b=True)).view(ctx.xshape)
+        if w.requires_grad:
+            ops.gemm(d2, x2, trans_a=True, trans_b=True, out=grad_buffer(w), accumulate=True)
+        return dx, None
+
+
+def tied_logits(x, emb_weight):
+    return _Logits.apply(x, emb_weight)
+
+
+# =============================================================================================== fused layer
+class _LayerCtx:
+    """Everything one layer's backward needs (activations + per-row LN statistics + dropout streams)."""
+    __slots__ = ("x", "a", "qkv", "att", "lse", "ao", "y", "c", "u", "g", "mo", "st1", "st2", "st3", "st4",
+                 "d_attn", "d_ao", "d_mo")
+
+
+def _layer_forward(layer, x, absmax_x, sep, drops, keep):
+    """x [b,s,h] -> (out, absmax_out); `keep` is a _LayerCtx to fill (None: inference, nothing retained).
+    Kernel chain (MP=1): LN1 | QKV GEMM+bias | attention | dense GEMM+bias+dropout+absmax | LN3+residual+absmax |
+    LN2 | h->4h GEMM+bias+GeLU | 4h->h GEMM+bias+dropout+absmax | LN4+residual+absmax."""
+    att_m, mlp_m = layer.attention, layer.mlp
+    b, s, h = x.shape
+    rows = b * s
+    mp, rank = mp_world_size_or_1(), mp_rank_or_0()
+    eps = layer.input_layernorm.eps
+    d_attn, d_ao, d_mo = drops
+    dev = x.device
+    npp = att_m.num_attention_heads_per_partition
+    hp = npp * 64
+
+    a, m1, r1 = ops.sandwich_ln_fwd(x, layer.input_layernorm.weight, layer.input_layernorm.bias, eps, absmax_x,
+                                    save_stats=keep is not None)
+    qkv = ops.gemm(a.view(rows, h), att_m.query_key_value.weight, bias=att_m.query_key_value.bias).view(b, s, 3 * hp)
+    q = qkv[:, :, 0:hp].view(b, s, npp, 64)
+    k = qkv[:, :, hp:2 * hp].view(b, s, npp, 64)
+    v = qkv[:, :, 2 * hp:].view(b, s, npp, 64)
+    att, lse = ops.attention_fwd(q, k, v, sep=sep, dropout=d_attn)
+
+    slot_ao = ops.new_absmax_slot(dev)
+    if mp == 1:
+        ao = ops.gemm(att.view(rows, hp), att_m.dense.weight, bias=att_m.dense.bias, dropout=d_ao, absmax=slot_ao)
+    else:
+        ao = ops.gemm(att.view(rows, hp), att_m.dense.weight, bias=att_m.dense.bias if rank == 0 else None)
+        _mp_allreduce(ao)
+        if d_ao is not None:
+            ao = ops.dropout(ao, *d_ao, absmax_out=slot_ao)
+        else:
+            ops.absmax(ao, slot_ao)
+    slot_y = ops.new_absmax_slot(dev)
+    y, m3, r3 = ops.sandwich_ln_fwd(ao.view(b, s, h), layer.third_layernorm.weight, layer.third_layernorm.bias, eps,
+                                    slot_ao, residual=x, absmax_out=slot_y, save_stats=keep is not None)
+    c, m2, r2 = ops.sandwich_ln_fwd(y, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.bias,
+                                    eps, slot_y, save_stats=keep is not None)
+    f4 = mlp_m.dense_h_to_4h.weight.shape[0]
+    u = torch.empty((rows, f4), dtype=x.dtype, device=dev) if keep is not None else None
+    g = ops.gemm(c.view(rows, h), mlp_m.dense_h_to_4h.weight, bias=mlp_m.dense_h_to_4h.bias, gelu=True, gelu_aux=u)
+    slot_mo = ops.new_absmax_slot(dev)
+    if mp == 1:
+        mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias, dropout=d_mo, absmax=slot_mo)
+    else:
+        mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias if rank == 0 else None)
+        _mp_allreduce(mo)
+        if d_mo is not None:
+            mo = ops.dropout(mo, *d_mo, absmax_out=slot_mo)
+        else:
+            ops.absmax(mo, slot_mo)
+    slot_out = ops.new_absmax_slot(dev)
+    out, m4, r4 = ops.sandwich_ln_fwd(mo.view(b, s, h), layer.fourth_layernorm.weight, layer.fourth_layernorm.bias,
+                                      eps, slot_mo, residual=y, absmax_out=slot_out, save_stats=keep is not None)
+    if keep is not None:
+        keep.x, keep.a, keep.qkv, keep.att, keep.lse, keep.ao, keep.y, keep.c = x, a, qkv, att, lse, ao, y, c
+        keep.u, keep.g, keep.mo = u, g, mo
+        keep.st1, keep.st2, keep.st3, keep.st4 = (m1, r1), (m2, r2), (m3, r3), (m4, r4)
+        keep.d_attn, keep.d_ao, keep.d_mo = d_attn, d_ao, d_mo
+    return out, slot_out
+
+
+def _layer_backward(layer, kp, dout, sep):
+    """dout [b,s,h] -> dx; parameter gradients are accumulated into param.grad."""
+    att_m, mlp_m = layer.attention, layer.mlp
+    b, s, h = kp.x.shape
+    rows = b * s
+    npp = att_m.num_attention_heads_per_partition
+    hp = npp * 64
+    G = grad_buffer
+    ln1, ln2, ln3, ln4 = (layer.input_layernorm, layer.post_attention_layernorm, layer.third_layernorm,
+                          layer.fourth_layernorm)
+    W1, b1, W2, b2 = mlp_m.dense_h_to_4h.weight, mlp_m.dense_h_to_4h.bias, mlp_m.dense_4h_to_h.weight, mlp_m.dense_4h_to_h.bias
+    Wq, bq, Wo, bo = att_m.query_key_value.weight, att_m.query_key_value.bias, att_m.dense.weight, att_m.dense.bias
+    dout = dout if dout.is_contiguous() else dout.contiguous()
+
+    # out = y + LN4(mo):  d_mo = mask(LN4'(dout)); bias grad of 4h->h = column sums of d_mo
+    d_mo = ops.sandwich_ln_bwd(dout, kp.mo, ln4.weight, *kp.st4, dropout=kp.d_mo, dgamma=G(ln4.weight),
+                               dbeta=G(ln4.bias), colsum=G(b2), accumulate=True).view(rows, h)
+    du = ops.gemm(d_mo, W2, trans_b=True, dgelu_aux=kp.u)                       # dgrad fused with dGeLU
+    ops.gemm(d_mo, kp.g, trans_a=True, trans_b=True, out=G(W2), accumulate=True)
+    dc = _mp_allreduce(ops.gemm(du, W1, trans_b=True))
+    ops.gemm(du, kp.c.view(rows, h), trans_a=True, trans_b=True, out=G(W1), accumulate=True)
+    ops.colsum(du, out=G(b1), accumulate=True)
+    # y feeds LN2 and the second residual:  dy = dout + LN2'(dc)
+    dy = ops.sandwich_ln_bwd(dc.view(b, s, h), kp.y, ln2.weight, *kp.st2, add_in=dout, dgamma=G(ln2.weight),
+                             dbeta=G(ln2.bias), accumulate=True)
+    # y = x + LN3(ao):  d_ao = mask(LN3'(dy))
+    d_ao = ops.sandwich_ln_bwd(dy, kp.ao, ln3.weight, *kp.st3, dropout=kp.d_ao, dgamma=G(ln3.weight),
+                               dbeta=G(ln3.bias), colsum=G(bo), accumulate=True).view(rows, h)
+    d_att = ops.gemm(d_ao, Wo, trans_b=True).view(b, s, npp, 64)
+    ops.gemm(d_ao, kp.att.view(rows, hp), trans_a=True, trans_b=True, out=G(Wo), accumulate=True)
+    qkv = kp.qkv
+    q = qkv[:, :, 0:hp].view(b, s, npp, 64)
+    k = qkv[:, :, hp:2 * hp].view(b, s, npp, 64)
+    v = qkv[:, :, 2 * hp:].view(b, s, npp, 64)
+    dqkv = torch.empty_like(qkv)
+    ops.attention_bwd(d_att, q, k, v, kp.att, kp.lse, sep=sep, dropout=kp.d_attn,
+                      dq=dqkv[:, :, 0:hp].view(b, s, npp, 64), dk=dqkv[:, :, hp:2 * hp].view(b, s, npp, 64),
+                      dv=dqkv[:, :, 2 * hp:].view(b, s, npp, 64))
+    dqkv2 = dqkv.view(rows, 3 * hp)
+    da = _mp_allreduce(ops.gemm(dqkv2, Wq, trans_b=True))
+    ops.gemm(dqkv2, kp.a.view(rows, h), trans_a=True, trans_b=True, out=G(Wq), accumulate=True)
+    ops.colsum(dqkv2, out=G(bq), accumulate=True)
+    dx = ops.sandwich_ln_bwd(da.view(b, s, h), kp.x, ln1.weight, *kp.st1, add_in=dy, dgamma=G(ln1.weight),
+                             dbeta=G(ln1.bias), accumulate=True)
+    return dx
+
+
+class _TransformerLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, absmax_x, layer, sep, drops, recompute, on_backward_done):
+        xc = x if x.is_contiguous() else x.contiguous()
+        keep = None if recompute else _LayerCtx()
+        out, slot = _layer_forward(layer, xc, absmax_x, sep, drops, keep)
+        ctx.layer, ctx.sep, ctx.drops, ctx.recompute, ctx.keep = layer, sep, drops, recompute, keep
+        ctx.done_cb = on_backward_done
+        if recompute:
+            ctx.save_for_backward(xc, absmax_x)
+        ctx.mark_non_differentiable(slot)
+        return out, slot
+
+    @staticmethod
+    def backward(ctx, dout, _):
+        keep = ctx.keep
+        if ctx.recompute:
+            # activation checkpointing (mpu/random.py:273-372): only the layer input was kept; the dropout
+            # streams are part of `drops`, so the recomputed forward replays identical masks
+            xc, absmax_x = ctx.saved_tensors
+            keep = _LayerCtx()
+            _layer_forward(ctx.layer, xc, absmax_x, ctx.sep, ctx.drops, keep)
+        dx = _layer_backward(ctx.layer, keep, dout, ctx.sep)
+        ctx.keep = None
+        if ctx.done_cb is not None:
+            ctx.done_cb(ctx.layer)
+        return dx, None, None, None, None, None, None
+
+
+def transformer_layer(layer, x, absmax_x, sep, training, recompute=False, on_backward_done=None):
+    """Fused GPT2ParallelTransformerLayer.forward (mpu/sparse_transformer.py:314-342), dense attention."""
+    p_attn = layer.attention.attention_dropout.p
+    p_out = layer.attention.output_dropout.p
+    p_mlp = layer.mlp.dropout.p
+    drops = (_drop(p_attn, training, attention=True), _drop(p_out, training), _drop(p_mlp, training))
+    if absmax_x is None:
+        absmax_x = ops.absmax(x if x.is_contiguous() else x.contiguous())
+    if torch.is_grad_enabled() and x.requires_grad:
+        out, slot = _TransformerLayer.apply(x, absmax_x, layer, sep, drops, recompute, on_backward_done)
+    else:
+        out, slot = _layer_forward(layer, x if x.is_contiguous() else x.contiguous(), absmax_x, sep, drops, None)
+    out._cogv_absmax = slot
+    return out

@@ -1,0 +1,64 @@
+"""clip_grad_norm with the semantics of mpu/grads.py:28-74: global norm over the model-parallel group with
+non-model-parallel parameters counted once (on model-parallel rank 0), in-place scaling by
+max_norm / (norm + 1e-6) when that is < 1.  The reference syncs with the host once per tensor
+(`.norm().item()`); here the sum of squares is one device kernel per tensor (or ONE kernel when the
+gradients live in a flat arena -- see fp16.FP16_Optimizer) and a single host read."""
+import torch
+
+from .. import ops
+from .initialize import get_model_parallel_group, mp_rank_or_0, mp_world_size_or_1
+
+inf = float('inf')
+
+
+def _one_chunk_table(t):
+    dev = t.device
+    return (torch.zeros(1, dtype=torch.int64, device=dev), torch.tensor([t.numel()], dtype=torch.int32, device=dev),
+            torch.ones(1, dtype=torch.uint8, device=dev))
+
+
+def clip_grad_norm(parameters, max_norm, norm_type=2):
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    parameters = [p for p in parameters if p.grad is not None]
+    max_norm, norm_type = float(max_norm), float(norm_type)
+    if not parameters:
+        return 0.0
+    dev = parameters[0].grad.device
+    mp = mp_world_size_or_1()
+    if norm_type == inf:
+        slot = ops.new_absmax_slot(dev)
+        for p in parameters:
+            g = p.grad.data
+            if g.dtype == torch.float32:
+                torch.maximum(slot, g.abs().max().reshape(1), out=slot)
+            else:
+                ops.absmax(g.contiguous(), slot)
+        total = slot.clone()
+        if mp > 1:
+            torch.distributed.all_reduce(total, op=torch.distributed.ReduceOp.MAX, group=get_model_parallel_group())
+        total_norm = total.item()
+    elif norm_type == 2.0:
+        stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        for p in parameters:
+            if getattr(p, 'model_parallel', False) or mp_rank_or_0() == 0:
+                g = p.grad.data
+                if g.dtype == torch.float32:
+                    # fp32 master gradients (FP16_Optimizer's non-arena path): torch reduction on a tiny API path
+                    stats[0] += g.double().pow(2).sum()
+                else:
+                    ops.grad_stats(g.contiguous().view(-1), *_one_chunk_table(g), stats)
+        if mp > 1:
+            torch.distributed.all_reduce(stats, group=get_model_parallel_group())
+        total_norm = float(stats[0].item()) ** 0.5
+    else:
+        raise NotImplementedError("clip_grad_norm: only the 2-norm and the inf-norm are used by the reference path")
+    clip_coef = max_norm / (total_norm + 1e-6)
+    if clip_coef < 1:
+        for p in parameters:
+            g = p.grad.data
+            if g.dtype == torch.float32 or g.numel() % 8 or not g.is_contiguous():
+                g.mul_(clip_coef)
+            else:
+                g.copy_(ops.scale(g, clip_coef))
+    return total_norm

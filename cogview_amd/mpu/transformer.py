@@ -1,0 +1,255 @@
+"""GPT-2 transformer with Sandwich-LN -- module surface of the reference's mpu/sparse_transformer.py
+(class names, constructor arguments, parameter names and shapes, forward signatures), HIP arithmetic.
+
+Forward paths:
+  * training / evaluation on whole sequences (no memories): each layer is ONE fused autograd Function
+    (cogview_amd.functional.transformer_layer);
+  * incremental decoding with `mems` (generation/sampling.py:64-186 keeps LAYER INPUTS as memories): the same
+    kernels composed op by op (no autograd needed there).
+Sparse attention (is_sparse = 1/2, mpu/sparse_transformer.py:675-750) is the next row of the scope table
+ and raises NotImplementedError.
+"""
+import math
+
+import torch
+
+from .. import functional as F_
+from .. import ops
+from .initialize import mp_world_size_or_1
+from .layers import ColumnParallelLinear, RowParallelLinear
+from .utils import divide, split_tensor_along_last_dim
+
+
+class LayerNorm(torch.nn.Module):
+    """Sandwich-LN primitive: LayerNorm(x / (max|x| / 8)) (mpu/sparse_transformer.py:40-44; the reference
+    subclasses apex FusedLayerNorm -- parameters `weight`, `bias`, attribute `eps`)."""
+
+    def __init__(self, normalized_shape, eps=1e-5, elementwise_affine=True):
+        super().__init__()
+        if isinstance(normalized_shape, int):
+            normalized_shape = (normalized_shape,)
+        assert len(normalized_shape) == 1 and elementwise_affine
+        self.normalized_shape = tuple(normalized_shape)
+        self.eps = eps
+        self.elementwise_affine = True
+        self.weight = torch.nn.Parameter(torch.ones(*normalized_shape))
+        self.bias = torch.nn.Parameter(torch.zeros(*normalized_shape))
+
+    def forward(self, x):
+        return F_.sandwich_layer_norm(x, self.weight, self.bias, self.eps)
+
+
+def gelu(x):
+    """OpenAI tanh GeLU (mpu/sparse_transformer.py:172-179)."""
+    return F_.gelu(x)
+
+
+standard_attention = F_.standard_attention
+
+
+class _Dropout(torch.nn.Module):
+    """torch.nn.Dropout stand-in (same `.p` / `.training` protocol) on the counter-based HIP dropout."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        return F_.dropout(x, self.p, self.training)
+
+
+class GPT2ParallelSelfAttention(torch.nn.Module):
+    """mpu/sparse_transformer.py:46-169."""
+
+    def __init__(self, hidden_size, num_attention_heads, attention_dropout_prob, output_dropout_prob, init_method,
+                 output_layer_init_method=None, query_window=128, key_window_times=6):
+        super().__init__()
+        if output_layer_init_method is None:
+            output_layer_init_method = init_method
+        world_size = mp_world_size_or_1()
+        self.hidden_size_per_partition = divide(hidden_size, world_size)
+        self.hidden_size_per_attention_head = divide(hidden_size, num_attention_heads)
+        self.num_attention_heads_per_partition = divide(num_attention_heads, world_size)
+        if self.hidden_size_per_attention_head != 64:
+            raise NotImplementedError("the HIP attention kernels are built for head dim 64 (every CogView config)")
+        self.query_window, self.key_window_times = query_window, key_window_times
+        self.query_key_value = ColumnParallelLinear(hidden_size, 3 * hidden_size, stride=3, gather_output=False,
+                                                    init_method=init_method)
+        self.attention_dropout = _Dropout(attention_dropout_prob)
+        self.dense = RowParallelLinear(hidden_size, hidden_size, input_is_parallel=True,
+                                       init_method=output_layer_init_method)
+        self.output_dropout = _Dropout(output_dropout_prob)
+
+    def _transpose_for_scores(self, tensor):
+        shape = tensor.size()[:-1] + (self.num_attention_heads_per_partition, self.hidden_size_per_attention_head)
+        return tensor.view(*shape).permute(0, 2, 1, 3)
+
+    def forward(self, hidden_states, ltor_mask, pivot_idx=None, is_sparse=0, mem=None):
+        if is_sparse:
+            raise NotImplementedError("sparse attention is not implemented yet (SURVEY.md section 8f, item 1)")
+        query_length = hidden_states.size(1)
+        src = hidden_states if mem is None else torch.cat((mem, hidden_states), 1)
+        mixed = self.query_key_value(src)
+        q, k, v = split_tensor_along_last_dim(mixed, 3)
+        if mem is not None:
+            q = q[:, -query_length:]
+        ctx = standard_attention(self._transpose_for_scores(q), self._transpose_for_scores(k),
+                                 self._transpose_for_scores(v), ltor_mask, self.attention_dropout)
+        ctx = ctx.permute(0, 2, 1, 3).contiguous()
+        ctx = ctx.view(*ctx.size()[:-2], self.hidden_size_per_partition)
+        return self.output_dropout(self.dense(ctx))
+
+
+class GPT2ParallelMLP(torch.nn.Module):
+    """mpu/sparse_transformer.py:189-234."""
+
+    def __init__(self, hidden_size, output_dropout_prob, init_method, output_layer_init_method=None):
+        super().__init__()
+        if output_layer_init_method is None:
+            output_layer_init_method = init_method
+        self.dense_h_to_4h = ColumnParallelLinear(hidden_size, 4 * hidden_size, gather_output=False,
+                                                  init_method=init_method)
+        self.dense_4h_to_h = RowParallelLinear(4 * hidden_size, hidden_size, input_is_parallel=True,
+                                               init_method=output_layer_init_method)
+        self.dropout = _Dropout(output_dropout_prob)
+
+    def forward(self, hidden_states):
+        return self.dropout(self.dense_4h_to_h(gelu(self.dense_h_to_4h(hidden_states))))
+
+
+class GPT2ParallelTransformerLayer(torch.nn.Module):
+    """mpu/sparse_transformer.py:237-342 (Sandwich-LN: four LayerNorms per layer)."""
+
+    def __init__(self, hidden_size, num_attention_heads, attention_dropout_prob, output_dropout_prob,
+                 layernorm_epsilon, init_method, output_layer_init_method=None, query_window=128, key_window_times=6,
+                 scale_normalization=True):
+        super().__init__()
+        if output_layer_init_method is None:
+            output_layer_init_method = init_method
+        self.input_layernorm = LayerNorm(hidden_size, eps=layernorm_epsilon)
+        self.attention = GPT2ParallelSelfAttention(hidden_size, num_attention_heads, attention_dropout_prob,
+                                                   output_dropout_prob, init_method,
+                                                   output_layer_init_method=output_layer_init_method,
+                                                   query_window=query_window, key_window_times=key_window_times)
+        self.post_attention_layernorm = LayerNorm(hidden_size, eps=layernorm_epsilon)
+        self.scale_normalization = scale_normalization
+        if scale_normalization:
+            self.third_layernorm = LayerNorm(hidden_size, eps=layernorm_epsilon)
+            self.fourth_layernorm = LayerNorm(hidden_size, eps=layernorm_epsilon)
+        self.mlp = GPT2ParallelMLP(hidden_size, output_dropout_prob, init_method,
+                                   output_layer_init_method=output_layer_init_method)
+
+    def forward(self, hidden_states, ltor_mask, pivot_idx=None, is_sparse=0, mem=None, recompute=False,
+                on_backward_done=None):
+        if is_sparse:
+            raise NotImplementedError("sparse attention is not implemented yet (SURVEY.md section 8f, item 1)")
+        if mem is None and self.scale_normalization:
+            s = hidden_states.size(1)
+            sep = F_.mask_to_sep(ltor_mask, s, s)
+            return F_.transformer_layer(self, hidden_states, getattr(hidden_states, "_cogv_absmax", None), sep,
+                                        self.training, recompute, on_backward_done)
+        # op-by-op composition (memories / no Sandwich-LN), exactly the reference's dataflow
+        a = self.input_layernorm(hidden_states)
+        mem = self.input_layernorm(mem) if mem is not None else None
+        att = self.attention(a, ltor_mask, pivot_idx, is_sparse, mem)
+        if self.scale_normalization:
+            att = self.third_layernorm(att)
+        y = F_.add(hidden_states, att)
+        m = self.mlp(self.post_attention_layernorm(y))
+        if self.scale_normalization:
+            m = self.fourth_layernorm(m)
+        return F_.add(y, m)
+
+
+def unscaled_init_method(sigma):
+    def init_(tensor):
+        return torch.nn.init.normal_(tensor, mean=0.0, std=sigma)
+    return init_
+
+
+def scaled_init_method(sigma, num_layers):
+    std = sigma / math.sqrt(2.0 * num_layers)
+
+    def init_(tensor):
+        return torch.nn.init.normal_(tensor, mean=0.0, std=std)
+    return init_
+
+
+class GPT2ParallelTransformer(torch.nn.Module):
+    """mpu/sparse_transformer.py:361-626."""
+
+    def __init__(self, num_layers, hidden_size, num_attention_heads, max_sequence_length, max_memory_length,
+                 embedding_dropout_prob, attention_dropout_prob, output_dropout_prob, checkpoint_activations,
+                 checkpoint_num_layers=1, layernorm_epsilon=1.0e-5, init_method_std=0.02,
+                 use_scaled_init_for_output_weights=True, query_window=128, key_window_times=6, num_pivot=768):
+        super().__init__()
+        self.checkpoint_activations = checkpoint_activations
+        self.checkpoint_num_layers = checkpoint_num_layers
+        self.max_memory_length = max_memory_length
+        self.max_sequence_length = max_sequence_length
+        output_layer_init_method = None
+        if use_scaled_init_for_output_weights:
+            output_layer_init_method = scaled_init_method(init_method_std, num_layers)
+        self.embedding_dropout = _Dropout(embedding_dropout_prob)
+        self.position_embeddings = torch.nn.Embedding(max_sequence_length, hidden_size)
+        torch.nn.init.normal_(self.position_embeddings.weight, mean=0.0, std=init_method_std)
+        self.query_window, self.key_window_times, self.num_pivot = query_window, key_window_times, num_pivot
+        self.layers = torch.nn.ModuleList([
+            GPT2ParallelTransformerLayer(hidden_size, num_attention_heads, attention_dropout_prob, output_dropout_prob,
+                                         layernorm_epsilon, unscaled_init_method(init_method_std),
+                                         output_layer_init_method=output_layer_init_method, query_window=query_window,
+                                         key_window_times=key_window_times, scale_normalization=True)
+            for _ in range(num_layers)])
+        self.final_layernorm = LayerNorm(hidden_size, eps=layernorm_epsilon)
+        self.rmask = None
+        self.on_layer_backward_done = None      # set by the data-parallel wrapper to overlap the all-reduce
+
+    def embed(self, input_ids, position_ids, word_embeddings):
+        """word + position embedding + embedding dropout in ONE kernel (mpu/layers.py:117-133 and
+        mpu/sparse_transformer.py:522-524); returns hidden states carrying their abs-max slot."""
+        drop = F_._drop(self.embedding_dropout.p, self.training)
+        return F_.embedding(input_ids, word_embeddings.weight, word_embeddings.vocab_start_index, position_ids,
+                            self.position_embeddings.weight, drop)
+
+    def forward(self, hidden_states, position_ids, attention_mask, txt_indices_bool, img_indices_bool, is_sparse=0,
+                *mems, embedded=False):
+        if is_sparse:
+            raise NotImplementedError("sparse attention is not implemented yet (SURVEY.md section 8f, item 1)")
+        batch_size, query_length = hidden_states.size()[:2]
+        memory_length = mems[0].size(1) if mems else 0
+        key_length = query_length + memory_length
+        if isinstance(attention_mask, torch.Tensor) and attention_mask.numel() > 1:
+            sep = F_.mask_to_sep(attention_mask, query_length, key_length)
+        else:
+            sep = int(attention_mask) if not isinstance(attention_mask, torch.Tensor) else int(attention_mask.item())
+        if not embedded:
+            # generic entry (hidden_states = word embeddings): position add + dropout, op by op
+            pos = F_.embedding(position_ids, self.position_embeddings.weight, 0)
+            hidden_states = F_.add(hidden_states, pos.expand_as(hidden_states).contiguous())
+            hidden_states = F_.dropout(hidden_states, self.embedding_dropout.p, self.training)
+        mem_layers = [hidden_states.detach()] if self.max_memory_length > 0 else []
+        recompute = bool(self.checkpoint_activations) and torch.is_grad_enabled()
+        for i, layer in enumerate(self.layers):
+            mem_i = mems[i] if mems else None
+            hidden_states = layer(hidden_states, sep, mem=mem_i, recompute=recompute,
+                                  on_backward_done=self.on_layer_backward_done)
+            if self.max_memory_length > 0:
+                mem_layers.append(hidden_states.detach())
+        output = self.final_layernorm(hidden_states)
+        if self.max_memory_length > 0:
+            mem_layers = self.update_mems(mem_layers, mems)
+        return (output, *mem_layers)
+
+    def update_mems(self, hiddens, mems):
+        """mpu/sparse_transformer.py:615-626."""
+        memory_length = mems[0].size(1) if mems else 0
+        query_length = hiddens[0].size(1)
+        new_memory_length = min(self.max_memory_length, memory_length + query_length)
+        new_mems = []
+        with torch.no_grad():
+            for i in range(len(hiddens)):
+                if new_memory_length <= query_length:
+                    new_mems.append(hiddens[i][:, -new_memory_length:])
+                else:
+                    new_mems.append(torch.cat((mems[i][:, -new_memory_length + query_length:], hiddens[i]), dim=1))
+        return new_mems

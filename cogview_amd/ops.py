@@ -73,6 +73,37 @@ def new_absmax_slot(device):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+_GEMM_TIMING = None      # list of (variant, flops, start_event, end_event) while bench.py's timed region runs
+
+
+def enable_gemm_timing():
+    """Bracket every cogv_gemm launch with HIP events on the launch stream (bench.py's roofline leg)."""
+    global _GEMM_TIMING
+    _GEMM_TIMING = []
+    return _GEMM_TIMING
+
+
+def collect_gemm_timing():
+    """Synchronise, resolve the events and return aggregate statistics; disables timing."""
+    global _GEMM_TIMING
+    rec, _GEMM_TIMING = _GEMM_TIMING, None
+    torch.cuda.synchronize()
+    tot_ms, tot_fl, by = 0.0, 0.0, {}
+    for variant, fl, s, e in rec:
+        ms = s.elapsed_time(e)
+        tot_ms += ms
+        tot_fl += fl
+        a = by.setdefault(variant, [0.0, 0.0, 0])
+        a[0] += fl
+        a[1] += ms
+        a[2] += 1
+    n = max(len(rec), 1)
+    return {"launches": len(rec), "total_ms": tot_ms, "avg_ms": tot_ms / n,
+            "tflops": tot_fl / max(tot_ms, 1e-9) / 1e9,
+            "by_variant": {k: {"tflops": v[0] / max(v[1], 1e-9) / 1e9, "launches": v[2], "avg_ms": v[1] / v[2]}
+                           for k, v in by.items()}}
+
+
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, gelu_aux=None, dgelu_aux=None,
          dropout=None, absmax=None, accumulate=False, splitk=None, out_dtype=None):
     """C[M,N] = epilogue(A_op[M,K] . B_op[N,K]^T); a, b 2-D, last dim contiguous.
@@ -129,7 +160,16 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
         nbytes = lib.cogv_gemm_workspace_bytes(C.byref(d))
         ws = workspace("gemm_splitk", nbytes, a.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-    L.check(lib.cogv_gemm(C.byref(d), _stream()), "cogv_gemm")
+    if _GEMM_TIMING is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        L.check(lib.cogv_gemm(C.byref(d), _stream()), "cogv_gemm")
+        ev1.record()
+        variant = ("T" if trans_a else "N") + ("T" if trans_b else "N")
+        _GEMM_TIMING.append(({"NN": "NT_fwd", "NT": "NN_dgrad", "TT": "TN_wgrad", "TN": "TN_other"}[variant],
+                             2.0 * M * N * K, ev0, ev1))
+    else:
+        L.check(lib.cogv_gemm(C.byref(d), _stream()), "cogv_gemm")
     return out
 
 
@@ -383,6 +423,7 @@ def adamw_step(params, grads, master, exp_avg, exp_avg_sq, chunk_start, chunk_le
     for i, (lr, wd) in enumerate(zip(lrs, wds)):
         d.lr[i], d.weight_decay[i] = float(lr), float(wd)
     d.beta1, d.beta2, d.eps = float(beta1), float(beta2), float(eps)
+    d.beta1_d, d.beta2_d = float(beta1), float(beta2)
     d.step, d.bias_correction, d.adam_w_mode = int(step), int(bias_correction), int(adam_w_mode)
     d.inv_loss_scale, d.max_grad_norm = float(inv_loss_scale), float(max_grad_norm)
     d.stats = None if stats is None else stats.data_ptr()

@@ -1,0 +1,55 @@
+"""FusedAdam -- stand-in for apex.optimizers.FusedAdam (reference call site pretrain_gpt2.py:43,139-140):
+Adam with decoupled weight decay (adam_w_mode=True), bias correction, betas (0.9, 0.999), eps 1e-8.
+
+Inside FP16_Optimizer with arena-backed parameters the whole update is ONE HIP kernel over flat buffers
+(unscale + clip + AdamW + cast to the 16-bit model parameters: cogv_adamw_step).  Stand-alone use on
+arbitrary fp32 parameters takes the same update rule through torch tensor ops (API completeness, not the
+hot path)."""
+import torch
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, bias_correction=True, betas=(0.9, 0.999), eps=1e-8, adam_w_mode=True,
+                 weight_decay=0., amsgrad=False, set_grad_none=True):
+        if amsgrad:
+            raise RuntimeError('FusedAdam does not support the AMSGrad variant.')
+        defaults = dict(lr=lr, bias_correction=bias_correction, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.adam_w_mode = 1 if adam_w_mode else 0
+        self.set_grad_none = set_grad_none
+
+    def zero_grad(self, set_to_none=None):
+        if set_to_none is None:
+            set_to_none = self.set_grad_none
+        super().zero_grad(set_to_none=set_to_none)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            beta1, beta2 = group['betas']
+            group['step'] = group.get('step', 0) + 1
+            step = group['step']
+            bc1 = 1 - beta1 ** step if group['bias_correction'] else 1.0
+            bc2 = 1 - beta2 ** step if group['bias_correction'] else 1.0
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                g = p.grad.float()
+                st = self.state[p]
+                if len(st) == 0:
+                    st['exp_avg'] = torch.zeros_like(p, dtype=torch.float32)
+                    st['exp_avg_sq'] = torch.zeros_like(p, dtype=torch.float32)
+                m, v = st['exp_avg'], st['exp_avg_sq']
+                if not self.adam_w_mode:
+                    g = g.add(p.float(), alpha=group['weight_decay'])
+                m.mul_(beta1).add_(g, alpha=1 - beta1)
+                v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+                upd = (m / bc1) / ((v / bc2).sqrt() + group['eps'])
+                if self.adam_w_mode:
+                    upd.add_(p.float(), alpha=group['weight_decay'])
+                p.add_(upd.to(p.dtype), alpha=-group['lr'])
+        return loss

@@ -172,6 +172,7 @@ typedef struct cogv_adam_desc {
   const int64_t* chunk_start; const int32_t* chunk_len; const uint8_t* chunk_group; int nchunks;
   float lr[8]; float weight_decay[8];
   float beta1, beta2, eps; int step; int bias_correction; int adam_w_mode;
+  double beta1_d, beta2_d;         /* the same betas in double (1-beta and beta^step are formed in double) */
   float inv_loss_scale;            /* grads are multiplied by this */
   float max_grad_norm;             /* > 0: clip by global norm computed from stats */
   const double* stats;             /* from cogv_grad_stats (device); stats[1] != 0 => whole step skipped */

@@ -1,0 +1,371 @@
+"""GPU parity: every HIP kernel (through the C ABI) against the CPU oracle on seeded inputs.
+
+Tolerances (relative L2 error ||hip - oracle|| / ||oracle||, oracle in fp32 on the inputs rounded to the
+storage type): fp16 3e-3, bf16 2e-2 for single kernels whose output is rounded once to 16 bits
+(bf16 has 8 significant bits: 2^-9 = 2e-3 per element before any accumulation effects).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cogview_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: 3e-3, torch.bfloat16: 2e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X; run with -m 'not gpu' elsewhere"
+    from cogview_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def rnd(shape, dtype, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (510, 768, 256), (300, 136, 72), (1088, 1024, 1024), (64, 2560, 2560)])
+def test_gemm_nt_bias(ops, dtype, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a, b, bias = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 0.1), rnd((N,), dtype, g)
+    ref = O.linear(a.float(), b.float(), bias.float())
+    out = ops.gemm(dev(a), dev(b), bias=dev(bias))
+    assert rel(out, ref) < TOL[dtype]
+    out1 = ops.gemm(dev(a), dev(b), bias=dev(bias), splitk=1)
+    assert rel(out1, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_asymmetric_identity(ops, dtype):
+    """A = I with an asymmetric B catches transposed C writes / operand swaps."""
+    n = 256
+    a = torch.eye(n).to(dtype)
+    b = (torch.arange(n).view(n, 1) * 0.01 + torch.arange(n).view(1, n) * 0.5).to(dtype)   # b[j][k]
+    out = ops.gemm(dev(a), dev(b))          # C[m][j] = sum_k I[m][k] b[j][k] = b[j][m]
+    assert torch.equal(out.cpu(), b.t().contiguous())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(510, 256, 768), (1088, 1024, 3072), (136, 72, 304)])
+def test_gemm_dgrad_nn(ops, dtype, M, N, K):
+    """dX[M,N] = dY[M,K] W[K,N]  (trans_b: B stored [K][N])."""
+    g = torch.Generator().manual_seed(K)
+    dy, w = rnd((M, K), dtype, g), rnd((K, N), dtype, g, 0.1)
+    ref = dy.float() @ w.float()
+    assert rel(ops.gemm(dev(dy), dev(w), trans_b=True), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,splitk", [(768, 256, 510, 1), (1024, 1024, 4352, None), (72, 136, 300, 3), (3072, 1024, 2176, 4)])
+def test_gemm_wgrad_tn(ops, dtype, M, N, K, splitk):
+    """dW[M,N] = dY[K,M]^T X[K,N]  (both operands stored contraction-major)."""
+    g = torch.Generator().manual_seed(K + 1)
+    dy, x = rnd((K, M), dtype, g), rnd((K, N), dtype, g)
+    ref = dy.float().t() @ x.float()
+    out = ops.gemm(dev(dy), dev(x), trans_a=True, trans_b=True, splitk=splitk)
+    assert rel(out, ref) < TOL[dtype]
+    # accumulate into an existing gradient
+    prev = rnd((M, N), dtype, g, 5.0)
+    acc = dev(prev.clone())
+    ops.gemm(dev(dy), dev(x), trans_a=True, trans_b=True, out=acc, accumulate=True, splitk=splitk)
+    assert rel(acc, ref + prev.float()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_gelu_dgelu_epilogues(ops, dtype):
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 320, 512, 128
+    a, w, bias = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 0.2), rnd((N,), dtype, g)
+    u_ref = O.linear(a.float(), w.float(), bias.float())
+    aux = torch.empty((M, N), dtype=dtype, device="cuda")
+    out = ops.gemm(dev(a), dev(w), bias=dev(bias), gelu=True, gelu_aux=aux)
+    assert rel(aux, u_ref) < TOL[dtype]
+    assert rel(out, O.gelu(aux.float().cpu())) < TOL[dtype]          # activation of the stored pre-activation
+    # dgelu epilogue: out = (dy @ w2) * gelu'(u)
+    dy, w2 = rnd((M, K), dtype, g), rnd((K, N), dtype, g, 0.2)
+    u = aux.float().cpu().requires_grad_(True)
+    O.gelu(u).backward(torch.ones_like(u))
+    ref = (dy.float() @ w2.float()) * u.grad
+    out2 = ops.gemm(dev(dy), dev(w2), trans_b=True, dgelu_aux=aux)
+    assert rel(out2, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_dropout_absmax(ops, dtype):
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 200, 384, 64
+    a, w = rnd((M, K), dtype, g), rnd((N, K), dtype, g)
+    ref = a.float() @ w.float().t()
+    mask = torch.from_numpy(O.dropout_keep_mask(M * N, 0.1, 99, 5)).view(M, N)
+    slot = ops.new_absmax_slot(torch.device("cuda"))
+    out = ops.gemm(dev(a), dev(w), dropout=(0.1, 99, 5), absmax=slot)
+    assert torch.equal((out.cpu() == 0), (mask == 0) | (out.cpu() == 0))
+    assert rel(out, ref * mask) < TOL[dtype]
+    assert abs(slot.item() - out.float().abs().max().item()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,h", [(60, 128), (1088, 1024), (257, 2560), (33, 256), (17, 4096)])
+def test_sandwich_ln_fwd_bwd(ops, dtype, rows, h):
+    g = torch.Generator().manual_seed(h + rows)
+    x = rnd((rows, h), dtype, g, 3.0)
+    w = (torch.rand(h, generator=g) + 0.5).to(dtype)
+    b = rnd((h,), dtype, g, 0.1)
+    dy = rnd((rows, h), dtype, g)
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    yr = O.sandwich_layernorm(xr, wr, br, 1e-5)
+    yr.backward(dy.float())
+    xd = dev(x)
+    amax = ops.absmax(xd)
+    assert amax.item() == x.float().abs().max().item()
+    y, mean, rstd = ops.sandwich_ln_fwd(xd, dev(w), dev(b), 1e-5, amax)
+    assert rel(y, yr) < TOL[dtype]
+    dg = torch.zeros(h, dtype=dtype, device="cuda")
+    db = torch.zeros(h, dtype=dtype, device="cuda")
+    dx = ops.sandwich_ln_bwd(dev(dy), xd, dev(w), mean, rstd, dgamma=dg, dbeta=db)
+    assert rel(dx, xr.grad) < TOL[dtype] * 2
+    assert rel(dg, wr.grad) < TOL[dtype] * 2
+    assert rel(db, br.grad) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sandwich_ln_fused_residual_dropout_colsum(ops, dtype):
+    g = torch.Generator().manual_seed(11)
+    rows, h = 300, 512
+    x, res = rnd((rows, h), dtype, g, 2.0), rnd((rows, h), dtype, g)
+    w, b = (torch.rand(h, generator=g) + 0.5).to(dtype), rnd((h,), dtype, g, 0.1)
+    xd = dev(x)
+    amax = ops.absmax(xd)
+    slot = ops.new_absmax_slot(xd.device)
+    y, mean, rstd = ops.sandwich_ln_fwd(xd, dev(w), dev(b), 1e-5, amax, residual=dev(res), absmax_out=slot)
+    ln = O.sandwich_layernorm(x.float(), w.float(), b.float()).to(dtype).float()
+    assert rel(y, res.float() + ln) < TOL[dtype]
+    assert slot.item() == y.float().abs().max().item()
+    # backward with dropout mask replay, residual-gradient add and column sums
+    dy, add_in = rnd((rows, h), dtype, g), rnd((rows, h), dtype, g)
+    xr = x.float().requires_grad_(True)
+    O.sandwich_layernorm(xr, w.float(), b.float()).backward(dy.float())
+    mask = torch.from_numpy(O.dropout_keep_mask(rows * h, 0.1, 7, 3)).view(rows, h)
+    cs = torch.zeros(h, dtype=dtype, device="cuda")
+    dx = ops.sandwich_ln_bwd(dev(dy), xd, dev(w), mean, rstd, add_in=dev(add_in), dropout=(0.1, 7, 3), colsum=cs)
+    ref = xr.grad * mask + add_in.float()
+    assert rel(dx, ref) < TOL[dtype] * 2
+    assert rel(cs, dx.float().cpu().sum(0)) < TOL[dtype] * 2
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, sep, drop=None, dout=None):
+    """q,k,v [b,s,H,64] -> oracle on [b,H,s,64]."""
+    qr, kr, vr = [t.float().permute(0, 2, 1, 3).contiguous().requires_grad_(True) for t in (q, k, v)]
+    mask = O.build_mask(q.shape[1], k.shape[1], sep)
+    o = O.standard_attention(qr, kr, vr, mask, drop)
+    if dout is not None:
+        o.backward(dout.float().permute(0, 2, 1, 3))
+        return o.permute(0, 2, 1, 3), [t.grad.permute(0, 2, 1, 3) for t in (qr, kr, vr)]
+    return o.permute(0, 2, 1, 3), None
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,H,s_q,s_k,sep", [(2, 2, 40, 40, 0), (1, 3, 200, 200, 0), (2, 1, 24, 40, 5), (1, 2, 321, 321, 0),
+                                             (1, 1, 1, 77, 0), (1, 2, 130, 130, 37)])
+def test_attention_fwd_bwd(ops, dtype, b, H, s_q, s_k, sep):
+    g = torch.Generator().manual_seed(s_q * 3 + s_k)
+    # q/k/v as strided views of one [b, s, 3*H*64] buffer, exactly how the QKV GEMM output is consumed
+    qkv = rnd((b, s_k, 3 * H * 64), dtype, g)
+    q = qkv[:, s_k - s_q:, 0:H * 64].reshape(b, s_q, H, 64)
+    k = qkv[:, :, H * 64:2 * H * 64].reshape(b, s_k, H, 64)
+    v = qkv[:, :, 2 * H * 64:].reshape(b, s_k, H, 64)
+    dout = rnd((b, s_q, H, 64), dtype, g)
+    o_ref, grads = _attn_ref(q, k, v, sep, None, dout)
+    qkv_d = dev(qkv)
+    qd = qkv_d[:, s_k - s_q:, 0:H * 64].view(b, s_q, H, 64)
+    kd = qkv_d[:, :, H * 64:2 * H * 64].view(b, s_k, H, 64)
+    vd = qkv_d[:, :, 2 * H * 64:].view(b, s_k, H, 64)
+    o, lse = ops.attention_fwd(qd, kd, vd, sep=sep)
+    assert rel(o, o_ref) < TOL[dtype]
+    dq, dk, dv = ops.attention_bwd(dev(dout), qd, kd, vd, o, lse, sep=sep)
+    for name, got, want in zip("qkv", (dq, dk, dv), grads):
+        assert rel(got, want) < TOL[dtype] * 2, name
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_dropout_mask_replay(ops, dtype):
+    g = torch.Generator().manual_seed(21)
+    b, H, s = 2, 2, 96
+    q, k, v, dout = [rnd((b, s, H, 64), dtype, g) for _ in range(4)]
+    drop = torch.from_numpy(O.attention_keep_mask(b, H, s, s, 0.1, 31, 9))
+    o_ref, grads = _attn_ref(q, k, v, 0, drop, dout)
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    o, lse = ops.attention_fwd(qd, kd, vd, dropout=(0.1, 31, 9))
+    assert rel(o, o_ref) < TOL[dtype]
+    dq, dk, dv = ops.attention_bwd(dev(dout), qd, kd, vd, o, lse, dropout=(0.1, 31, 9))
+    for name, got, want in zip("qkv", (dq, dk, dv), grads):
+        assert rel(got, want) < TOL[dtype] * 2, name
+
+
+def test_attention_full_length_properties(ops):
+    """s = 1088 (BASELINE sequence): causal property -- output at position i must not change when
+    later keys/values change; checked bit-exactly."""
+    g = torch.Generator().manual_seed(5)
+    b, H, s = 1, 2, 1088
+    q, k, v = [dev(rnd((b, s, H, 64), torch.float16, g)) for _ in range(3)]
+    o1, _ = ops.attention_fwd(q, k, v)
+    k2, v2 = k.clone(), v.clone()
+    k2[:, 600:] = 7.0
+    v2[:, 600:] = -3.0
+    o2, _ = ops.attention_fwd(q, k2, v2)
+    assert torch.equal(o1[:, :600], o2[:, :600])
+    assert not torch.equal(o1[:, 600:], o2[:, 600:])
+    assert torch.isfinite(o1.float()).all()
+
+
+# ------------------------------------------------------------------------------------------------ embedding
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embedding_fwd_bwd(ops, dtype):
+    g = torch.Generator().manual_seed(6)
+    V, P, h, b, s = 96, 48, 128, 2, 40
+    table, pos_table = rnd((V, h), dtype, g), rnd((P, h), dtype, g)
+    ids = torch.randint(0, 128, (b, s), generator=g)          # some ids outside the shard [16, 112)
+    pos = torch.arange(s).unsqueeze(0).expand(b, -1)
+    vs = 16
+    inside = (ids >= vs) & (ids < vs + V)
+    word = torch.where(inside.unsqueeze(-1), table.float()[(ids - vs).clamp(0, V - 1)], torch.zeros(1))
+    ref = (word + pos_table.float()[pos]).to(dtype).float()
+    mask = torch.from_numpy(O.dropout_keep_mask(b * s * h, 0.1, 3, 1)).view(b, s, h)
+    slot = ops.new_absmax_slot(torch.device("cuda"))
+    out = ops.embedding_fwd(dev(ids), dev(table), vs, dev(pos), dev(pos_table), dropout=(0.1, 3, 1), absmax_out=slot)
+    assert rel(out, ref * mask) < TOL[dtype]
+    assert slot.item() == out.float().abs().max().item()
+    dout = rnd((b, s, h), dtype, g)
+    dt = torch.zeros((V, h), dtype=dtype, device="cuda")
+    dp = torch.zeros((P, h), dtype=dtype, device="cuda")
+    ops.embedding_bwd(dev(dout), dev(ids), dt, vs, dev(pos), dp, dropout=(0.1, 3, 1))
+    dm = dout.float() * mask
+    rt = torch.zeros(V, h).index_add_(0, (ids - vs).clamp(0, V - 1).view(-1), (dm * inside.unsqueeze(-1)).view(-1, h))
+    rp = torch.zeros(P, h).index_add_(0, pos.reshape(-1), dm.view(-1, h))
+    assert rel(dt, rt) < TOL[dtype] * 3
+    assert rel(dp, rp) < TOL[dtype] * 3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise(ops, dtype):
+    g = torch.Generator().manual_seed(8)
+    x, dy = rnd((33, 256), dtype, g, 2.0), rnd((33, 256), dtype, g)
+    assert rel(ops.gelu_fwd(dev(x)), O.gelu(x.float())) < TOL[dtype]
+    xr = x.float().requires_grad_(True)
+    O.gelu(xr).backward(dy.float())
+    assert rel(ops.gelu_bwd(dev(dy), dev(x)), xr.grad) < TOL[dtype]
+    mask = torch.from_numpy(O.dropout_keep_mask(x.numel(), 0.25, 1, 2)).view_as(x)
+    assert rel(ops.dropout(dev(x), 0.25, 1, 2), x.float() * mask) < TOL[dtype]
+    assert rel(ops.add(dev(x), dev(dy)), x.float() + dy.float()) < TOL[dtype]
+    assert rel(ops.colsum(dev(x)), x.float().sum(0)) < TOL[dtype]
+    big = rnd((2000, 1024), dtype, g)
+    assert rel(ops.colsum(dev(big)), big.float().sum(0)) < TOL[dtype]
+
+
+# ------------------------------------------------------------------------------------------------ CE
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,V", [(14, 96), (80, 58240), (5, 29184)])
+def test_cross_entropy(ops, dtype, rows, V):
+    g = torch.Generator().manual_seed(V)
+    logits = (torch.randn(rows, V, generator=g) * 4).to(dtype)
+    tgt = torch.randint(0, V, (rows,), generator=g)
+    lr = logits.float().requires_grad_(True)
+    ce = O.vocab_parallel_cross_entropy(lr, tgt)
+    w = torch.rand(rows, generator=g)
+    (ce * w).sum().backward()
+    rowmax, sumexp, pred, loss = ops.ce_fwd(dev(logits), dev(tgt), 0)
+    assert rel(loss, ce) < 1e-5
+    d = ops.ce_bwd(dev(logits), dev(tgt), 0, rowmax, sumexp, dev(w))
+    tol = 1e-5 if dtype == torch.float32 else TOL[dtype]
+    assert rel(d, lr.grad) < tol
+    # two-shard statistics combine to the same loss (plays the 3 all-reduces of mpu/cross_entropy.py)
+    half = V // 2
+    if half % 8 == 0:
+        a = ops.ce_fwd(dev(logits[:, :half].contiguous()), dev(tgt), 0, want_loss=False)
+        b = ops.ce_fwd(dev(logits[:, half:].contiguous()), dev(tgt), half, want_loss=False)
+        gm = torch.maximum(a[0], b[0])
+        gs = a[1] * torch.exp(a[0] - gm) + b[1] * torch.exp(b[0] - gm)
+        loss2 = torch.log(gs) + gm - (a[2] + b[2])
+        assert rel(loss2, ce) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_grad_stats_and_adamw(ops, dtype):
+    g = torch.Generator().manual_seed(12)
+    sizes = [1000, 24, 4096, 130, 70000]
+    offs, o = [], 0
+    for s in sizes:
+        offs.append(o)
+        o += (s + 127) // 128 * 128
+    total = o
+    p32 = torch.zeros(total)
+    grads = torch.zeros(total)
+    for s, of in zip(sizes, offs):
+        p32[of:of + s] = torch.randn(s, generator=g)
+        grads[of:of + s] = torch.randn(s, generator=g) * 64.0
+    p16 = p32.to(dtype)
+    g16 = grads.to(dtype)
+    # chunk table: chunks of <= 32768 elements, groups: tensors 0,2,4 decay (group 0), 1,3 no decay (group 1)
+    cs, cl, cg, cn = [], [], [], []
+    for i, (s, of) in enumerate(zip(sizes, offs)):
+        for c0 in range(0, s, 32768):
+            cs.append(of + c0)
+            cl.append(min(32768, s - c0))
+            cg.append(i % 2)
+            cn.append(0 if i == 3 else 1)          # tensor 3 excluded from the norm (MP dedup)
+    D = "cuda"
+    cs_t, cl_t = torch.tensor(cs, dtype=torch.int64, device=D), torch.tensor(cl, dtype=torch.int32, device=D)
+    cg_t, cn_t = torch.tensor(cg, dtype=torch.uint8, device=D), torch.tensor(cn, dtype=torch.uint8, device=D)
+    stats = torch.zeros(2, dtype=torch.float64, device=D)
+    ops.grad_stats(dev(g16), cs_t, cl_t, cn_t, stats)
+    ref_sq = sum(float((g16[of:of + s].double() ** 2).sum()) for i, (s, of) in enumerate(zip(sizes, offs)) if i != 3)
+    assert abs(stats[0].item() - ref_sq) < 1e-5 * ref_sq and stats[1].item() == 0.0
+    # oracle: unscale by 1/64, clip to 1.0, AdamW with per-group weight decay, 2 steps
+    lr, wd, scale, max_norm = 1e-2, 0.1, 64.0, 1.0
+    master = p16.float().clone()
+    m, v = torch.zeros(total), torch.zeros(total)
+    pd, gd = dev(p16.clone()), dev(g16)
+    md, ed, vd = dev(master.clone()), dev(m.clone()), dev(v.clone())
+    for step in (1, 2):
+        gs = [g16[of:of + s].float() / scale for s, of in zip(sizes, offs)]
+        norm = math.sqrt(sum(float(x.double().norm() ** 2) for i, x in enumerate(gs) if i != 3))
+        coef = max_norm / (norm + 1e-6)
+        for i, (s, of) in enumerate(zip(sizes, offs)):
+            gi = gs[i] * coef if coef < 1 else gs[i]
+            O.adamw_step(master[of:of + s], gi, m[of:of + s], v[of:of + s], step, lr, weight_decay=wd if i % 2 == 0 else 0.0)
+        stats.zero_()
+        ops.grad_stats(gd, cs_t, cl_t, cn_t, stats)
+        ops.adamw_step(pd, gd, md, ed, vd, cs_t, cl_t, cg_t, [lr, lr], [wd, 0.0], 0.9, 0.999, 1e-8, step,
+                       inv_loss_scale=1.0 / scale, max_grad_norm=max_norm, stats=stats)
+    assert rel(md, master) < 1e-5
+    assert rel(ed, m) < 1e-5 and rel(vd, v) < 1e-5
+    assert torch.equal(pd.cpu(), md.cpu().to(dtype))
+    # overflow: an inf anywhere flags the step and the kernel leaves everything untouched
+    gbad = g16.clone()
+    gbad[offs[2] + 5] = float("inf")
+    stats.zero_()
+    ops.grad_stats(dev(gbad), cs_t, cl_t, cn_t, stats)
+    assert stats[1].item() == 1.0
+    before = md.clone()
+    ops.adamw_step(pd, dev(gbad), md, ed, vd, cs_t, cl_t, cg_t, [lr, lr], [wd, 0.0], 0.9, 0.999, 1e-8, 3,
+                   inv_loss_scale=1.0 / scale, max_grad_norm=max_norm, stats=stats)
+    assert torch.equal(before, md)

