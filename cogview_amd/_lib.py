@@ -65,6 +65,16 @@ class AdamDesc(C.Structure):
     ]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int), ("B", C.c_int), ("IH", C.c_int), ("IW", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+        ("relu", C.c_int),
+        ("in", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+    ]
+
+
+CONV_4X4_S2, CONV_1X1, CONVT_4X4_S2 = 0, 1, 2
+
 _vp, _i, _f, _u64, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_int64, C.c_size_t
 
 # name -> (restype, argtypes).  Mirrors include/cogview_hip.h one-to-one (tests/test_abi.py checks this).
@@ -97,6 +107,11 @@ SIGNATURES = {
     "cogv_adamw_step": (_i, [C.POINTER(AdamDesc), _vp]),
     "cogv_cast_flat": (_i, [_i, _vp, _vp, _sz, _vp]),
     "cogv_cast_flat_back": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "cogv_conv2d_nhwc_f32": (_i, [C.POINTER(ConvDesc), _vp]),
+    "cogv_vq_argmin_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "cogv_nchw3_to_nhwc4_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "cogv_embed_code_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "cogv_conv1x1_to_rgb_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
 }
 
 _lib = None

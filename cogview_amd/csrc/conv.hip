@@ -1,0 +1,396 @@
+// VQ-VAE tokenizer kernels (reference vqvae/vqvae_zc.py, production config vqvae/api.py:12-20:
+// channel 512, embed_dim 256, n_embed 8192, stride 6 -> three 4x4 stride-2 convs + 1x1, quantise,
+// three 4x4 stride-2 transposed convs + 1x1).  gfx950, fp32 end to end.
+//
+// Why fp32: the reference runs the tokenizer in fp32 and the token id is an argmin over fp32 distances; the
+// north star asks for ids that match the CPU path.  CDNA4 has an exact-fp32 MFMA (v_mfma_f32_32x32x2_f32,
+// 157 TFLOP/s peak = 16x below bf16 MFMA, bit-for-bit an fmaf chain), so the convolutions stay on the matrix
+// cores without giving up fp32 products/accumulation.  Only the summation ORDER differs from the CPU path.
+//
+// One implicit-GEMM kernel covers every layer through a tap table:
+//     out[b, y*om+oy, x*om+ox, co] = act( bias[co] + sum_t sum_ci in[b, y*im+dy[t], x*im+dx[t], ci] * W[co][t][ci] )
+//   4x4 stride-2 pad-1 conv   : im=2, om=1, 16 taps (dy,dx) = (ky-1, kx-1)
+//   1x1 conv                  : im=1, om=1, 1 tap
+//   4x4 stride-2 pad-1 convT  : 4 output parities (blockIdx.z), each a 2x2-tap conv at input resolution
+//                               (sub-pixel decomposition), im=1, om=2
+// Activations are NHWC fp32 (channels contiguous = the contraction index contiguous), weights are repacked
+// once on the host side to [parity][Cout][tap][Cin].  Tile 128 pixels x 128 channels x 32 (k), 4 waves,
+// 2x2 MFMA 32x32 per wave, LDS rows of 128 B with the same XOR swizzle as the 16-bit GEMM.
+// The k-slot relabelling trick (attention.hip) lets one ds_read_b128 feed four MFMA k-steps.
+#include "common.cuh"
+#include "cogview_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;   // BK in floats (128 B per LDS row)
+constexpr int NT = 256;
+
+struct ConvArgs {
+  const float* in; const float* w; const float* bias; float* out;
+  int B, IH, IW, Cin;
+  int GH, GW;               // iteration grid (pixels per image = GH*GW)
+  int OH, OW, Cout;
+  int in_mul, out_mul;
+  int ntaps;
+  int8_t dy[4][16], dx[4][16];
+  int8_t ooy[4], oox[4];
+  long long w_parity_stride;
+  int relu_out;
+  int K;                    // ntaps * Cin
+  int M;                    // B * GH * GW
+};
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// A tile: 128 pixels x 32 k.  thread -> (row = t/8 + 32p, chunk = t%8); chunk = 4 consecutive k = 4 channels of one tap
+__device__ __forceinline__ void load_a(const ConvArgs& p, int z, int m0, int k0, f32x4 (&r)[4]) {
+  const int t = threadIdx.x;
+  const int k = k0 + (t & 7) * 4;
+  const int tap = k / p.Cin, ci = k - tap * p.Cin;
+  const bool kok = k < p.K;
+  const int dy = kok ? p.dy[z][tap] : 0, dx = kok ? p.dx[z][tap] : 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int m = m0 + (t >> 3) + 32 * q;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (kok && m < p.M) {
+      const int b = m / (p.GH * p.GW);
+      const int rem = m - b * (p.GH * p.GW);
+      const int y = rem / p.GW, x = rem - y * p.GW;
+      const int iy = y * p.in_mul + dy, ix = x * p.in_mul + dx;
+      if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+        v = ld4(p.in + (((size_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci);
+    }
+    r[q] = v;
+  }
+}
+// B tile: 128 output channels x 32 k from W[z][co][K]
+__device__ __forceinline__ void load_b(const float* w, int ldw, int n0, int N, int k0, int K, f32x4 (&r)[4]) {
+  const int t = threadIdx.x;
+  const int k = k0 + (t & 7) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = n0 + (t >> 3) + 32 * q;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < N && k < K) v = ld4(w + (size_t)n * ldw + k);
+    r[q] = v;
+  }
+}
+__device__ __forceinline__ void store_tile(char* lds, const f32x4 (&r)[4]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = (t >> 3) + 32 * q;
+    *reinterpret_cast<f32x4*>(lds + row * 128 + (((t & 7) ^ swz(row)) << 4)) = r[q];
+  }
+}
+__device__ __forceinline__ f32x4 frag(const char* lds, int row, int chunk) {
+  return *reinterpret_cast<const f32x4*>(lds + row * 128 + ((chunk ^ swz(row)) << 4));
+}
+
+// one k-tile (32 floats) of MFMAs for a wave's 64x64 sub-tile
+__device__ __forceinline__ void mma_tile(const char* la, const char* lb, int wm, int wn, int fr, int fg,
+                                         f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {          // 8 k per step: lanes g=0 take slots 0..3, g=1 slots 4..7
+    f32x4 fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i] = frag(la, wm + 32 * i + fr, 2 * kb + fg);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = frag(lb, wn + 32 * j + fr, 2 * kb + fg);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (A 16K + B 16K) = 64 KiB
+  const int z = blockIdx.z;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int fr = lane & 31, fg = lane >> 5;
+  const float* W = p.w + (size_t)z * p.w_parity_stride;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  f32x4 ra[4], rb[4];
+  load_a(p, z, m0, 0, ra); load_b(W, p.K, n0, p.Cout, 0, p.K, rb);
+  store_tile(smem, ra); store_tile(smem + 16384, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) { load_a(p, z, m0, (kt + 1) * BK, ra); load_b(W, p.K, n0, p.Cout, (kt + 1) * BK, p.K, rb); }
+    mma_tile(smem + cur * 32768, smem + cur * 32768 + 16384, wm, wn, fr, fg, acc);
+    if (kt + 1 < nk) { store_tile(smem + (cur ^ 1) * 32768, ra); store_tile(smem + (cur ^ 1) * 32768 + 16384, rb); }
+    __syncthreads();
+  }
+  float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        ct[(wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fg) * BN + wn + 32 * j + fr] = acc[i][j][e];
+  __syncthreads();
+  const int cchunk = (threadIdx.x & 15) * 8;
+#pragma unroll 1
+  for (int pass = 0; pass < 8; ++pass) {
+    const int row = pass * 16 + (threadIdx.x >> 4);
+    const int m = m0 + row, n = n0 + cchunk;
+    if (m < p.M && n < p.Cout) {
+      f32x4 x0 = ld4(ct + row * BN + cchunk), x1 = ld4(ct + row * BN + cchunk + 4);
+      if (p.bias) { const f32x4 b0 = ld4(p.bias + n), b1 = ld4(p.bias + n + 4); x0 += b0; x1 += b1; }
+      if (p.relu_out) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x0[i] = fmaxf(x0[i], 0.f); x1[i] = fmaxf(x1[i], 0.f); }
+      }
+      const int b = m / (p.GH * p.GW);
+      const int rem = m - b * (p.GH * p.GW);
+      const int y = rem / p.GW, x = rem - y * p.GW;
+      const int oy = y * p.out_mul + p.ooy[z], ox = x * p.out_mul + p.oox[z];
+      float* o = p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.Cout + n;
+      *reinterpret_cast<f32x4*>(o) = x0;
+      *reinterpret_cast<f32x4*>(o + 4) = x1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Quantize.forward_ (eval branch, vqvae/vqvae_zc.py:41-54): dist = |x|^2 - 2 x E + |E|^2, id = argmax(-dist)
+// (first maximum on ties).  GEMM x[M,256] . Et[8192,256]^T with a running (min, index) epilogue: the
+// 33.5 MB/image distance map of the reference is never written.  One workgroup = 128 rows x ALL codes.
+struct VqArgs { const float* x; const float* et; const float* e2; long long* ids; int M, D, NE; };
+
+__global__ __launch_bounds__(NT) void vq_argmin_kernel(const VqArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float x2s[BM];
+  __shared__ float best_v[2][BM];
+  __shared__ int best_i[2][BM];
+  const int m0 = blockIdx.x * BM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int fr = lane & 31, fg = lane >> 5;
+  // |x|^2 per row (2 threads per row, fp32)
+  {
+    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+    float s = 0.f;
+    if (m0 + row < p.M)
+      for (int k = half * (p.D / 2); k < (half + 1) * (p.D / 2); k += 4) {
+        const f32x4 v = ld4(p.x + (size_t)(m0 + row) * p.D + k);
+        s += v[0] * v[0]; s += v[1] * v[1]; s += v[2] * v[2]; s += v[3] * v[3];
+      }
+    s += __shfl_xor(s, 1, 64);
+    if (half == 0) x2s[row] = s;
+  }
+  __syncthreads();
+  float bv[2][16]; int bi[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { bv[i][e] = INFINITY; bi[i][e] = 0; }
+
+  const int nk = (p.D + BK - 1) / BK;
+  for (int n0 = 0; n0 < p.NE; n0 += BN) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    f32x4 ra[4], rb[4];
+    load_b(p.x, p.D, m0, p.M, 0, p.D, ra); load_b(p.et, p.D, n0, p.NE, 0, p.D, rb);
+    __syncthreads();
+    store_tile(smem, ra); store_tile(smem + 16384, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) { load_b(p.x, p.D, m0, p.M, (kt + 1) * BK, p.D, ra); load_b(p.et, p.D, n0, p.NE, (kt + 1) * BK, p.D, rb); }
+      mma_tile(smem + cur * 32768, smem + cur * 32768 + 16384, wm, wn, fr, fg, acc);
+      if (kt + 1 < nk) { store_tile(smem + (cur ^ 1) * 32768, ra); store_tile(smem + (cur ^ 1) * 32768 + 16384, rb); }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn + 32 * j + fr;
+      const float c2 = col < p.NE ? p.e2[col] : INFINITY;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fg;
+          const float d = (x2s[row] - 2.0f * acc[i][j][e]) + c2;      // same expression order as the reference
+          if (d < bv[i][e]) { bv[i][e] = d; bi[i][e] = col; }          // columns visited in increasing order
+        }
+    }
+  }
+  // reduce over the 32 lanes that hold different columns of the same row (ties -> smaller index)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = bv[i][e]; int ix = bi[i][e];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64); const int oi = __shfl_xor(ix, o, 64);
+        if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+      }
+      if (fr == 0) {
+        const int row = wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fg;
+        best_v[wave & 1][row] = v; best_i[wave & 1][row] = ix;
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x < BM && m0 + threadIdx.x < p.M) {
+    const int r = threadIdx.x;
+    const float v0 = best_v[0][r], v1 = best_v[1][r];
+    const int i0 = best_i[0][r], i1 = best_i[1][r];
+    p.ids[m0 + r] = (v1 < v0 || (v1 == v0 && i1 < i0)) ? i1 : i0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// layout helpers
+// NCHW (c = 3) -> NHWC4 (4th channel zero) : input of encoder conv 1
+__global__ void nchw3_to_nhwc4_kernel(const float* in, float* out, int B, int H, int W) {
+  const size_t n = (size_t)B * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / ((size_t)H * W), px = i % ((size_t)H * W);
+    f32x4 v;
+    v[0] = in[(b * 3 + 0) * H * W + px]; v[1] = in[(b * 3 + 1) * H * W + px]; v[2] = in[(b * 3 + 2) * H * W + px]; v[3] = 0.f;
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+// embed_code (vqvae/vqvae_zc.py:95-96): out[pixel][:] = Et[id][:]   (NHWC == the reference's pre-permute layout)
+__global__ void embed_code_kernel(const long long* ids, const float* et, float* out, size_t npix, int D, int NE) {
+  const int dv = D / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix * dv; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t px = i / dv; const int c = (int)(i % dv) * 4;
+    long long id = ids[px]; id = id < 0 ? 0 : (id >= NE ? NE - 1 : id);
+    *reinterpret_cast<f32x4*>(out + px * D + c) = ld4(et + (size_t)id * D + c);
+  }
+}
+// final 1x1 conv 512 -> 3 (vqvae/vqvae_zc.py:190) on NHWC input, output NCHW, optional de-normalisation
+// out = (w . x + b) * scale[c] + shift[c]  (vqvae/api.py:43).  One wave per pixel group; HBM-bound.
+__global__ __launch_bounds__(256) void conv1x1_to3_kernel(const float* in, const float* w, const float* bias,
+                                                         float* out, size_t npix, int HW, int Cin,
+                                                         float s0, float s1, float s2, float t0, float t1, float t2) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t px = wave; px < npix; px += nw) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int c = lane * 4; c < Cin; c += 256) {
+      const f32x4 x = ld4(in + px * Cin + c);
+      const f32x4 w0 = ld4(w + c), w1 = ld4(w + Cin + c), w2 = ld4(w + 2 * Cin + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a0 += x[i] * w0[i]; a1 += x[i] * w1[i]; a2 += x[i] * w2[i]; }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) {
+      const size_t b = px / HW, r = px % HW;
+      out[(b * 3 + 0) * HW + r] = (a0 + bias[0]) * s0 + t0;
+      out[(b * 3 + 1) * HW + r] = (a1 + bias[1]) * s1 + t1;
+      out[(b * 3 + 2) * HW + r] = (a2 + bias[2]) * s2 + t2;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cogv_conv2d_nhwc_f32(const cogv_conv_desc* d, void* stream) {
+  if (!d || !d->in || !d->w || !d->out) return COGV_ERR_ARG;
+  if (d->Cin <= 0 || (d->Cin & 3) || (d->Cout & 7) || d->B <= 0) return COGV_ERR_ARG;
+  if (((uintptr_t)d->in | (uintptr_t)d->w | (uintptr_t)d->out | (uintptr_t)d->bias) & 15) return COGV_ERR_ARG;
+  ConvArgs a;
+  a.in = (const float*)d->in; a.w = (const float*)d->w; a.bias = (const float*)d->bias; a.out = (float*)d->out;
+  a.B = d->B; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin; a.Cout = d->Cout; a.relu_out = d->relu;
+  int nz = 1;
+  if (d->kind == COGV_CONV_4X4_S2) {
+    if ((d->IH & 1) || (d->IW & 1)) return COGV_ERR_ARG;
+    a.GH = a.OH = d->IH / 2; a.GW = a.OW = d->IW / 2; a.in_mul = 2; a.out_mul = 1; a.ntaps = 16;
+    for (int ky = 0; ky < 4; ++ky) for (int kx = 0; kx < 4; ++kx) { a.dy[0][ky * 4 + kx] = (int8_t)(ky - 1); a.dx[0][ky * 4 + kx] = (int8_t)(kx - 1); }
+    a.ooy[0] = a.oox[0] = 0;
+  } else if (d->kind == COGV_CONV_1X1) {
+    a.GH = a.OH = d->IH; a.GW = a.OW = d->IW; a.in_mul = 1; a.out_mul = 1; a.ntaps = 1;
+    a.dy[0][0] = a.dx[0][0] = 0; a.ooy[0] = a.oox[0] = 0;
+  } else if (d->kind == COGV_CONVT_4X4_S2) {
+    // out[2y+py] gets taps ky with ky = (py+1) mod 2 (+2):  py=0: ky=1 (iy=y), ky=3 (iy=y-1);  py=1: ky=0 (iy=y+1), ky=2 (iy=y)
+    // weights are packed [py*2+px][co][ty*2+tx][ci] with (ty -> ky) = py==0 ? {1,3} : {0,2}, same for x
+    a.GH = d->IH; a.GW = d->IW; a.OH = 2 * d->IH; a.OW = 2 * d->IW; a.in_mul = 1; a.out_mul = 2; a.ntaps = 4;
+    nz = 4;
+    for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
+      const int z = py * 2 + px;
+      const int offy[2] = {py == 0 ? 0 : 1, py == 0 ? -1 : 0};
+      const int offx[2] = {px == 0 ? 0 : 1, px == 0 ? -1 : 0};
+      for (int ty = 0; ty < 2; ++ty) for (int tx = 0; tx < 2; ++tx) { a.dy[z][ty * 2 + tx] = (int8_t)offy[ty]; a.dx[z][ty * 2 + tx] = (int8_t)offx[tx]; }
+      a.ooy[z] = (int8_t)py; a.oox[z] = (int8_t)px;
+    }
+  } else return COGV_ERR_UNSUPPORTED;
+  a.K = a.ntaps * a.Cin;
+  a.M = a.B * a.GH * a.GW;
+  a.w_parity_stride = (long long)a.Cout * a.K;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; }
+  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, nz);
+  hipLaunchKernelGGL(conv_kernel, grid, dim3(NT), 65536, reinterpret_cast<hipStream_t>(stream), a);
+  return cogv_check_launch();
+}
+
+extern "C" int cogv_vq_argmin_f32(const float* x, const float* embed_t, const float* embed_sq, int64_t* ids, int M,
+                                  int D, int n_embed, void* stream) {
+  if (!x || !embed_t || !embed_sq || !ids || M <= 0 || D <= 0 || (D & 7) || n_embed <= 0) return COGV_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)embed_t) & 15) return COGV_ERR_ARG;
+  VqArgs a{x, embed_t, embed_sq, reinterpret_cast<long long*>(ids), M, D, n_embed};
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_argmin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; }
+  hipLaunchKernelGGL(vq_argmin_kernel, dim3((M + BM - 1) / BM), dim3(NT), 65536, reinterpret_cast<hipStream_t>(stream), a);
+  return cogv_check_launch();
+}
+
+extern "C" int cogv_nchw3_to_nhwc4_f32(const float* in, float* out, int B, int H, int W, void* stream) {
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || ((uintptr_t)out & 15)) return COGV_ERR_ARG;
+  const size_t n = (size_t)B * H * W;
+  int g = (int)((n + 255) / 256); if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out, B, H, W);
+  return cogv_check_launch();
+}
+
+extern "C" int cogv_embed_code_f32(const int64_t* ids, const float* embed_t, float* out, int64_t npix, int D,
+                                   int n_embed, void* stream) {
+  if (!ids || !embed_t || !out || npix <= 0 || (D & 3) || (((uintptr_t)embed_t | (uintptr_t)out) & 15)) return COGV_ERR_ARG;
+  const size_t n = (size_t)npix * (D / 4);
+  int g = (int)((n + 255) / 256); if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(embed_code_kernel, dim3(g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const long long*>(ids), embed_t, out, (size_t)npix, D, n_embed);
+  return cogv_check_launch();
+}
+
+extern "C" int cogv_conv1x1_to_rgb_f32(const float* in, const float* w, const float* bias, float* out, int B, int H,
+                                       int W, int Cin, const float* scale3_host, const float* shift3_host,
+                                       void* stream) {
+  if (!in || !w || !bias || !out || B <= 0 || (Cin & 3) || (((uintptr_t)in | (uintptr_t)w) & 15)) return COGV_ERR_ARG;
+  const float s[3] = {scale3_host ? scale3_host[0] : 1.f, scale3_host ? scale3_host[1] : 1.f, scale3_host ? scale3_host[2] : 1.f};
+  const float t[3] = {shift3_host ? shift3_host[0] : 0.f, shift3_host ? shift3_host[1] : 0.f, shift3_host ? shift3_host[2] : 0.f};
+  const size_t npix = (size_t)B * H * W;
+  size_t blocks = (npix + 3) / 4; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(conv1x1_to3_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, w,
+                     bias, out, npix, H * W, Cin, s[0], s[1], s[2], t[0], t[1], t[2]);
+  return cogv_check_launch();
+}

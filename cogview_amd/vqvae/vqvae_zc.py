@@ -1,0 +1,221 @@
+"""VQ-VAE image tokenizer: module surface of vqvae/vqvae_zc.py (class names, constructor arguments,
+state_dict keys: enc_b.blocks.{0,2,4,6}.*, quantize_t.{embed,cluster_size,embed_avg}, dec.blocks.{0,2,4,6}.*),
+inference arithmetic in the HIP library (cogview_amd/csrc/conv.hip).
+
+Scope: the frozen tokenizer as CogView uses it (vqvae/api.py: img2code / code2img, eval mode).  The HIP path
+implements the production topology -- stride=6, simple=True, n_res_block=0: three 4x4 stride-2 convolutions +
+1x1, nearest-code search, three 4x4 stride-2 transposed convolutions + 1x1 -- for any channel / embed_dim /
+n_embed that is a multiple of 8.  Training of the VQ-VAE (EMA codebook update, Gumbel-softmax relaxation) is not
+part of CogView's pipeline (no training script in the reference) and raises.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _conv(kind, x, w, bias, cout, relu):
+    """x NHWC fp32 contiguous -> NHWC fp32."""
+    if not x.is_cuda:
+        raise L.CogviewHipError("cogview_amd.vqvae runs only on an MI355X (HIP) device; there is no CPU fallback")
+    b, ih, iw, cin = x.shape
+    if kind == L.CONV_4X4_S2:
+        oh, ow = ih // 2, iw // 2
+    elif kind == L.CONVT_4X4_S2:
+        oh, ow = ih * 2, iw * 2
+    else:
+        oh, ow = ih, iw
+    out = torch.empty((b, oh, ow, cout), dtype=torch.float32, device=x.device)
+    d = L.ConvDesc()
+    d.kind, d.B, d.IH, d.IW, d.Cin, d.Cout, d.relu = kind, b, ih, iw, cin, cout, int(relu)
+    setattr(d, "in", x.data_ptr())
+    d.w, d.bias, d.out = w.data_ptr(), bias.data_ptr(), out.data_ptr()
+    L.check(L.lib().cogv_conv2d_nhwc_f32(C.byref(d), _stream()), "cogv_conv2d_nhwc_f32")
+    return out
+
+
+def pack_conv_weight(w):
+    """Conv2d weight [Cout, Cin, kh, kw] -> [Cout, kh*kw, Cin4] (Cin padded to a multiple of 4)."""
+    co, ci, kh, kw = w.shape
+    ci4 = (ci + 3) // 4 * 4
+    out = torch.zeros((co, kh * kw, ci4), dtype=torch.float32, device=w.device)
+    out[:, :, :ci] = w.detach().float().permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
+    return out.contiguous()
+
+
+def pack_convt_weight(w):
+    """ConvTranspose2d weight [Cin, Cout, 4, 4] (stride 2, pad 1) -> [4 parities][Cout][4 taps][Cin]:
+    output pixel (2y+py, 2x+px) = sum over taps (ty,tx) of in[y+offy, x+offx] with ky = 2*ty (py=1) or 1+2*ty (py=0)."""
+    ci, co, kh, kw = w.shape
+    assert kh == 4 and kw == 4
+    wf = w.detach().float()
+    out = torch.empty((4, co, 4, ci), dtype=torch.float32, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    ky = 2 * ty if py else 1 + 2 * ty
+                    kx = 2 * tx if px else 1 + 2 * tx
+                    out[py * 2 + px, :, ty * 2 + tx, :] = wf[:, :, ky, kx].t()
+    return out.contiguous()
+
+
+class Quantize(nn.Module):
+    """Codebook holder (vqvae/vqvae_zc.py:26-96).  `embed` is [dim, n_embed] as in the reference."""
+
+    def __init__(self, dim, n_embed, decay=0.99, eps=1e-5):
+        super().__init__()
+        self.dim, self.n_embed, self.decay, self.eps = dim, n_embed, decay, eps
+        embed = torch.randn(dim, n_embed)
+        torch.nn.init.xavier_uniform_(embed, gain=torch.nn.init.calculate_gain('tanh'))
+        self.register_buffer("embed", embed)
+        self.register_buffer("cluster_size", torch.zeros(n_embed))
+        self.register_buffer("embed_avg", embed.clone())
+        self._cache = None
+
+    def _tables(self):
+        """E^T [n_embed, dim] and |E_j|^2, rebuilt when the buffer changes (one-time set-up, not the hot path)."""
+        key = (self.embed.data_ptr(), self.embed._version)
+        if self._cache is None or self._cache[0] != key:
+            et = self.embed.detach().float().t().contiguous()
+            e2 = self.embed.detach().float().pow(2).sum(0).contiguous()       # vqvae_zc.py:46 `embed.pow(2).sum(0)`
+            self._cache = (key, et, e2)
+        return self._cache[1], self._cache[2]
+
+    def nearest_code(self, x_nhwc):
+        """x [b, h, w, dim] fp32 -> ids [b, h, w] int64 (argmax of -dist, first maximum)."""
+        et, e2 = self._tables()
+        flat = x_nhwc.reshape(-1, self.dim)
+        ids = torch.empty(flat.shape[0], dtype=torch.int64, device=flat.device)
+        L.check(L.lib().cogv_vq_argmin_f32(_p(flat), _p(et), _p(e2), _p(ids), flat.shape[0], self.dim, self.n_embed,
+                                           _stream()), "cogv_vq_argmin_f32")
+        return ids.view(*x_nhwc.shape[:-1])
+
+    def embed_code(self, embed_id):
+        """F.embedding(ids, embed^T) -> [..., dim] (vqvae/vqvae_zc.py:95-96)."""
+        et, _ = self._tables()
+        ids = embed_id.contiguous()
+        out = torch.empty(tuple(ids.shape) + (self.dim,), dtype=torch.float32, device=et.device)
+        L.check(L.lib().cogv_embed_code_f32(_p(ids), _p(et), _p(out), ids.numel(), self.dim, self.n_embed, _stream()),
+                "cogv_embed_code_f32")
+        return out
+
+    def forward_(self, input, continuous_relax=False, temperature=1., hard=False):
+        if continuous_relax or self.training:
+            raise NotImplementedError("only the frozen eval-mode tokenizer path is implemented (argmax + lookup)")
+        ids = self.nearest_code(input.contiguous())
+        quantize = self.embed_code(ids)
+        diff = (quantize - input).pow(2).mean()
+        return quantize, diff, ids
+
+
+class _ConvStack(nn.Module):
+    def __init__(self, blocks):
+        super().__init__()
+        self.blocks = nn.Sequential(*blocks)
+        self._packed = None
+
+    def _weights(self, packers):
+        key = tuple((m.weight.data_ptr(), m.weight._version) for m in self.blocks if hasattr(m, "weight"))
+        if self._packed is None or self._packed[0] != key:
+            mods = [m for m in self.blocks if hasattr(m, "weight")]
+            self._packed = (key, [(pk(m.weight), m.bias.detach().float().contiguous()) for pk, m in zip(packers, mods)])
+        return self._packed[1]
+
+
+class Encoder(_ConvStack):
+    """vqvae/vqvae_zc.py:116-164 (stride 6, simple): conv4x4s2+ReLU, conv4x4s2+ReLU, conv4x4s2, ReLU, conv1x1."""
+
+    def __init__(self, in_channel, channel, n_res_block, n_res_channel, stride, embed_dim, n_embed, simple):
+        if stride != 6 or not simple or n_res_block != 0:
+            raise NotImplementedError("HIP tokenizer path: stride=6, simple=True, n_res_block=0 (vqvae/api.py:12-20)")
+        super().__init__([nn.Conv2d(in_channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                          nn.Conv2d(channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                          nn.Conv2d(channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                          nn.Conv2d(channel, embed_dim, 1)])
+        self.channel, self.embed_dim = channel, embed_dim
+
+    def forward(self, input):
+        """NCHW image -> [b, h/8, w/8, embed_dim] (the reference returns the NHWC permutation too, :164)."""
+        (w1, b1), (w2, b2), (w3, b3), (w4, b4) = self._weights([pack_conv_weight] * 4)
+        x = input.contiguous().float()
+        b, c, h, w = x.shape
+        assert c == 3, "encoder expects RGB input"
+        x4 = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
+        L.check(L.lib().cogv_nchw3_to_nhwc4_f32(_p(x), _p(x4), b, h, w, _stream()), "cogv_nchw3_to_nhwc4_f32")
+        y = _conv(L.CONV_4X4_S2, x4, w1, b1, self.channel, True)
+        y = _conv(L.CONV_4X4_S2, y, w2, b2, self.channel, True)
+        y = _conv(L.CONV_4X4_S2, y, w3, b3, self.channel, True)     # ReLU of blocks[5] folded into this epilogue
+        return _conv(L.CONV_1X1, y, w4, b4, self.embed_dim, False)
+
+
+class Decoder(_ConvStack):
+    """vqvae/vqvae_zc.py:167-229 (stride 4, simple): convT+ReLU x3, conv1x1 -> RGB."""
+
+    def __init__(self, in_channel, out_channel, channel, n_res_block, n_res_channel, stride, simple):
+        if stride != 4 or not simple or n_res_block != 0 or out_channel != 3:
+            raise NotImplementedError("HIP tokenizer path: decoder stride=4, simple=True, n_res_block=0, RGB output")
+        super().__init__([nn.ConvTranspose2d(in_channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                          nn.ConvTranspose2d(channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                          nn.ConvTranspose2d(channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                          nn.Conv2d(channel, out_channel, 1)])
+        self.channel = channel
+
+    def forward_nhwc(self, q_nhwc, scale=None, shift=None):
+        (w1, b1), (w2, b2), (w3, b3), (w4, b4) = self._weights([pack_convt_weight] * 3 + [lambda w: w.detach().float().reshape(3, -1).contiguous()])
+        y = _conv(L.CONVT_4X4_S2, q_nhwc.contiguous(), w1, b1, self.channel, True)
+        y = _conv(L.CONVT_4X4_S2, y, w2, b2, self.channel, True)
+        y = _conv(L.CONVT_4X4_S2, y, w3, b3, self.channel, True)
+        b, h, w, c = y.shape
+        out = torch.empty((b, 3, h, w), dtype=torch.float32, device=y.device)
+        sc = (C.c_float * 3)(*scale) if scale is not None else None
+        sh = (C.c_float * 3)(*shift) if shift is not None else None
+        L.check(L.lib().cogv_conv1x1_to_rgb_f32(_p(y), _p(w4), _p(b4), _p(out), b, h, w, c, sc, sh, _stream()),
+                "cogv_conv1x1_to_rgb_f32")
+        return out
+
+    def forward(self, input):
+        """NCHW quantised map -> NCHW image."""
+        return self.forward_nhwc(input.permute(0, 2, 3, 1))
+
+
+class VQVAE(nn.Module):
+    def __init__(self, in_channel=3, channel=128, n_res_block=2, n_res_channel=32, embed_dim=64, n_embed=1024,
+                 stride=4, simple=True, decay=0.99):
+        super().__init__()
+        if channel == 2048:
+            n_res_block = 0
+        self.enc_b = Encoder(in_channel, channel, n_res_block, n_res_channel, stride, embed_dim, n_embed, simple)
+        self.quantize_t = Quantize(embed_dim, n_embed)
+        self.dec = Decoder(in_channel=embed_dim, out_channel=in_channel, channel=channel, n_res_block=n_res_block,
+                           n_res_channel=n_res_channel, stride=stride - 2, simple=simple)
+
+    def encode(self, input, continuous_relax=False, temperature=1., hard=False, KL=False):
+        """-> (quantised NCHW, diff [1], ids [b, h/8, w/8]) as vqvae/vqvae_zc.py:251-259."""
+        logits = self.enc_b(input)
+        quant_t, diff_t, id_t = self.quantize_t.forward_(logits, continuous_relax, temperature, hard)
+        return quant_t.permute(0, 3, 1, 2), diff_t.unsqueeze(0), id_t
+
+    def encode_ids(self, input):
+        """ids only: skips the embedding lookup / diff that img2code discards."""
+        return self.quantize_t.nearest_code(self.enc_b(input))
+
+    def decode(self, code):
+        return self.dec(code)
+
+    def decode_code(self, code_t, scale=None, shift=None):
+        return self.dec.forward_nhwc(self.quantize_t.embed_code(code_t), scale, shift)
+
+    def forward(self, input, continuous_relax=False, temperature=1., hard=False, KL=False):
+        quant_t, diff, _ = self.encode(input, continuous_relax, temperature, hard, KL)
+        return self.dec(quant_t), diff

@@ -183,6 +183,33 @@ int cogv_adamw_step(const cogv_adam_desc* d, void* stream);
 int cogv_cast_flat(int dtype, const void* src_half, float* dst_f32, size_t n, void* stream);
 int cogv_cast_flat_back(int dtype, const float* src_f32, void* dst_half, size_t n, void* stream);
 
+/* ------------------------------------------------------------------ VQ-VAE tokenizer (fp32, exact-fp32 MFMA)
+ * replaces the conv stacks of vqvae/vqvae_zc.py:121-129,159-164 (Encoder) and :172-192 (Decoder), the
+ * nearest-code search :41-54 and embed_code :95-96 for the production config of vqvae/api.py:12-20.
+ * Activations NHWC fp32; weights repacked by the caller to [parity][Cout][tap][Cin]:
+ *   COGV_CONV_4X4_S2  (Conv2d k4 s2 p1)        taps = ky*4+kx, 1 parity,  W_packed[co][ky*4+kx][ci] = W[co][ci][ky][kx]
+ *   COGV_CONV_1X1                              1 tap
+ *   COGV_CONVT_4X4_S2 (ConvTranspose2d k4 s2 p1) 4 parities z = py*2+px (output pixel (2y+py, 2x+px)), 4 taps
+ *        W_packed[z][co][ty*2+tx][ci] = W[ci][co][ky][kx],  ky = (py ? 2*ty : 1+2*ty),  kx = (px ? 2*tx : 1+2*tx)
+ */
+#define COGV_CONV_4X4_S2 0
+#define COGV_CONV_1X1 1
+#define COGV_CONVT_4X4_S2 2
+typedef struct cogv_conv_desc {
+  int kind; int B, IH, IW, Cin, Cout; int relu;     /* relu: applied to the output */
+  const void* in; const void* w; const void* bias; void* out;
+} cogv_conv_desc;
+int cogv_conv2d_nhwc_f32(const cogv_conv_desc* d, void* stream);
+/* ids[m] = argmin_j (|x_m|^2 - 2 x_m.E_j) + |E_j|^2, first minimum on ties; embed_t = E^T [n_embed][D], embed_sq = |E_j|^2 */
+int cogv_vq_argmin_f32(const float* x, const float* embed_t, const float* embed_sq, int64_t* ids, int M, int D,
+                       int n_embed, void* stream);
+int cogv_nchw3_to_nhwc4_f32(const float* in, float* out, int B, int H, int W, void* stream);
+int cogv_embed_code_f32(const int64_t* ids, const float* embed_t, float* out, int64_t npix, int D, int n_embed,
+                        void* stream);
+/* NHWC [B,H,W,Cin] -> NCHW [B,3,H,W]: (w[3][Cin] . x + bias) * scale + shift (scale/shift: 3 HOST floats or NULL) */
+int cogv_conv1x1_to_rgb_f32(const float* in, const float* w, const float* bias, float* out, int B, int H, int W,
+                            int Cin, const float* scale3_host, const float* shift3_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

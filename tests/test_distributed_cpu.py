@@ -1,0 +1,202 @@
+"""CPU, multi-process (gloo): the N>1 host logic -- process-group topology, the four tensor-parallel mappings,
+broadcast_data, data-parallel gradient averaging (both allreduce_params orders), loss-scaler overflow sync and
+the model-parallel weight sharding rule.  No compute kernels are involved (there is no GPU here)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _entry(rank, world, port, fn_name, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    try:
+        globals()[fn_name](rank, world)
+        ret[rank] = "ok"
+    except Exception as e:                      # surface the failure in the parent
+        import traceback
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn_name, world):
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_entry, args=(r, world, _free_port_shared[0], fn_name, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+        for r in range(world):
+            assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"
+
+
+_free_port_shared = [0]
+
+
+@pytest.fixture(autouse=True)
+def _port():
+    _free_port_shared[0] = _free_port()
+
+
+# ------------------------------------------------------------------------------------------------ workers
+def w_topology(rank, world):
+    from cogview_amd import mpu
+    mpu.initialize_model_parallel(2)
+    assert mpu.model_parallel_is_initialized()
+    assert mpu.get_model_parallel_world_size() == 2 and mpu.get_data_parallel_world_size() == world // 2
+    assert mpu.get_model_parallel_rank() == rank % 2 and mpu.get_data_parallel_rank() == rank // 2
+    assert mpu.get_model_parallel_src_rank() == (rank // 2) * 2            # adjacent ranks form a model-parallel group
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t, group=mpu.get_model_parallel_group())
+    assert t.item() == (rank // 2) * 4 + 1                                  # r + (r^1)
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t, group=mpu.get_data_parallel_group())
+    assert t.item() == sum(r for r in range(world) if r % 2 == rank % 2)
+    mpu.destroy_model_parallel()
+    assert not mpu.model_parallel_is_initialized()
+
+
+def w_mappings(rank, world):
+    from cogview_amd import mpu
+    mpu.initialize_model_parallel(world)
+    x = (torch.arange(6, dtype=torch.float32).view(1, 6) + 10 * rank).requires_grad_(True)
+    # copy: identity forward, all-reduce backward
+    y = mpu.copy_to_model_parallel_region(x)
+    y.backward(torch.ones_like(y) * (rank + 1))
+    assert torch.equal(y.detach(), x.detach()) and torch.equal(x.grad, torch.full_like(x, sum(range(1, world + 1))))
+    # reduce: all-reduce forward (in place on its input), identity backward
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = mpu.reduce_from_model_parallel_region(x2 * 1.0)
+    expect = sum(torch.arange(6, dtype=torch.float32).view(1, 6) + 10 * r for r in range(world))
+    assert torch.equal(y2.detach(), expect)
+    y2.backward(torch.ones_like(y2))
+    assert torch.equal(x2.grad, torch.ones_like(x2))
+    # scatter / gather are inverses along the last dim
+    full = torch.arange(12, dtype=torch.float32).view(2, 6).requires_grad_(True)
+    part = mpu.scatter_to_model_parallel_region(full)
+    w = 6 // world
+    assert torch.equal(part.detach(), full.detach()[:, rank * w:(rank + 1) * w])
+    back = mpu.gather_from_model_parallel_region(part)
+    assert torch.equal(back.detach(), full.detach())
+    back.sum().backward()
+    assert torch.equal(full.grad, torch.ones_like(full))
+
+
+def w_broadcast_data(rank, world):
+    from cogview_amd import mpu
+    mpu.initialize_model_parallel(2)
+    keys = ['text', 'loss_mask']
+    if mpu.get_model_parallel_rank() == 0:
+        g = torch.Generator().manual_seed(100 + rank)
+        data = {'text': torch.randint(0, 58219, (3, 1089), generator=g), 'loss_mask': torch.ones(3, 1089, dtype=torch.int64)}
+    else:
+        data = None
+    out = mpu.broadcast_data(keys, data, torch.int64)
+    g = torch.Generator().manual_seed(100 + mpu.get_model_parallel_src_rank())
+    assert torch.equal(out['text'].cpu(), torch.randint(0, 58219, (3, 1089), generator=g))
+    assert out['loss_mask'].shape == (3, 1089)
+
+
+def w_ddp(rank, world):
+    from cogview_amd import mpu
+    from cogview_amd.model import DistributedDataParallel
+    mpu.initialize_model_parallel(1)
+    torch.manual_seed(rank)                                   # replicas start different ...
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    ddp = DistributedDataParallel(net)
+    ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    torch.manual_seed(0)
+    ref0 = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    for p, q in zip(net.parameters(), ref0.parameters()):     # ... and end up with rank 0's parameters
+        assert torch.equal(p.data, q.data)
+    for order in (False, True):
+        for p in net.parameters():
+            p.grad = torch.full_like(p, float(rank + 1))
+        ddp.needs_reduction = True
+        ddp.allreduce_params(reduce_after=order)
+        mean = sum(range(1, world + 1)) / world
+        for p in net.parameters():
+            assert torch.allclose(p.grad, torch.full_like(p, mean))
+        ddp.allreduce_params()                                # needs_reduction False -> no-op
+        for p in net.parameters():
+            assert torch.allclose(p.grad, torch.full_like(p, mean))
+    assert set(ddp.state_dict().keys()) == set(net.state_dict().keys())      # unwrapped keys (model/distributed.py:27-29)
+
+
+def w_overflow_sync(rank, world):
+    from cogview_amd import mpu
+    from cogview_amd.fp16 import DynamicLossScaler
+    mpu.initialize_model_parallel(world)
+    sc = DynamicLossScaler(init_scale=2 ** 8)
+    assert sc.sync_overflow(rank == 1) is True                # one shard overflowed -> every rank skips
+    assert sc.sync_overflow(False) is False
+
+
+def w_sharding_rule(rank, world):
+    """_initialize_affine_weight: every rank draws the same master and keeps its strided slabs
+    (stride=3 for QKV keeps [q_r; k_r; v_r]); concatenating ranks' shards reproduces the master."""
+    from cogview_amd import mpu
+    from cogview_amd.mpu.layers import _initialize_affine_weight
+    mpu.initialize_model_parallel(world)
+    torch.manual_seed(7)
+    w = torch.empty(12 // world, 4)
+    master = _initialize_affine_weight(w, 12, 4, 12 // world, 0, torch.nn.init.normal_, stride=3, return_master_weight=True)
+    slabs = torch.split(master, 12 // world // 3, dim=0)
+    assert torch.equal(w, torch.cat(slabs[rank::world], dim=0))
+    parts = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(parts, w)
+    q = torch.cat([p_[0:len(p_) // 3] for p_ in parts])
+    assert torch.equal(q, master[0:4])                          # all ranks' q rows = master's q block
+    wr = torch.empty(5, 8 // world)
+    m2 = _initialize_affine_weight(wr, 5, 8, 8 // world, 1, torch.nn.init.normal_, return_master_weight=True)
+    assert torch.equal(wr, m2[:, rank * (8 // world):(rank + 1) * (8 // world)])
+    emb = mpu.VocabParallelEmbedding(16, 4)
+    assert (emb.vocab_start_index, emb.vocab_end_index) == (rank * 16 // world, (rank + 1) * 16 // world)
+    assert emb.weight.model_parallel and emb.weight.shape == (16 // world, 4)
+    col = mpu.ColumnParallelLinear(4, 12, gather_output=False)
+    row = mpu.RowParallelLinear(12, 4, input_is_parallel=True)
+    assert col.weight.shape == (12 // world, 4) and row.weight.shape == (4, 12 // world) and row.bias.shape == (4,)
+    assert col.bias.model_parallel and not hasattr(row.bias, "model_parallel")
+
+
+# ------------------------------------------------------------------------------------------------ tests
+def test_topology_world4_mp2():
+    _run("w_topology", 4)
+
+
+def test_mappings_world2():
+    _run("w_mappings", 2)
+
+
+def test_broadcast_data_world4_mp2():
+    _run("w_broadcast_data", 4)
+
+
+def test_data_parallel_allreduce_world2():
+    _run("w_ddp", 2)
+
+
+def test_overflow_flag_sync_world2():
+    _run("w_overflow_sync", 2)
+
+
+def test_weight_sharding_rule_world2():
+    _run("w_sharding_rule", 2)

@@ -1,0 +1,103 @@
+"""CPU: host-side logic that needs no kernels -- loss-scale state machine against the reference's own
+trajectories, weight-decay grouping, arena layout / chunk table, RNG-tracker semantics, mask translation."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_dynamic_loss_scaler_matches_reference_trajectories(golden_dir):
+    from cogview_amd.fp16 import DynamicLossScaler
+    z = np.load(os.path.join(golden_dir, "loss_scaler.npz"))
+    for tag, kw in {"default": dict(init_scale=2 ** 16, scale_window=4),
+                    "hyst": dict(init_scale=2 ** 20, scale_window=3, min_scale=256, delayed_shift=2)}.items():
+        sc = DynamicLossScaler(**kw)
+        got = []
+        for o in z[tag + "_pattern"].tolist():
+            sc.update_scale(bool(o))
+            got.append(sc.loss_scale)
+        assert got == z[tag + "_scales"].tolist()
+    assert DynamicLossScaler().loss_scale == 2 ** 32            # reference default (fp16/loss_scaler.py:88)
+
+
+def test_weight_decay_groups_and_state_dict_keys(golden_dir):
+    from cogview_amd import mpu
+    from cogview_amd.model import GPT2Model, gpt2_get_params_for_weight_decay_optimization
+    z = np.load(os.path.join(golden_dir, "gpt2_small.npz"))
+    L_, V_, H_, NH_, P_, S_, B_ = [int(v) for v in z["cfg"]]
+    m = GPT2Model(L_, V_, H_, NH_, 0.1, 0.1, 0.1, P_, 0, True)
+    assert set(m.state_dict().keys()) == {k[6:] for k in z.files if k.startswith("param.")}
+    for k in z.files:
+        if k.startswith("param."):
+            assert tuple(m.state_dict()[k[6:]].shape) == z[k].shape, k
+    decay, no_decay = gpt2_get_params_for_weight_decay_optimization(m)
+    assert no_decay["weight_decay"] == 0.0 and "weight_decay" not in decay
+    names = {id(p): n for n, p in m.named_parameters()}
+    for p in no_decay["params"]:
+        assert names[id(p)].endswith("bias") or "layernorm" in names[id(p)]
+    for p in decay["params"]:
+        assert names[id(p)].endswith("weight") and "layernorm" not in names[id(p)]
+    assert len(decay["params"]) + len(no_decay["params"]) == len(list(m.parameters()))
+    # model_parallel attributes as in mpu/layers.py:111,223,226,297
+    l0 = m.transformer.layers[0]
+    assert l0.attention.query_key_value.weight.model_parallel and l0.attention.query_key_value.bias.model_parallel
+    assert l0.attention.dense.weight.model_parallel and not hasattr(l0.attention.dense.bias, "model_parallel")
+    assert isinstance(l0.input_layernorm, mpu.LayerNorm) and l0.input_layernorm.eps == 1e-5
+
+
+def test_arena_layout_and_chunk_table():
+    from cogview_amd.arena import ALIGN, CHUNK, ParamArena
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in ((300, 5), (7,), (CHUNK + 10,), (128,))]
+    before = [p.detach().clone() for p in ps]
+    a = ParamArena(ps, torch.float32, torch.device("cpu"))
+    assert all(o % ALIGN == 0 for o in a.offsets) and a.total % ALIGN == 0
+    for p, b, o in zip(ps, before, a.offsets):
+        assert torch.equal(p.data, b) and p.data.data_ptr() == a.data.data_ptr() + 4 * o
+        assert p.grad.data_ptr() == a.grad.data_ptr() + 4 * o
+    ps[1].grad.fill_(3.0)
+    assert a.grad[a.offsets[1]:a.offsets[1] + 7].eq(3.0).all()
+    a.zero_grad()
+    assert a.grad.abs().sum() == 0 and ps[1].grad.data_ptr() == a.grad.data_ptr() + 4 * a.offsets[1]
+    starts, lens, groups, norms = a.chunk_table(lambda p: 1 if p.dim() == 1 else 0, lambda p: p is not ps[3])
+    assert int(lens.sum()) == sum(p.numel() for p in ps) and (starts % 8 == 0).all()
+    assert lens.max() <= CHUNK and len(lens) == 1 + 1 + 2 + 1
+    assert groups.tolist() == [0, 1, 1, 1, 1] and norms.tolist() == [1, 1, 1, 1, 0]
+    assert a.slice_of([ps[1], ps[2]]) == (a.offsets[1], a.offsets[3])
+    with pytest.raises(AssertionError):
+        a.slice_of([ps[0], ps[2]])
+
+
+def test_rng_tracker_fork_and_checkpoint_replay():
+    from cogview_amd.mpu import random as R
+    R.model_parallel_cuda_manual_seed(1234)
+    tr = R.get_cuda_rng_tracker()
+    a = R.next_dropout_stream()
+    with tr.fork():
+        b = R.next_dropout_stream()
+    c = R.next_dropout_stream()
+    assert a == (1234, 1) and c == (1234, 2)                 # the fork does not disturb the default stream
+    assert b == (1234 + 2718, 1)                             # seed + 2718 + mp_rank (mpu/random.py:217-219)
+    with pytest.raises(Exception):
+        tr.add('model-parallel-rng', 99)
+    with pytest.raises(Exception):
+        tr.add('other', 1234 + 2718)                         # seed reuse is refused (mpu/random.py:154-156)
+    # restoring saved states replays the same streams: what checkpoint recompute relies on
+    saved_default, saved_tracker = R.get_default_state(), tr.get_states()
+    first = (R.next_dropout_stream(), R.attention_dropout_stream())
+    R.set_default_state(saved_default)
+    tr.set_states(saved_tracker)
+    assert (R.next_dropout_stream(), R.attention_dropout_stream()) == first
+
+
+def test_mask_translation():
+    from cogview_amd.functional import mask_to_sep
+    from oracle import cogview_oracle as O
+    assert mask_to_sep(0, 8, 8) == 0 and mask_to_sep(5, 8, 8) == 5
+    assert mask_to_sep(O.build_mask(40, 40), 40, 40) == 0
+    assert mask_to_sep(O.build_mask(24, 40, sep=5), 24, 40) == 5
+    assert mask_to_sep(O.build_mask(24, 40), 24, 40) == 0
+    bad = O.build_mask(16, 16).clone()
+    bad[0, 0, 3, 9] = 1
+    with pytest.raises(NotImplementedError):
+        mask_to_sep(bad, 16, 16)

@@ -80,5 +80,23 @@ def main():
     json.dump(out, open("gpurun_out/microbench.json", "w"), indent=1)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not os.environ.get("MB_VQVAE"):
     main()
+
+
+def vqvae_bench(batch=32):
+    from cogview_amd import vqvae
+    torch.manual_seed(0)
+    m = vqvae.new_model().eval().cuda()
+    img = torch.randn(batch, 3, 256, 256, device="cuda")
+    t = timeit(lambda: vqvae.img2code(m, img), iters=3, warm=1)
+    ids = vqvae.img2code(m, img)
+    t2 = timeit(lambda: vqvae.code2img(m, ids.view(batch, 32, 32)), iters=3, warm=1)
+    res = {"vqvae.batch": batch, "vqvae.encode_img_per_s": batch / t, "vqvae.encode_TF": 48.32e9 * batch / t / 1e12,
+           "vqvae.decode_img_per_s": batch / t2, "vqvae.decode_TF": 176.29e9 * batch / t2 / 1e12}
+    print(json.dumps({k: round(v, 2) for k, v in res.items()}), flush=True)
+    return res
+
+
+if __name__ == "__main__" and os.environ.get("MB_VQVAE"):
+    vqvae_bench(int(os.environ.get("MB_VQVAE")))
