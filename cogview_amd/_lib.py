@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int),
         ("absmax", C.c_void_p),
         ("dropout_p", C.c_float), ("seed", C.c_uint64), ("stream_id", C.c_uint64),
-        ("splitk", C.c_int),
+        ("splitk", C.c_int), ("kernel_variant", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 

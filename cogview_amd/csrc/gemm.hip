@@ -294,6 +294,290 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
   }
 }
 
+// =====================================================================================================
+// Generation-2 kernel (all operand layouts): direct-to-LDS loads (global_load_lds_dwordx4: no VGPR staging,
+// no ds_write pass) into a 3-stage LDS ring, prefetch distance TWO k-tiles, counted s_waitcnt vmcnt(N)
+// (never 0 inside the loop), raw s_barrier -- one barrier per k-tile -- and the DMA issue spread behind the
+// MFMA groups.  The generation-1 kernel above drains its loads after ONE tile of compute (~512 MFMA cycles
+// per wave), which does not cover global latency under load (measured 0.6 PF).
+//
+// LDS images (the DMA writes linearly: wave-uniform base + lane*16 B, so every permutation is applied to the
+// per-lane SOURCE address and undone by the read):
+//   K-contiguous operand ("natural"):  [rows = output index][64 k]  128-B rows, 16-B chunk c stored at
+//       c ^ swz(row); fragments by one ds_read_b128 per MFMA operand.
+//   contraction-strided operand (dgrad's W, both wgrad operands): DMA'd in its NATURAL global layout
+//       [64 k rows][output index], row = TB*2 bytes, chunk c stored at c ^ ((k&3)<<2); fragments by two
+//       ds_read_b64_tr_b16 -- the LDS transposing read (lane c of a 16-lane group receives, for j = 0..3,
+//       element (c&3) of the 8 bytes addressed by lane 4j + (c>>2): verified on hardware by
+//       tools/probes/tr_read_probe.hip).  The XOR term sends the 4 k-rows of one transpose block to the 4
+//       different 64-B quarters of the 256-B bank row.  No register transposes, no transposed copies in HBM.
+//   Both kinds label MFMA k-slot (g, e) of k-step ks as contraction index 16 ks + 8 g + e, so they mix freely.
+// Tile (WM*64) x (WN*64) x 64, WM*WN waves, each wave a 64x64 sub-tile (2x2 MFMA 32x32x16).
+// Requirements (checked by the dispatcher): K % 64 == 0.  Output rows/columns beyond M / N are clamped on the
+// load side (their products land in rows/columns that are never stored).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// fragment of a natural region: rows = output index
+template <typename T>
+__device__ __forceinline__ typename HT<T>::v8 frag_nat(const char* reg, int row, int ks, int fg) {
+  return read_frag<T>(reg, row, 2 * ks + fg);
+}
+// fragment of a transposed region ([64 k][TB cols], ROWB bytes per k-row): 32-wide column block at col0.
+// Issued through inline asm: with the __builtin_amdgcn_ds_read_tr16_b64 form hipcc (ROCm 7.2) orders the read
+// against the in-flight LDS-DMA and emits s_waitcnt vmcnt(0) in front of it, draining the prefetch ring every
+// k-step (measured: 70 % of wave cycles parked).  The asm reads are invisible to the compiler's counters, so
+// the matching wait is explicit (tr_wait) and carries the destination registers as in/out operands.
+struct TrRaw { u32x2 lo, hi; };
+template <int ROWB>
+__device__ __forceinline__ uint32_t tr_addr(const char* reg, int col0, int lane) {
+  const int G = lane >> 4, cb = G & 1, g = G >> 1, r = (lane & 15) >> 2, qq = lane & 3;
+  const int c = (col0 >> 3) + 2 * cb + (qq >> 1);
+  const int pc = c ^ (r << 2);
+  return (uint32_t)(uintptr_t)(reg) + (8 * g + r) * ROWB + pc * 16 + (qq & 1) * 8;
+}
+template <int ROWB>
+__device__ __forceinline__ void tr_issue(uint32_t addr0, int ks, TrRaw& o) {
+  const uint32_t a = addr0 + ks * 16 * ROWB;
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+               : "=&v"(o.lo), "=&v"(o.hi) : "v"(a), "n"(4 * ROWB) : "memory");
+}
+// natural-region fragment through asm as well (used only in kernels that also have asm transposing reads, so that
+// no compiler-generated lgkmcnt wait -- which cannot see the asm reads queued behind its own -- lands between
+// the read issue and the MFMA group)
+__device__ __forceinline__ void nat_issue(uint32_t addr, u32x4& o) {
+  asm volatile("ds_read_b128 %0, %1" : "=&v"(o) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void nat_wait2(u32x4& a, u32x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory");
+}
+__device__ __forceinline__ void tr_wait2(TrRaw& a, TrRaw& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) : : "memory");
+}
+template <typename T>
+__device__ __forceinline__ typename HT<T>::v8 tr_pack(const TrRaw& r) {
+  typename HT<T>::v8 out;
+  __builtin_memcpy(&out, &r.lo, 8);
+  __builtin_memcpy(reinterpret_cast<char*>(&out) + 8, &r.hi, 8);
+  return out;
+}
+
+template <typename T, bool AT, bool BT, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(const GemmArgs p) {
+  constexpr int NW = WM * WN, TBM = WM * 64, TBN = WN * 64;
+  constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PER = TBM / 8 / NW, B_PER = TBN / 8 / NW;      // 1-KiB DMA pieces per wave per k-tile
+  constexpr int LPT = A_PER + B_PER;
+  static_assert(A_PER >= 1 && B_PER >= 1, "tile too small for the wave count");
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // 3 * STAGE
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  constexpr int GROUP_M = 4;
+  const int in_group = GROUP_M * p.tiles_n;
+  const int group_id = wgid / in_group;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tile_m = first_m + (wgid % in_group) % gsz;
+  const int tile_n = (wgid % in_group) / gsz;
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = (wave / WN) * 64, wn = (wave % WN) * 64;
+  const int fr = lane & 31, fg = lane >> 5;
+  const int nk_total = p.K / BK;
+  const int kt0 = blockIdx.y * p.ktiles_per_split;
+  const int nk = min(nk_total, kt0 + p.ktiles_per_split) - kt0;   // >= 1 by construction
+
+  // per-lane DMA source pointers for k-tile 0 of this split, and the per-k-tile byte stride
+  const char* srcA[A_PER];
+  const char* srcB[B_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int piece = i * NW + wave;
+    if (!AT) {
+      const int row = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz(row);
+      const int gm = min(m0 + row, p.M - 1);
+      srcA[i] = reinterpret_cast<const char*>(p.A) + ((size_t)gm * p.lda + (size_t)kt0 * BK + c * 8) * 2;
+    } else {
+      constexpr int ROWB = TBM * 2;
+      const int off = piece * 1024 + lane * 16;
+      const int krow = off / ROWB, pc = (off % ROWB) >> 4;
+      const int c = pc ^ ((krow & 3) << 2);
+      const int col = min(m0 + c * 8, p.M - 8);
+      srcA[i] = reinterpret_cast<const char*>(p.A) + ((size_t)((size_t)kt0 * BK + krow) * p.lda + col) * 2;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int piece = i * NW + wave;
+    if (!BT) {
+      const int row = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz(row);
+      const int gn = min(n0 + row, p.N - 1);
+      srcB[i] = reinterpret_cast<const char*>(p.B) + ((size_t)gn * p.ldb + (size_t)kt0 * BK + c * 8) * 2;
+    } else {
+      constexpr int ROWB = TBN * 2;
+      const int off = piece * 1024 + lane * 16;
+      const int krow = off / ROWB, pc = (off % ROWB) >> 4;
+      const int c = pc ^ ((krow & 3) << 2);
+      const int col = min(n0 + c * 8, p.N - 8);
+      srcB[i] = reinterpret_cast<const char*>(p.B) + ((size_t)((size_t)kt0 * BK + krow) * p.ldb + col) * 2;
+    }
+  }
+  const size_t kstrideA = AT ? (size_t)BK * p.lda * 2 : (size_t)BK * 2;
+  const size_t kstrideB = BT ? (size_t)BK * p.ldb * 2 : (size_t)BK * 2;
+  // one LDS-DMA instruction: piece idx in [0, LPT): first the A pieces of this wave, then the B pieces
+  auto issue_piece = [&](int kt, int st, int idx) {
+    char* la = smem + st * STAGE;
+    char* lb = la + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i)
+      if (idx == i)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcA[i] + kt * kstrideA), (lds_void_t*)(la + (i * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+      if (idx == A_PER + i)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(srcB[i] + kt * kstrideB), (lds_void_t*)(lb + (i * NW + wave) * 1024), 16, 0, 0);
+  };
+  auto issue = [&](int kt, int st) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) issue_piece(kt, st, i);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  issue(0, 0);
+  issue(nk > 1 ? 1 : 0, 1);
+  int st = 0;
+  constexpr int PPS = (LPT + 3) / 4;          // DMA pieces issued behind each of the 4 MFMA groups
+  constexpr int DSR = (AT || BT) ? 0 : 4;   // compiler-visible LDS reads per k-step
+  // LDS byte addresses (stage 0) of this lane's transposing reads
+  uint32_t trA[2] = {0, 0}, trB[2] = {0, 0};
+  if (AT) { trA[0] = tr_addr<TBM * 2>(smem, wm, lane); trA[1] = tr_addr<TBM * 2>(smem, wm + 32, lane); }
+  if (BT) { trB[0] = tr_addr<TBN * 2>(smem + A_BYTES, wn, lane); trB[1] = tr_addr<TBN * 2>(smem + A_BYTES, wn + 32, lane); }
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<LPT>();                         // tile kt has landed (the batch issued last iteration may be in flight)
+    __builtin_amdgcn_s_barrier();              // ... for every wave; stage (kt+2)%3 is free again
+    // Branch-free body: past the end the prefetch re-reads the last tile into a stage nobody reads any more
+    // (keeps the vmcnt bookkeeping uniform and lets the compiler software-pipeline ds_read against MFMA).
+    const int kpf = min(kt + 2, nk - 1);
+    const int pst = st == 0 ? 2 : st - 1;
+    const char* la = smem + st * STAGE;
+    const char* lb = la + A_BYTES;
+    const uint32_t soff = (uint32_t)(st * STAGE);
+    typename HT<T>::v8 fa[2][2], fb[2][2];
+    TrRaw ta[2], tb[2];
+    u32x4 na[2], nb[2];
+    constexpr bool ASM_ALL = AT || BT;         // mixed kernels: every fragment read is asm-issued
+    auto fetch = [&](int ks, int buf) {        // fragments of k-step ks -> fa[buf], fb[buf] (asm reads stay raw)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (AT) tr_issue<TBM * 2>(trA[i] + soff, ks, ta[i]);
+        else if (ASM_ALL) { const int row = wm + 32 * i + fr; nat_issue((uint32_t)(uintptr_t)la + row * 128 + (((2 * ks + fg) ^ swz(row)) << 4), na[i]); }
+        else fa[buf][i] = frag_nat<T>(la, wm + 32 * i + fr, ks, fg);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (BT) tr_issue<TBN * 2>(trB[j] + soff, ks, tb[j]);
+        else if (ASM_ALL) { const int row = wn + 32 * j + fr; nat_issue((uint32_t)(uintptr_t)lb + row * 128 + (((2 * ks + fg) ^ swz(row)) << 4), nb[j]); }
+        else fb[buf][j] = frag_nat<T>(lb, wn + 32 * j + fr, ks, fg);
+      }
+    };
+    auto land = [&](int buf) {                 // explicit wait + pack for the asm-issued reads
+      if (AT) { tr_wait2(ta[0], ta[1]); fa[buf][0] = tr_pack<T>(ta[0]); fa[buf][1] = tr_pack<T>(ta[1]); }
+      else if (ASM_ALL) { nat_wait2(na[0], na[1]); __builtin_memcpy(&fa[buf][0], &na[0], 16); __builtin_memcpy(&fa[buf][1], &na[1], 16); }
+      if (BT) { tr_wait2(tb[0], tb[1]); fb[buf][0] = tr_pack<T>(tb[0]); fb[buf][1] = tr_pack<T>(tb[1]); }
+      else if (ASM_ALL) { nat_wait2(nb[0], nb[1]); __builtin_memcpy(&fb[buf][0], &nb[0], 16); __builtin_memcpy(&fb[buf][1], &nb[1], 16); }
+    };
+    fetch(0, 0);
+    land(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks < 3) fetch(ks + 1, nxt);
+      if (AT || BT) __builtin_amdgcn_sched_barrier(0);     // keep the read issue ahead of the MFMA group
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = HT<T>::mfma32(fa[cur][i], fb[cur][j], acc[i][j]);
+#pragma unroll
+      for (int q2 = 0; q2 < PPS; ++q2)
+        if (ks * PPS + q2 < LPT) issue_piece(kpf, pst, ks * PPS + q2);
+      // pin the issue order inside this group: next fragments first (their LDS latency hides under the
+      // MFMAs), DMA pieces between MFMAs.  Masks: 0x100 DS read, 0x008 MFMA, 0x010 VMEM.
+      if (ks < 3 && DSR > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x100, DSR / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, DSR - DSR / 2, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+#pragma unroll
+      for (int q2 = 0; q2 < 3; ++q2) {
+        if (ks * PPS + q2 < LPT && q2 < PPS) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      if (ks < 3 && (AT || BT)) { __builtin_amdgcn_sched_barrier(0); land(nxt); }
+    }
+    st = (st == 2) ? 0 : st + 1;
+  }
+  wait_vmcnt<0>();   // drain the (redundant) tail prefetches before the ring is reused
+  __syncthreads();   // every wave is done reading the ring: reuse it for the fp32 C tile [TBM][TBN]
+
+  float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        ct[(wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fg) * TBN + wn + 32 * j + fr] = acc[i][j][e];
+  __syncthreads();
+  float amax = 0.f; bool nan = false;
+  constexpr int CPR = TBN / 8;                       // 8-column chunks per row
+  constexpr int RPP = NW * 64 / CPR;                 // rows per pass
+  const int cchunk = (threadIdx.x % CPR) * 8;
+#pragma unroll 1
+  for (int row = threadIdx.x / CPR; row < TBM; row += RPP) {
+    const int m = m0 + row, n = n0 + cchunk;
+    if (m < p.M && n < p.N) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(ct + row * TBN + cchunk);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(ct + row * TBN + cchunk + 4);
+      if (p.splitk > 1) {
+        float* w = p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n;
+        *reinterpret_cast<f32x4*>(w) = x0;
+        *reinterpret_cast<f32x4*>(w + 4) = x1;
+      } else {
+        float v[8];
+        v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
+        v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+        const float a = epilogue8<T>(p, m, n, v);
+        if (a != a) nan = true; else amax = fmaxf(amax, a);
+      }
+    }
+  }
+  if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
+    float bm = block_max(amax, reinterpret_cast<float*>(smem));
+    const bool any_nan = __syncthreads_or(nan);
+    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, any_nan ? __uint_as_float(0x7fc00000u) : bm);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   __shared__ float red[16];
@@ -320,8 +604,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
+template <typename T, bool AT, bool BT, int WM, int WN>
+void launch_glds(GemmArgs& a, hipStream_t st) {
+  constexpr int TBM = WM * 64, TBN = WN * 64;
+  constexpr int shmem = 3 * (TBM + TBN) * 128;
+  a.tiles_m = (a.M + TBM - 1) / TBM; a.tiles_n = (a.N + TBN - 1) / TBN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, AT, BT, WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_glds_kernel<T, AT, BT, WM, WN>), dim3(a.tiles_m * a.tiles_n, a.splitk), dim3(WM * WN * 64),
+                     shmem, st, a);
+}
+template <typename T, int WM, int WN>
+void launch_glds_layout(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
+  if (!d->trans_a && !d->trans_b) launch_glds<T, false, false, WM, WN>(a, st);
+  else if (!d->trans_a && d->trans_b) launch_glds<T, false, true, WM, WN>(a, st);
+  else if (d->trans_a && d->trans_b) launch_glds<T, true, true, WM, WN>(a, st);
+  else launch_glds<T, true, false, WM, WN>(a, st);
+}
+
 template <typename T>
 int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
+  const bool glds_ok = (a.K % BK) == 0 && a.M >= 64 && a.N >= 64 && (!d->trans_a || (a.M & 7) == 0) &&
+                       (!d->trans_b || (a.N & 7) == 0) && d->kernel_variant != 1;
+  if (glds_ok) {
+    launch_glds_layout<T, 4, 2>(d, a, st);
+    if (a.splitk > 1) {
+      const size_t nvec = (size_t)a.M * (a.N / 8);
+      int blocks = (int)((nvec + 255) / 256); if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, a);
+    }
+    return cogv_check_launch();
+  }
   dim3 grid(a.tiles_m * a.tiles_n, a.splitk), block(NTHREADS);
   const size_t shmem = 65536;
 #define LAUNCH(AT_, BT_)                                                                                 \
@@ -357,12 +674,14 @@ extern "C" size_t cogv_gemm_workspace_bytes(const cogv_gemm_desc* d) {
 // Heuristic used by the host side: split the contraction when the output has too few tiles to fill 256 CUs
 // (weight-gradient GEMMs of the 336M config: 64..256 tiles, contraction = b*1088 tokens).
 extern "C" int cogv_gemm_pick_splitk(int M, int N, int K) {
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  // generation-2 kernel: 256x128 tiles, one workgroup per CU (256 CUs).  Split when fewer than 1.5 rounds of
+  // tiles exist, to about 3 rounds, keeping >= 8 k-tiles per split.
+  const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
   const int nk = (K + BK - 1) / BK;
-  if (tiles >= 512 || nk < 8) return 1;
-  int s = (1024 + tiles - 1) / tiles;
-  if (s > nk / 4) s = nk / 4;
-  if (s > 32) s = 32;
+  if (tiles >= 384 || nk < 16) return 1;
+  int s = (768 + tiles - 1) / tiles;
+  if (s > nk / 8) s = nk / 8;
+  if (s > 64) s = 64;
   return s < 1 ? 1 : s;
 }
 

@@ -105,7 +105,7 @@ def collect_gemm_timing():
 
 
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, gelu_aux=None, dgelu_aux=None,
-         dropout=None, absmax=None, accumulate=False, splitk=None, out_dtype=None):
+         dropout=None, absmax=None, accumulate=False, splitk=None, out_dtype=None, variant=0):
     """C[M,N] = epilogue(A_op[M,K] . B_op[N,K]^T); a, b 2-D, last dim contiguous.
     trans_a: `a` is stored [K, M];  trans_b: `b` is stored [K, N].
     dropout = (p, seed, stream_id).  Returns C."""
@@ -156,6 +156,7 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
     if splitk is None:
         splitk = lib.cogv_gemm_pick_splitk(M, N, K)
     d.splitk = int(splitk)
+    d.kernel_variant = int(variant)
     if d.splitk > 1:
         nbytes = lib.cogv_gemm_workspace_bytes(C.byref(d))
         ws = workspace("gemm_splitk", nbytes, a.device)

@@ -1,0 +1,13 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cogview_amd import ops
+M, N, K = 17408, 4096, 1024
+x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.05
+dy = torch.randn(M, N, device="cuda", dtype=torch.bfloat16)
+for _ in range(3):
+    ops.gemm(x, w)
+    ops.gemm(dy, w, trans_b=True)                       # NN dgrad
+    ops.gemm(dy, x, trans_a=True, trans_b=True)         # TN wgrad
+torch.cuda.synchronize()
