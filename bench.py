@@ -97,7 +97,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cogview-small-336M", choices=list(CONFIGS))
-    ap.add_argument("--batch", type=int, default=16, help="micro-batch per GPU (sequences of 1089 tokens)")
+    ap.add_argument("--batch", type=int, default=30,
+                    help="micro-batch per GPU (sequences of 1089 tokens); 30 x 1088 rows = 127.5 -> 128 row-tiles of 256, i.e. "
+                         "whole rounds of 256-row x 128-column GEMM tiles on 256 CUs for every N of the 336M config")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--dropout", type=float, default=0.1, help="reference default (arguments.py:30,40)")
     ap.add_argument("--checkpoint-activations", action="store_true",
@@ -205,7 +207,7 @@ def main():
         "mfma_roofline_frac_end_to_end": value / world * fpt / 1e12 / PEAK_MFMA_TFLOPS,
     }
     if gemm_stats is not None:
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<%s> (NT fwd + NN dgrad + TN wgrad, 128x128x64 MFMA tiles)" % args.dtype,
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_glds_kernel<%s> (NT fwd + NN dgrad + TN wgrad; 256x128x64 tiles, LDS-DMA 3-stage ring)" % args.dtype,
                            "achieved": gemm_stats["tflops"], "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": gemm_stats["tflops"] / PEAK_MFMA_TFLOPS, "traffic": None,
                            "launches": gemm_stats["launches"], "avg_launch_ms": gemm_stats["avg_ms"],

@@ -14,8 +14,14 @@
 // accumulator registers are *already* a valid B-operand fragment for the next MFMA (O^T = V^T P^T etc.),
 // because the hardware's k-slot <-> (lane-group g, element e) map may be relabelled freely as long as the
 // A operand uses the same relabelling:   slot(g, e) of k-step t  <->  index 16t + 8(e>>2) + 4g + (e&3).
-// The A operands that need the contraction index contiguous (V^T, K^T, Q^T, dO^T) are produced by a
-// register transpose while staging HBM -> LDS (4 rows x 8 columns per thread, ds_write_b64 granules).
+//
+// Data movement: every K / V / Q / dO tile (64 rows x 64 halves) is DMA'd ONCE, in its natural layout, straight
+// into a 3-stage LDS ring (global_load_lds_dwordx4, prefetch distance two blocks, counted vmcnt, raw s_barrier).
+// Operands whose contraction index runs along the tile ROWS (V^T, K^T, Q^T, dO^T) are read with the LDS
+// transposing read ds_read_b64_tr_b16 (semantics verified by tools/probes/tr_read_probe.hip); operands whose
+// contraction index is d are read with ds_read_b128 from the SAME tile.  One XOR swizzle of the 16-B chunk
+// index, aswz(row) = (b1<<2)|(b3<<1)|b2, keeps both read patterns bank-conflict free; it is applied to the
+// per-lane DMA source address (the DMA writes LDS linearly).  No staging registers, no register transposes.
 //
 // q/k/v are addressed as base + b*batch_stride + row*row_stride + head*64, i.e. straight out of the
 // [b, s, 3*h/p] QKV GEMM output -- the reference's _transpose_for_scores permute copies
@@ -23,11 +29,14 @@
 #include "common.cuh"
 #include "cogview_hip.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int HD = 64;          // head dim
 constexpr int NT = 256;         // threads per block (4 waves)
 constexpr float MASKED = -10000.0f;
+constexpr int TILE = 8192;      // one 64 x 64 16-bit tile
 
 struct AttnArgs {
   const void* q; const void* k; const void* v; void* o;        // forward
@@ -40,86 +49,69 @@ struct AttnArgs {
   uint32_t thr16; float keep_scale; uint32_t rng_key;
 };
 
-__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-// ---- natural tile: ROWS x 64 halves, 128 B per row, 16-B chunk swizzle (read with ds_read_b128)
-template <typename T, int ROWS>
-struct NatStage {
-  static constexpr int PER = ROWS * 8 / NT;   // 16-B chunks per thread
-  u32x4 r[PER > 0 ? PER : 1];
-  __device__ __forceinline__ void load(const T* base, long long rs, int row0, int nrows) {
-#pragma unroll
-    for (int p = 0; p < PER; ++p) {
-      const int idx = threadIdx.x + p * NT;
-      const int row = idx >> 3, chunk = idx & 7;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (row0 + row < nrows) v = *reinterpret_cast<const u32x4*>(base + (long long)(row0 + row) * rs + chunk * 8);
-      r[p] = v;
-    }
-  }
-  __device__ __forceinline__ void store(char* lds) const {
-#pragma unroll
-    for (int p = 0; p < PER; ++p) {
-      const int idx = threadIdx.x + p * NT;
-      const int row = idx >> 3, chunk = idx & 7;
-      *reinterpret_cast<u32x4*>(lds + row * 128 + ((chunk ^ swz(row)) << 4)) = r[p];
-    }
-  }
-};
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// chunk swizzle of a 64-row tile: row bit 1 -> chunk bit 2 (separates the rows r, r+2 of a transpose block),
+// row bits 3,2 -> chunk bits 1,0 (with bit 1: a bijection of (row>>1)&7, which makes ds_read_b128 conflict free)
+__device__ __forceinline__ int aswz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+// DMA of one tile: 8 pieces of 1 KiB (8 rows each); wave w issues pieces w and w+4.  Rows beyond `nrows` are
+// clamped to the last valid row (finite data; every use of such a row is masked out by the kernels).
 template <typename T>
-__device__ __forceinline__ typename HT<T>::v8 nat_frag(const char* lds, int row, int chunk) {
-  return *reinterpret_cast<const typename HT<T>::v8*>(lds + row * 128 + ((chunk ^ swz(row)) << 4));
+__device__ __forceinline__ void dma_tile(const T* base, long long rs, int row0, int nrows, char* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = wave + 4 * i;
+    const int row = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ aswz(row);
+    const int gr = min(row0 + row, nrows - 1);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + (long long)gr * rs + c * 8), (lds_void_t*)(lds + piece * 1024), 16, 0, 0);
+  }
+}
+// 64 floats (one per row of the current block) -> LDS; every wave issues it (same data) to keep vmcnt uniform
+__device__ __forceinline__ void dma_stat(const float* base, int row0, int nrows, char* lds, int lane) {
+  const int gr = min(row0 + lane, nrows - 1);
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + gr), (lds_void_t*)lds, 4, 0, 0);
 }
 
-// ---- transposed tile: source ROWS x 64 (row-major) -> LDS [64 cols][ROWS] halves, row = ROWS*2 bytes,
-//      8-byte granules (4 source rows) XOR-swizzled by ((col >> 1) & (G-1)), G = granules per LDS row.
-//      Staged by a 128-thread half of the block (ROWS == 64: one item each; ROWS == 32: threads 0..63 of it).
-template <typename T, int ROWS>
-struct TrStage {
-  u32x4 r[4];
-  // tid: 0..127 index inside the staging half
-  __device__ __forceinline__ void load(const T* base, long long rs, int row0, int nrows, int tid) {
-    const int c = tid & 7, rg = tid >> 3;        // 8-column chunk, 4-row group
-    if (rg * 4 < ROWS) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        const int row = row0 + rg * 4 + i;
-        if (row < nrows) v = *reinterpret_cast<const u32x4*>(base + (long long)row * rs + c * 8);
-        r[i] = v;
-      }
-    }
-  }
-  __device__ __forceinline__ void store(char* lds, int tid) const {
-    constexpr int G = ROWS / 4;                  // granules per LDS row
-    const int c = tid & 7, rg = tid >> 3;
-    if (rg * 4 < ROWS) {
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        u32x2 lo, hi;
-        lo[0] = (r[0][w] & 0xffffu) | (r[1][w] << 16);
-        lo[1] = (r[2][w] & 0xffffu) | (r[3][w] << 16);
-        hi[0] = (r[0][w] >> 16) | (r[1][w] & 0xffff0000u);
-        hi[1] = (r[2][w] >> 16) | (r[3][w] & 0xffff0000u);
-        const int ce = c * 8 + 2 * w, co = ce + 1;
-        *reinterpret_cast<u32x2*>(lds + ce * (ROWS * 2) + ((rg ^ ((ce >> 1) & (G - 1))) << 3)) = lo;
-        *reinterpret_cast<u32x2*>(lds + co * (ROWS * 2) + ((rg ^ ((co >> 1) & (G - 1))) << 3)) = hi;
-      }
-    }
-  }
-};
-// A-operand fragment from a transposed tile: row = output index (d), contraction slots of k-step `t16`
-// (16 source rows starting at src0): elements e -> source row src0 + 8(e>>2) + 4g + (e&3)
-template <typename T, int ROWS>
-__device__ __forceinline__ typename HT<T>::v8 tr_frag(const char* lds, int col, int src0, int g) {
-  constexpr int G = ROWS / 4;
-  const int g0 = (src0 >> 2) + g;       // granule holding rows src0+4g .. +3
-  const int g1 = g0 + 2;                // rows src0+8+4g .. +3
-  const int sw = (col >> 1) & (G - 1);
-  const u32x2 a = *reinterpret_cast<const u32x2*>(lds + col * (ROWS * 2) + ((g0 ^ sw) << 3));
-  const u32x2 b = *reinterpret_cast<const u32x2*>(lds + col * (ROWS * 2) + ((g1 ^ sw) << 3));
-  u32x4 w; w[0] = a[0]; w[1] = a[1]; w[2] = b[0]; w[3] = b[1];
-  typename HT<T>::v8 out; __builtin_memcpy(&out, &w, 16);
+template <typename T>
+__device__ __forceinline__ typename HT<T>::v8 nat_frag(const char* lds, int row, int chunk) {
+  return *reinterpret_cast<const typename HT<T>::v8*>(lds + row * 128 + ((chunk ^ aswz(row)) << 4));
+}
+
+// Transposed A-operand fragment: output row i = d = 32*dblk + (lane&31); contraction slots (g, e) <-> tile row
+// src0 + 8(e>>2) + 4g + (e&3).  Two ds_read_b64_tr_b16 (rows src0+4g.. and src0+8+4g..), issued through inline asm
+// (the builtin form makes hipcc drain vmcnt(0) in front of every read while LDS-DMA is in flight).
+struct TrRaw { u32x2 lo, hi; };
+__device__ __forceinline__ uint32_t tr_lane_off(int dblk, int lane) {
+  // byte offset inside a tile for src0 = 0, WITHOUT the row-dependent swizzle of rows >= 4 (added per call)
+  const int G = lane >> 4, cb = G & 1, g = G >> 1, r = (lane & 15) >> 2, qq = lane & 3;
+  const int c = 4 * dblk + 2 * cb + (qq >> 1);
+  return (uint32_t)((4 * g + r) * 128 + ((c ^ ((r >> 1) << 2)) << 4) + (qq & 1) * 8);
+}
+// rows src0 + 4g + r: bits 3,2 of the row come from (src0 + 4g) -> chunk bits 1,0; src0 is a multiple of 8, so
+// bit 2 = g (already lane-dependent): fold g's contribution here, src0's (bit 3 and up) at the call.
+__device__ __forceinline__ uint32_t tr_lane_fix(int lane) { return (uint32_t)((((lane >> 5) & 1)) << 4); }   // chunk bit 0 <- row bit 2 = g
+template <int SRC0>
+__device__ __forceinline__ void tr_issue(uint32_t tile_addr, uint32_t lane_off, TrRaw& o) {
+  // row = SRC0 + 4g + r (+8 for the second read).  chunk ^= (b3<<1) where b3 = bit 3 of the row:
+  //   first read : b3 = (SRC0 >> 3) & 1 ; second read: b3 = ((SRC0 + 8) >> 3) & 1
+  constexpr int X0 = (((SRC0 >> 3) & 1) << 1) << 4, X1 = ((((SRC0 + 8) >> 3) & 1) << 1) << 4;
+  const uint32_t a0 = tile_addr + SRC0 * 128 + (lane_off ^ X0);        // lane_off < 1024: the XOR stays inside
+  const uint32_t a1 = tile_addr + (SRC0 + 8) * 128 + (lane_off ^ X1);  // the 128-B row of this lane
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(o.lo), "=&v"(o.hi) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ void tr_wait(TrRaw& a, TrRaw& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) : : "memory");
+}
+template <typename T>
+__device__ __forceinline__ typename HT<T>::v8 tr_pack(const TrRaw& r) {
+  typename HT<T>::v8 out;
+  __builtin_memcpy(&out, &r.lo, 8);
+  __builtin_memcpy(reinterpret_cast<char*>(&out) + 8, &r.hi, 8);
   return out;
 }
 
@@ -139,19 +131,73 @@ __device__ __forceinline__ typename HT<T>::v8 load_frag_global(const T* rowptr, 
 
 __device__ __forceinline__ bool visible(int q, int key, int off, int sep_k) { return key <= q + off || key < sep_k; }
 
+// raw v_exp_f32 (2^x): no denormal-range fix-up sequence (softmax terms that small are zero anyway)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Masking of one 32-element accumulator fragment whose element e has index base + (e&3) + 8*(e>>2) along the
+// masked axis.  `lim` = largest visible index relative to `base` (visible iff rel <= lim) and `bound` = number of
+// valid indices relative to `base`; both are per-lane scalars, the per-element offsets are compile-time constants.
+// Only called for blocks that touch the diagonal / the sequence end (wave-uniform branch at the call site).
+__device__ __forceinline__ void mask_frag(f32x16& a, int lim, int lim_sep, int bound, float masked_raw) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int rel = (e & 3) + 8 * (e >> 2);
+    float v = a[e];
+    v = (rel <= lim || rel < lim_sep) ? v : masked_raw;     // reference: score*M - 10000*(1-M)
+    v = (rel < bound) ? v : -INFINITY;                       // padding beyond the sequence: not a key at all
+    a[e] = v;
+  }
+}
+
 // dropout bits for (attention row `arow` = (b*H+head)*s_q + q, keys key0..key0+3, key0 % 4 == 0)
 __device__ __forceinline__ u32x2 attn_bits(uint32_t key, long long arow, int ngrp, int key0) {
   return Philox::gen64_k(key, (uint64_t)(arow * ngrp + (key0 >> 2)));
 }
 __device__ __forceinline__ uint32_t bits_of(const u32x2& r, int i) { return (r[i >> 1] >> (16 * (i & 1))) & 0xffffu; }
 
+// 4 transposed fragments (2 d-blocks x k-steps t = 0,1 of a 32-row sub-block SB) of one tile
+template <typename T, int SB>
+__device__ __forceinline__ void tr_frags_issue(uint32_t tile_addr, const uint32_t (&loff)[2], TrRaw (&r)[2][2]) {
+#pragma unroll
+  for (int d = 0; d < 2; ++d) { tr_issue<SB * 32>(tile_addr, loff[d], r[0][d]); tr_issue<SB * 32 + 16>(tile_addr, loff[d], r[1][d]); }
+}
+
+// Synchronous variant (reads + wait in ONE asm statement): the destination registers are valid when the
+// statement ends, so it stays correct even if the compiler spills them.  Used by the dK/dV kernel, whose
+// register pressure is at the limit; the asynchronous form above must only be used in spill-free kernels
+// (cogview_amd/csrc/build.py checks ScratchSize == 0 for them).
+template <typename T, int SB>
+__device__ __forceinline__ void tr_frags_sync(uint32_t tile_addr, const uint32_t (&loff)[2], TrRaw (&r)[2][2]) {
+  constexpr int S0 = SB * 32, S1 = SB * 32 + 16;
+  constexpr int XA = (((S0 >> 3) & 1) << 1) << 4, XB = ((((S0 + 8) >> 3) & 1) << 1) << 4;
+  constexpr int XC = (((S1 >> 3) & 1) << 1) << 4, XD = ((((S1 + 8) >> 3) & 1) << 1) << 4;
+  uint32_t a[2][4];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    a[d][0] = tile_addr + S0 * 128 + (loff[d] ^ XA);
+    a[d][1] = tile_addr + (S0 + 8) * 128 + (loff[d] ^ XB);
+    a[d][2] = tile_addr + S1 * 128 + (loff[d] ^ XC);
+    a[d][3] = tile_addr + (S1 + 8) * 128 + (loff[d] ^ XD);
+  }
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\tds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
+      "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\tds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r[0][0].lo), "=&v"(r[0][0].hi), "=&v"(r[1][0].lo), "=&v"(r[1][0].hi),
+        "=&v"(r[0][1].lo), "=&v"(r[0][1].hi), "=&v"(r[1][1].lo), "=&v"(r[1][1].hi)
+      : "v"(a[0][0]), "v"(a[0][1]), "v"(a[0][2]), "v"(a[0][3]), "v"(a[1][0]), "v"(a[1][1]), "v"(a[1][2]), "v"(a[1][3])
+      : "memory");
+}
+
 // =====================================================================================================
-// forward: grid (ceil(s_q/128), H, B); wave w owns queries q0 + 32w .. +31
+// forward: grid (ceil(s_q/128), H, B); wave w owns queries q0 + 32w .. +31.  Ring stage = K tile | V tile.
 // =====================================================================================================
 template <typename T>
-__global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K 8 KiB + V^T 8 KiB)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 stages x 16 KiB
+  constexpr int STAGE = 2 * TILE, LPT = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 31, fg = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
   const int q0 = blockIdx.x * 128, q0w = q0 + wave * 32;
@@ -166,7 +212,6 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) qf[t] = load_frag_global<T>(Q + (long long)myq * p.q_rs + 16 * t + 8 * fg, myq < p.s_q);
 
-  // key range: the block needs keys up to the last row's horizon (or the visible prefix)
   const int q_last = min(p.s_q, q0 + 128) - 1;
   const int kend_blk = min(p.s_k, max(q_last + off + 1, p.sep_k));
   const int nkb = (kend_blk + 63) >> 6;
@@ -179,28 +224,26 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const float sl2 = p.scale * 1.4426950408889634f;   // scores are kept in the log2 domain
-  const float masked_l2 = MASKED * 1.4426950408889634f;
+  const float sl2 = p.scale * 1.4426950408889634f;   // raw score -> log2 domain
+  const float masked_raw = MASKED / p.scale;         // raw value whose scaled score is exactly -10000
   const long long arow = ((long long)b * p.H + head) * p.s_q + myq;
   const int ngrp = (p.s_k + 3) >> 2;
+  const uint32_t loff[2] = {tr_lane_off(0, lane) ^ tr_lane_fix(lane), tr_lane_off(1, lane) ^ tr_lane_fix(lane)};
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
 
-  NatStage<T, 64> ks; TrStage<T, 64> vs;
-  const bool vstager = threadIdx.x < 128;
-  auto g_load = [&](int kb) {
-    ks.load(K, p.k_rs, kb * 64, p.s_k);
-    if (vstager) vs.load(V, p.v_rs, kb * 64, p.s_k, threadIdx.x);
+  auto issue = [&](int kb, int st) {
+    dma_tile<T>(K, p.k_rs, kb * 64, p.s_k, smem + st * STAGE, wave, lane);
+    dma_tile<T>(V, p.v_rs, kb * 64, p.s_k, smem + st * STAGE + TILE, wave, lane);
   };
-  auto l_store = [&](int s) {
-    ks.store(smem + s * 16384);
-    if (vstager) vs.store(smem + s * 16384 + 8192, threadIdx.x);
-  };
-  if (nkb > 0) { g_load(0); l_store(0); }
-  __syncthreads();
+  if (nkb > 0) { issue(0, 0); issue(nkb > 1 ? 1 : 0, 1); }
+  int st = 0;
   for (int kb = 0; kb < nkb; ++kb) {
-    const int cur = kb & 1;
-    if (kb + 1 < nkb) g_load(kb + 1);
+    wait_vmcnt<LPT>();
+    __builtin_amdgcn_s_barrier();
+    issue(min(kb + 2, nkb - 1), st == 0 ? 2 : st - 1);
     if (kb * 64 < kend_w) {
-      const char* lk = smem + cur * 16384; const char* lv = lk + 8192;
+      const char* lk = smem + st * STAGE;
+      const uint32_t lv = smem_addr + st * STAGE + TILE;
       f32x16 sacc[2];
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
@@ -210,66 +253,80 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs p) {
         for (int t = 0; t < 4; ++t)
           sacc[sb] = HT<T>::mfma32(nat_frag<T>(lk, sb * 32 + fr, 2 * t + fg), qf[t], sacc[sb]);
       }
-      // mask + scale (log2 domain), block max
-      float mb = -INFINITY;
+      // V^T fragments of the first 32 keys: issued now, consumed after the softmax
+      TrRaw vr[2][2];
+      tr_frags_issue<T, 0>(lv, loff, vr);
+      const int kfirst = kb * 64;
+      const bool all_visible = (kfirst + 63 <= q0w + off) || (kfirst + 63 < p.sep_k);
+      if (!all_visible || kfirst + 64 > p.s_k) {
 #pragma unroll
-      for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = kb * 64 + sb * 32 + (e & 3) + 8 * (e >> 2) + 4 * fg;
-          float s = sacc[sb][e] * sl2;
-          if (!visible(myq, key, off, p.sep_k)) s = masked_l2;
-          if (key >= p.s_k) s = -INFINITY;
-          sacc[sb][e] = s;
-          mb = fmaxf(mb, s);
+        for (int sb = 0; sb < 2; ++sb) {
+          const int base = kfirst + sb * 32 + 4 * fg;
+          mask_frag(sacc[sb], myq + off - base, p.sep_k - base, p.s_k - base, masked_raw);
         }
-      mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
-      const float m_new = fmaxf(m_run, mb);
-      const float alpha = exp2f(m_run - m_new);
-      m_run = m_new;
+      }
+      float mb = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+      for (int e = 1; e < 16; ++e) mb = fmaxf(mb, fmaxf(sacc[0][e], sacc[1][e]));
+      mb = fmaxf(mb, __shfl_xor(mb, 32, 64)) * sl2;
+      if (!__all(mb <= m_run)) {               // running max grew for some row of this wave: rescale (rare later on)
+        const float m_new = fmaxf(m_run, mb);
+        const float alpha = fast_exp2(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+      }
       float ls = 0.f;
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const float pv = exp2f(sacc[sb][e] - m_new); sacc[sb][e] = pv; ls += pv; }
-      l_run = l_run * alpha + ls;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+        for (int e = 0; e < 16; ++e) { const float pv = fast_exp2(fmaf(sacc[sb][e], sl2, -m_run)); sacc[sb][e] = pv; ls += pv; }
+      l_run += ls;
       if (p.thr16) {
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
-            const int key0 = kb * 64 + sb * 32 + 8 * gq + 4 * fg;
-            const u32x2 r = attn_bits(p.rng_key, arow, ngrp, key0);
+            const u32x2 r = attn_bits(p.rng_key, arow, ngrp, kb * 64 + sb * 32 + 8 * gq + 4 * fg);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               sacc[sb][4 * gq + i] = (bits_of(r, i) >= p.thr16) ? sacc[sb][4 * gq + i] * p.keep_scale : 0.f;
           }
       }
       // O^T[d][query] += V^T[d][key] . P^T[key][query]
+      TrRaw vr2[2][2];
+      tr_wait(vr[0][0], vr[0][1]); tr_wait(vr[1][0], vr[1][1]);
+      tr_frags_issue<T, 1>(lv, loff, vr2);
 #pragma unroll
-      for (int sb = 0; sb < 2; ++sb)
+      for (int t = 0; t < 2; ++t) {
+        float pe[8];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          float pe[8];
+        for (int e = 0; e < 8; ++e) pe[e] = sacc[0][8 * t + e];
+        const typename HT<T>::v8 pb = cvt8<T>(pe);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) pe[e] = sacc[sb][8 * t + e];
-          const typename HT<T>::v8 pb = cvt8<T>(pe);
+        for (int d = 0; d < 2; ++d) oacc[d] = HT<T>::mfma32(tr_pack<T>(vr[t][d]), pb, oacc[d]);
+      }
+      tr_wait(vr2[0][0], vr2[0][1]); tr_wait(vr2[1][0], vr2[1][1]);
 #pragma unroll
-          for (int d = 0; d < 2; ++d)
-            oacc[d] = HT<T>::mfma32(tr_frag<T, 64>(lv, d * 32 + fr, sb * 32 + 16 * t, fg), pb, oacc[d]);
-        }
+      for (int t = 0; t < 2; ++t) {
+        float pe[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pe[e] = sacc[1][8 * t + e];
+        const typename HT<T>::v8 pb = cvt8<T>(pe);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) oacc[d] = HT<T>::mfma32(tr_pack<T>(vr2[t][d]), pb, oacc[d]);
+      }
     }
-    if (kb + 1 < nkb) l_store(cur ^ 1);
-    __syncthreads();
+    st = (st == 2) ? 0 : st + 1;
   }
+  wait_vmcnt<0>();
   if (wave_active && myq < p.s_q) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (fg == 0 && p.lse) p.lse[((long long)b * p.H + head) * p.s_q + myq] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+    if (fg == 0 && p.lse) p.lse[((long long)b * p.H + head) * p.s_q + myq] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
     T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + (long long)myq * p.o_rs + head * HD;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -307,11 +364,14 @@ __global__ __launch_bounds__(256) void attn_dvec_kernel(const AttnArgs p) {
 
 // =====================================================================================================
 // dQ: grid (ceil(s_q/128), H, B); lane = query.   dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
+// Ring stage = K tile | V tile (K serves both S^T (natural read) and dQ^T (transposing read)).
 // =====================================================================================================
 template <typename T>
-__global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K 8K + V 8K + K^T 8K)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 2 * TILE, LPT = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 31, fg = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
   const int q0 = blockIdx.x * 128, q0w = q0 + wave * 32;
@@ -335,7 +395,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const AttnArgs p) {
   const float dv = qvalid ? p.dvec[arow] : 0.f;
   const int ngrp = (p.s_k + 3) >> 2;
   const float sl2 = p.scale * 1.4426950408889634f;
-  const float masked_l2 = MASKED * 1.4426950408889634f;
+  const float masked_raw = MASKED / p.scale;
 
   const int q_last = min(p.s_q, q0 + 128) - 1;
   const int kend_blk = min(p.s_k, max(q_last + off + 1, p.sep_k));
@@ -348,28 +408,24 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const AttnArgs p) {
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dqacc[d][e] = 0.f;
+  const uint32_t loff[2] = {tr_lane_off(0, lane) ^ tr_lane_fix(lane), tr_lane_off(1, lane) ^ tr_lane_fix(lane)};
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
 
-  NatStage<T, 64> ks, vs; TrStage<T, 64> kts;
-  const bool tstager = threadIdx.x < 128;
-  auto g_load = [&](int kb) {
-    ks.load(K, p.k_rs, kb * 64, p.s_k);
-    vs.load(V, p.v_rs, kb * 64, p.s_k);
-    if (tstager) kts.load(K, p.k_rs, kb * 64, p.s_k, threadIdx.x);
+  auto issue = [&](int kb, int st) {
+    dma_tile<T>(K, p.k_rs, kb * 64, p.s_k, smem + st * STAGE, wave, lane);
+    dma_tile<T>(V, p.v_rs, kb * 64, p.s_k, smem + st * STAGE + TILE, wave, lane);
   };
-  auto l_store = [&](int s) {
-    ks.store(smem + s * 24576);
-    vs.store(smem + s * 24576 + 8192);
-    if (tstager) kts.store(smem + s * 24576 + 16384, threadIdx.x);
-  };
-  if (nkb > 0) { g_load(0); l_store(0); }
-  __syncthreads();
+  if (nkb > 0) { issue(0, 0); issue(nkb > 1 ? 1 : 0, 1); }
+  int st = 0;
   for (int kb = 0; kb < nkb; ++kb) {
-    const int cur = kb & 1;
-    if (kb + 1 < nkb) g_load(kb + 1);
+    wait_vmcnt<LPT>();
+    __builtin_amdgcn_s_barrier();
+    issue(min(kb + 2, nkb - 1), st == 0 ? 2 : st - 1);
     if (kb * 64 < kend_w) {
-      const char* lk = smem + cur * 24576; const char* lv = lk + 8192; const char* lkt = lk + 16384;
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
+      const char* lk = smem + st * STAGE; const char* lv = lk + TILE;
+      const uint32_t lkt = smem_addr + st * STAGE;
+      auto half = [&](auto SBc) {
+        constexpr int sb = decltype(SBc)::value;
         f32x16 sacc, pacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; pacc[e] = 0.f; }
@@ -378,36 +434,42 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const AttnArgs p) {
           sacc = HT<T>::mfma32(nat_frag<T>(lk, sb * 32 + fr, 2 * t + fg), qf[t], sacc);     // S^T
           pacc = HT<T>::mfma32(nat_frag<T>(lv, sb * 32 + fr, 2 * t + fg), dof[t], pacc);    // dP^T = V dO^T
         }
+        TrRaw kr[2][2];
+        tr_frags_issue<T, sb>(lkt, loff, kr);
+        const int kfirst = kb * 64 + sb * 32;
+        const bool all_visible = (kfirst + 31 <= q0w + off) || (kfirst + 31 < p.sep_k);
+        if (!all_visible || kfirst + 32 > p.s_k) {
+          const int base = kfirst + 4 * fg;
+          mask_frag(sacc, myq + off - base, p.sep_k - base, p.s_k - base, masked_raw);
+        }
         float ds[16];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const int key0 = kb * 64 + sb * 32 + 8 * gq + 4 * fg;
           u32x2 r = {0u, 0u};
-          if (p.thr16) r = attn_bits(p.rng_key, arow, ngrp, key0);
+          if (p.thr16) r = attn_bits(p.rng_key, arow, ngrp, kfirst + 8 * gq + 4 * fg);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int e = 4 * gq + i, key = key0 + i;
-            float s = sacc[e] * sl2;
-            if (!visible(myq, key, off, p.sep_k)) s = masked_l2;
-            float pr = exp2f(s - lse2);
-            if (key >= p.s_k) pr = 0.f;
+            const int e = 4 * gq + i;
+            const float pr = fast_exp2(fmaf(sacc[e], sl2, -lse2));
             float dp = pacc[e];
             if (p.thr16) dp = (bits_of(r, i) >= p.thr16) ? dp * p.keep_scale : 0.f;
             ds[e] = pr * (dp - dv);
           }
         }
+        tr_wait(kr[0][0], kr[0][1]); tr_wait(kr[1][0], kr[1][1]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const typename HT<T>::v8 dsb = cvt8<T>(ds + 8 * t);
 #pragma unroll
-          for (int d = 0; d < 2; ++d)
-            dqacc[d] = HT<T>::mfma32(tr_frag<T, 64>(lkt, d * 32 + fr, sb * 32 + 16 * t, fg), dsb, dqacc[d]);
+          for (int d = 0; d < 2; ++d) dqacc[d] = HT<T>::mfma32(tr_pack<T>(kr[t][d]), dsb, dqacc[d]);
         }
-      }
+      };
+      half(std::integral_constant<int, 0>{});
+      half(std::integral_constant<int, 1>{});
     }
-    if (kb + 1 < nkb) l_store(cur ^ 1);
-    __syncthreads();
+    st = (st == 2) ? 0 : st + 1;
   }
+  wait_vmcnt<0>();
   if (qvalid) {
     T* DQ = reinterpret_cast<T*>(p.dq) + b * p.dq_bs + (long long)myq * p.dq_rs + head * HD;
 #pragma unroll
@@ -425,13 +487,15 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const AttnArgs p) {
 // =====================================================================================================
 // dK/dV: grid (ceil(s_k/128), H, B); lane = key.
 //   dV^T[d][key] = sum_q dO^T[d][q] Pd[q][key]        dK^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
+// Ring stage = Q tile | dO tile | LSE[64] | D[64]  (64 queries per stage; Q and dO each serve a natural and a
+// transposing read).
 // =====================================================================================================
 template <typename T>
-__global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(const AttnArgs p) {
-  // per stage: Q 8K | dO 8K | Q^T 8K | dO^T 8K | lse 256 B | dvec 256 B   (64 queries per stage)
+__global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = 4 * 8192 + 512;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int STAGE = 2 * TILE + 512, LPT = 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 31, fg = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
   const int k0 = blockIdx.x * 128, k0w = k0 + wave * 32;
@@ -452,13 +516,13 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(const AttnArgs p) {
     kf[t] = load_frag_global<T>(K + (long long)mykey * p.k_rs + 16 * t + 8 * fg, kvalid);
     vf[t] = load_frag_global<T>(V + (long long)mykey * p.v_rs + 16 * t + 8 * fg, kvalid);
   }
-  // first query that can see any key of this block / wave (keys < sep_k are seen by every query)
   const int qbeg_blk = (k0 < p.sep_k) ? 0 : max(0, k0 - off);
   const int qbeg_w = (k0w < p.sep_k) ? 0 : max(0, k0w - off);
   const int qb0 = qbeg_blk >> 6;
   const int nqb = (p.s_q + 63) >> 6;
   const float sl2 = p.scale * 1.4426950408889634f;
-  const float masked_l2 = MASKED * 1.4426950408889634f;
+  const float l2e = 1.4426950408889634f;
+  const float masked_raw = MASKED / p.scale;
   const int ngrp = (p.s_k + 3) >> 2;
   const long long arow0 = ((long long)b * p.H + head) * p.s_q;
 
@@ -467,35 +531,28 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(const AttnArgs p) {
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dkacc[d][e] = 0.f; dvacc[d][e] = 0.f; }
+  const uint32_t loff[2] = {tr_lane_off(0, lane) ^ tr_lane_fix(lane), tr_lane_off(1, lane) ^ tr_lane_fix(lane)};
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
 
-  NatStage<T, 64> qs, dos; TrStage<T, 64> ts;   // waves 0,1 transpose Q ; waves 2,3 transpose dO
-  float st_l = 0.f, st_d = 0.f;
-  auto g_load = [&](int qb) {
-    qs.load(Q, p.q_rs, qb * 64, p.s_q);
-    dos.load(DO, p.do_rs, qb * 64, p.s_q);
-    if (threadIdx.x < 128) ts.load(Q, p.q_rs, qb * 64, p.s_q, threadIdx.x);
-    else ts.load(DO, p.do_rs, qb * 64, p.s_q, threadIdx.x - 128);
-    if (threadIdx.x < 64) { const int q = qb * 64 + threadIdx.x; st_l = q < p.s_q ? LSE[q] * 1.4426950408889634f : 0.f; }
-    else if (threadIdx.x < 128) { const int q = qb * 64 + threadIdx.x - 64; st_d = q < p.s_q ? DV[q] : 0.f; }
+  auto issue = [&](int qb, int st) {
+    char* base = smem + st * STAGE;
+    dma_tile<T>(Q, p.q_rs, qb * 64, p.s_q, base, wave, lane);
+    dma_tile<T>(DO, p.do_rs, qb * 64, p.s_q, base + TILE, wave, lane);
+    dma_stat(LSE, qb * 64, p.s_q, base + 2 * TILE, lane);
+    dma_stat(DV, qb * 64, p.s_q, base + 2 * TILE + 256, lane);
   };
-  auto l_store = [&](int s) {
-    char* base = smem + s * STAGE;
-    qs.store(base); dos.store(base + 8192);
-    if (threadIdx.x < 128) ts.store(base + 16384, threadIdx.x); else ts.store(base + 24576, threadIdx.x - 128);
-    float* stat = reinterpret_cast<float*>(base + 32768);
-    if (threadIdx.x < 64) stat[threadIdx.x] = st_l; else if (threadIdx.x < 128) stat[threadIdx.x] = st_d;
-  };
-  if (qb0 < nqb) { g_load(qb0); l_store(0); }
-  __syncthreads();
+  if (qb0 < nqb) { issue(qb0, 0); issue(min(qb0 + 1, nqb - 1), 1); }
+  int st = 0;
   for (int qb = qb0; qb < nqb; ++qb) {
-    const int cur = (qb - qb0) & 1;
-    if (qb + 1 < nqb) g_load(qb + 1);
+    wait_vmcnt<LPT>();
+    __builtin_amdgcn_s_barrier();
+    issue(min(qb + 2, nqb - 1), st == 0 ? 2 : st - 1);
     if (wave_active && qb * 64 + 63 >= qbeg_w) {
-      const char* lq = smem + cur * STAGE; const char* ldo = lq + 8192;
-      const char* lqt = lq + 16384; const char* ldot = lq + 24576;
-      const float* stat = reinterpret_cast<const float*>(lq + 32768);
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
+      const char* lq = smem + st * STAGE; const char* ldo = lq + TILE;
+      const uint32_t lqt = smem_addr + st * STAGE, ldot = lqt + TILE;
+      const float* stat = reinterpret_cast<const float*>(lq + 2 * TILE);
+      auto half = [&](auto SBc) {
+        constexpr int sb = decltype(SBc)::value;
         f32x16 sacc, pacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; pacc[e] = 0.f; }
@@ -504,43 +561,84 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(const AttnArgs p) {
           sacc = HT<T>::mfma32(nat_frag<T>(lq, sb * 32 + fr, 2 * t + fg), kf[t], sacc);     // S = Q K^T
           pacc = HT<T>::mfma32(nat_frag<T>(ldo, sb * 32 + fr, 2 * t + fg), vf[t], pacc);    // dPd = dO V^T
         }
+        // element e <-> query qfirst + 4fg + (e&3) + 8(e>>2); key fixed per lane
+        const int qfirst = qb * 64 + sb * 32;
+        const bool all_visible = (qfirst >= k0w + 31 - off) || (k0w + 31 < p.sep_k);
+        const bool tail = qfirst + 32 > p.s_q;
+        // Dropout bits: the generator's group is (query row, 4 consecutive keys).  The 4 lanes of a quad hold the 4
+        // keys of one group, so lane c of the quad hashes only the queries with (e & 3) == c, reduces each 64-bit
+        // draw to a 4-bit keep mask (bit f <-> key 4m+f) and the quad shares it by a broadcast DPP move:
+        // 4 hashes per lane per 32x32 tile instead of 16.
+        uint32_t kmask[4] = {0u, 0u, 0u, 0u};
+        if (p.thr16) {
+          const int c = lane & 3;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int q = qb * 64 + sb * 32 + 8 * gq + 4 * fg + c;
+            const u32x2 r = attn_bits(p.rng_key, arow0 + q, ngrp, mykey & ~3);
+            uint32_t m4 = 0;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) m4 |= (bits_of(r, f) >= p.thr16 ? 1u : 0u) << f;
+            kmask[gq] = m4;
+          }
+        }
+        const int kbit = mykey & 3;
         float pd[16], ds[16];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int ql = sb * 32 + 8 * gq + 4 * fg;                // local query of element i = 0
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + ql);
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + 64 + ql);
+          uint32_t km[4];
+          if (p.thr16) {                                           // quad_perm(i,i,i,i): value held by quad lane i
+            km[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)kmask[gq], 0x00, 0xf, 0xf, true);
+            km[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)kmask[gq], 0x55, 0xf, 0xf, true);
+            km[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)kmask[gq], 0xaa, 0xf, 0xf, true);
+            km[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)kmask[gq], 0xff, 0xf, 0xf, true);
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int e = 4 * gq + i, q = qb * 64 + ql + i;
-            float s = sacc[e] * sl2;
-            if (!visible(q, mykey, off, p.sep_k)) s = masked_l2;
-            float pr = exp2f(s - l4[i]);
-            if (q >= p.s_q || !kvalid) pr = 0.f;
+            const int e = 4 * gq + i;
+            float a = sacc[e];
+            if (!all_visible) { const int q = qb * 64 + ql + i; if (!visible(q, mykey, off, p.sep_k)) a = masked_raw; }
+            float pr = fast_exp2(fmaf(a, sl2, -l4[i] * l2e));
+            if (tail) { if (qb * 64 + ql + i >= p.s_q) pr = 0.f; }
             float keep = 1.f;
-            if (p.thr16) {
-              const u32x2 r = attn_bits(p.rng_key, arow0 + q, ngrp, mykey & ~3);
-              keep = (bits_of(r, mykey & 3) >= p.thr16) ? p.keep_scale : 0.f;
-            }
+            if (p.thr16) keep = ((km[i] >> kbit) & 1u) ? p.keep_scale : 0.f;
             pd[e] = pr * keep;
             ds[e] = pr * (pacc[e] * keep - d4[i]);
           }
         }
+        if (!kvalid) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const typename HT<T>::v8 pb = cvt8<T>(pd + 8 * t);
-          const typename HT<T>::v8 dsb = cvt8<T>(ds + 8 * t);
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            dvacc[d] = HT<T>::mfma32(tr_frag<T, 64>(ldot, d * 32 + fr, sb * 32 + 16 * t, fg), pb, dvacc[d]);
-            dkacc[d] = HT<T>::mfma32(tr_frag<T, 64>(lqt, d * 32 + fr, sb * 32 + 16 * t, fg), dsb, dkacc[d]);
-          }
+          for (int e = 0; e < 16; ++e) { pd[e] = 0.f; ds[e] = 0.f; }
         }
-      }
+        typename HT<T>::v8 pb[2], dsb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { pb[t] = cvt8<T>(pd + 8 * t); dsb[t] = cvt8<T>(ds + 8 * t); }
+        {
+          TrRaw dor[2][2];
+          tr_frags_sync<T, sb>(ldot, loff, dor);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) dvacc[d] = HT<T>::mfma32(tr_pack<T>(dor[t][d]), pb[t], dvacc[d]);
+        }
+        {
+          TrRaw qr[2][2];
+          tr_frags_sync<T, sb>(lqt, loff, qr);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) dkacc[d] = HT<T>::mfma32(tr_pack<T>(qr[t][d]), dsb[t], dkacc[d]);
+        }
+      };
+      half(std::integral_constant<int, 0>{});
+      half(std::integral_constant<int, 1>{});
     }
-    if (qb + 1 < nqb) l_store(cur ^ 1);
-    __syncthreads();
+    st = (st == 2) ? 0 : st + 1;
   }
+  wait_vmcnt<0>();
   if (kvalid) {
     T* DK = reinterpret_cast<T*>(p.dk) + b * p.dk_bs + (long long)mykey * p.dk_rs + head * HD;
     T* DVp = reinterpret_cast<T*>(p.dv) + b * p.dv_bs + (long long)mykey * p.dv_rs + head * HD;
@@ -600,7 +698,7 @@ extern "C" int cogv_attention_fwd(const cogv_attn_desc* d, void* stream) {
   if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs) & 7) return COGV_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((a.s_q + 127) / 128, a.H, a.B);
-  const int sh = 2 * 16384;
+  const int sh = 3 * 2 * TILE;
   if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), grid, dim3(NT), sh, st, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, dim3(NT), sh, st, a);
   return cogv_check_launch();
@@ -619,7 +717,7 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   const long long nrow = (long long)a.B * a.H * a.s_q;
   const int gD = (int)((nrow * 8 + 255) / 256);
   dim3 gq((a.s_q + 127) / 128, a.H, a.B), gk((a.s_k + 127) / 128, a.H, a.B);
-  const int sh_q = 2 * 24576, sh_k = 2 * (4 * 8192 + 512);
+  const int sh_q = 3 * 2 * TILE, sh_k = 3 * (2 * TILE + 512);
   static bool attr = false;
   if (!attr) {
     set_smem(&attn_bwd_dkdv_kernel<f16_t>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t>, sh_k);

@@ -37,11 +37,30 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+# Kernels that issue LDS reads through inline asm and wait for them in a LATER statement: a compiler spill of
+# the destination register between the two would store garbage.  They must be spill-free.
+NO_SPILL_KERNELS = ("attn_fwd_kernel", "attn_bwd_dq_kernel", "gemm_glds_kernel")
+
+
+def _check_no_spill(src, log):
+    import re
+    name = None
+    for line in log.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and any(k in name for k in NO_SPILL_KERNELS) and int(m.group(1)) != 0:
+            raise RuntimeError(f"{src}: kernel {name} uses asynchronous asm LDS reads but has "
+                               f"{m.group(1)} B/lane of scratch (register spills): unsafe, refusing to build")
+
+
 def _compile(src, obj):
-    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    _check_no_spill(src, r.stderr)
     return obj
 
 
