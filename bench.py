@@ -213,6 +213,16 @@ def main():
                            "launches": gemm_stats["launches"], "avg_launch_ms": gemm_stats["avg_ms"],
                            "share_of_step_time": gemm_stats["total_ms"] / (elapsed * 1e3),
                            "by_variant_tflops": gemm_stats["by_variant"]}
+    if gemm_stats is not None:
+        # HBM-side traffic of the dominant kernel: measured off-line with rocprofv3 PMC passes (tools/collect_traffic.sh,
+        # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read correction) for the DEFAULT workload only.
+        tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic_pmc_336M_b30.json")
+        if os.path.exists(tpath) and args.config == "cogview-small-336M" and args.batch == 30:
+            t = json.load(open(tpath))
+            algo = gemm_stats["algo_bytes"] / max(gemm_stats["launches"], 1)
+            out["roofline"]["traffic"] = t["gemm_glds_hbm_bytes_per_launch_corrected"]
+            out["roofline"]["traffic_unit"] = "bytes per launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE, includes Infinity-Cache hits)"
+            out["roofline"]["algorithmic_bytes_per_launch"] = algo
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(L, h, heads)
     if rank == 0:

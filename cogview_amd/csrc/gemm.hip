@@ -323,16 +323,23 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// fragment of a natural region: rows = output index
-template <typename T>
-__device__ __forceinline__ typename HT<T>::v8 frag_nat(const char* reg, int row, int ks, int fg) {
-  return read_frag<T>(reg, row, 2 * ks + fg);
+// ---- LDS addressing of the DMA kernel, parameterised by the k-tile depth BKT (64 or 32 halves per row)
+//   natural region : [rows][BKT] , row = 2*BKT bytes, NC = BKT/8 16-B chunks per row
+//       BKT = 64: chunk c at c ^ swz(row)            (rows r, r+1 share a 256-B bank row)
+//       BKT = 32: chunk c at c ^ ((row >> 2) & 3)    (4 rows share a bank row; rows r, r+4, r+8, r+12 get
+//                                                      different chunks, so any 16 distinct rows are conflict free)
+template <int BKT> __device__ __forceinline__ int nswz(int row) {
+  return BKT == 64 ? swz(row) : ((row >> 2) & 3);
 }
-// fragment of a transposed region ([64 k][TB cols], ROWB bytes per k-row): 32-wide column block at col0.
+template <int BKT> __device__ __forceinline__ uint32_t nat_off(int row, int chunk) {
+  return (uint32_t)(row * (2 * BKT) + ((chunk ^ nswz<BKT>(row)) << 4));
+}
+
+// fragment of a transposed region ([BKT k][TB cols], ROWB bytes per k-row): 32-wide column block at col0.
 // Issued through inline asm: with the __builtin_amdgcn_ds_read_tr16_b64 form hipcc (ROCm 7.2) orders the read
 // against the in-flight LDS-DMA and emits s_waitcnt vmcnt(0) in front of it, draining the prefetch ring every
 // k-step (measured: 70 % of wave cycles parked).  The asm reads are invisible to the compiler's counters, so
-// the matching wait is explicit (tr_wait) and carries the destination registers as in/out operands.
+// the matching wait is explicit (tr_wait2) and carries the destination registers as in/out operands.
 struct TrRaw { u32x2 lo, hi; };
 template <int ROWB>
 __device__ __forceinline__ uint32_t tr_addr(const char* reg, int col0, int lane) {
@@ -367,12 +374,24 @@ __device__ __forceinline__ typename HT<T>::v8 tr_pack(const TrRaw& r) {
   return out;
 }
 
-template <typename T, bool AT, bool BT, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(const GemmArgs p) {
-  constexpr int NW = WM * WN, TBM = WM * 64, TBN = WN * 64;
-  constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_PER = TBM / 8 / NW, B_PER = TBN / 8 / NW;      // 1-KiB DMA pieces per wave per k-tile
+// waves per SIMD the register allocation must allow: BKT = 64 -> one 8-wave workgroup per CU (2);
+// BKT = 32 -> two 8-wave workgroups (4) or three 4-wave workgroups (3) per CU
+// Workgroups per CU the register allocation must allow (expressed as waves per SIMD):
+//   ring <= 80 KiB (BKT = 32) -> two workgroups per CU (three for the small 128x128 tile), else one.
+constexpr int glds_min_waves(int nw, int ring_bytes) {
+  return (ring_bytes <= 53 * 1024 ? 3 : ring_bytes <= 80 * 1024 ? 2 : 1) * nw / 4;
+}
+
+// per-wave tile = (32*MI) x (32*NJ); workgroup tile = (WM*32*MI) x (WN*32*NJ); WM*WN waves
+template <typename T, bool AT, bool BT, int WM, int WN, int MI, int NJ, int BKT>
+__global__ __launch_bounds__(WM * WN * 64, glds_min_waves(WM * WN, 3 * (WM * 32 * MI + WN * 32 * NJ) * 2 * BKT))
+void gemm_glds_kernel(const GemmArgs p) {
+  constexpr int NW = WM * WN, TBM = WM * 32 * MI, TBN = WN * 32 * NJ;
+  constexpr int A_BYTES = TBM * 2 * BKT, B_BYTES = TBN * 2 * BKT, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PER = A_BYTES / 1024 / NW, B_PER = B_BYTES / 1024 / NW;      // 1-KiB DMA pieces per wave per k-tile
   constexpr int LPT = A_PER + B_PER;
+  constexpr int KS = BKT / 16;                                                 // MFMA k-steps per k-tile
+  constexpr int RPP_N = 1024 / (2 * BKT);                                      // natural rows per DMA piece
   static_assert(A_PER >= 1 && B_PER >= 1, "tile too small for the wave count");
   extern __shared__ __attribute__((aligned(16))) char smem[];     // 3 * STAGE
 
@@ -391,11 +410,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(const GemmArgs 
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = (wave / WN) * 64, wn = (wave % WN) * 64;
+  const int wm = (wave / WN) * (32 * MI), wn = (wave % WN) * (32 * NJ);
   const int fr = lane & 31, fg = lane >> 5;
-  const int nk_total = p.K / BK;
-  const int kt0 = blockIdx.y * p.ktiles_per_split;
-  const int nk = min(nk_total, kt0 + p.ktiles_per_split) - kt0;   // >= 1 by construction
+  const int nk_total = p.K / BKT;
+  const int kt0 = blockIdx.y * p.ktiles_per_split * (BK / BKT);
+  const int nk = min(nk_total, kt0 + p.ktiles_per_split * (BK / BKT)) - kt0;   // >= 1 by construction
 
   // per-lane DMA source pointers for k-tile 0 of this split, and the per-k-tile byte stride
   const char* srcA[A_PER];
@@ -404,38 +423,38 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(const GemmArgs 
   for (int i = 0; i < A_PER; ++i) {
     const int piece = i * NW + wave;
     if (!AT) {
-      const int row = piece * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ swz(row);
+      const int row = piece * RPP_N + lane / (BKT / 8);
+      const int c = (lane % (BKT / 8)) ^ nswz<BKT>(row);
       const int gm = min(m0 + row, p.M - 1);
-      srcA[i] = reinterpret_cast<const char*>(p.A) + ((size_t)gm * p.lda + (size_t)kt0 * BK + c * 8) * 2;
+      srcA[i] = reinterpret_cast<const char*>(p.A) + ((size_t)gm * p.lda + (size_t)kt0 * BKT + c * 8) * 2;
     } else {
       constexpr int ROWB = TBM * 2;
       const int off = piece * 1024 + lane * 16;
       const int krow = off / ROWB, pc = (off % ROWB) >> 4;
       const int c = pc ^ ((krow & 3) << 2);
       const int col = min(m0 + c * 8, p.M - 8);
-      srcA[i] = reinterpret_cast<const char*>(p.A) + ((size_t)((size_t)kt0 * BK + krow) * p.lda + col) * 2;
+      srcA[i] = reinterpret_cast<const char*>(p.A) + ((size_t)((size_t)kt0 * BKT + krow) * p.lda + col) * 2;
     }
   }
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) {
     const int piece = i * NW + wave;
     if (!BT) {
-      const int row = piece * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ swz(row);
+      const int row = piece * RPP_N + lane / (BKT / 8);
+      const int c = (lane % (BKT / 8)) ^ nswz<BKT>(row);
       const int gn = min(n0 + row, p.N - 1);
-      srcB[i] = reinterpret_cast<const char*>(p.B) + ((size_t)gn * p.ldb + (size_t)kt0 * BK + c * 8) * 2;
+      srcB[i] = reinterpret_cast<const char*>(p.B) + ((size_t)gn * p.ldb + (size_t)kt0 * BKT + c * 8) * 2;
     } else {
       constexpr int ROWB = TBN * 2;
       const int off = piece * 1024 + lane * 16;
       const int krow = off / ROWB, pc = (off % ROWB) >> 4;
       const int c = pc ^ ((krow & 3) << 2);
       const int col = min(n0 + c * 8, p.N - 8);
-      srcB[i] = reinterpret_cast<const char*>(p.B) + ((size_t)((size_t)kt0 * BK + krow) * p.ldb + col) * 2;
+      srcB[i] = reinterpret_cast<const char*>(p.B) + ((size_t)((size_t)kt0 * BKT + krow) * p.ldb + col) * 2;
     }
   }
-  const size_t kstrideA = AT ? (size_t)BK * p.lda * 2 : (size_t)BK * 2;
-  const size_t kstrideB = BT ? (size_t)BK * p.ldb * 2 : (size_t)BK * 2;
+  const size_t kstrideA = AT ? (size_t)BKT * p.lda * 2 : (size_t)BKT * 2;
+  const size_t kstrideB = BT ? (size_t)BKT * p.ldb * 2 : (size_t)BKT * 2;
   // one LDS-DMA instruction: piece idx in [0, LPT): first the A pieces of this wave, then the B pieces
   auto issue_piece = [&](int kt, int st, int idx) {
     char* la = smem + st * STAGE;
@@ -453,23 +472,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(const GemmArgs 
 #pragma unroll
     for (int i = 0; i < LPT; ++i) issue_piece(kt, st, i);
   };
-  f32x16 acc[2][2];
+
+  f32x16 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   issue(0, 0);
   issue(nk > 1 ? 1 : 0, 1);
   int st = 0;
-  constexpr int PPS = (LPT + 3) / 4;          // DMA pieces issued behind each of the 4 MFMA groups
-  constexpr int DSR = (AT || BT) ? 0 : 4;   // compiler-visible LDS reads per k-step
+  constexpr int PPS = (LPT + KS - 1) / KS;    // DMA pieces issued behind each MFMA group
+  constexpr int DSR = (AT || BT) ? 0 : MI + NJ;     // compiler-visible LDS reads per k-step
   // LDS byte addresses (stage 0) of this lane's transposing reads
-  uint32_t trA[2] = {0, 0}, trB[2] = {0, 0};
-  if (AT) { trA[0] = tr_addr<TBM * 2>(smem, wm, lane); trA[1] = tr_addr<TBM * 2>(smem, wm + 32, lane); }
-  if (BT) { trB[0] = tr_addr<TBN * 2>(smem + A_BYTES, wn, lane); trB[1] = tr_addr<TBN * 2>(smem + A_BYTES, wn + 32, lane); }
+  uint32_t trA[MI], trB[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) trA[i] = AT ? tr_addr<TBM * 2>(smem, wm + 32 * i, lane) : 0u;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) trB[j] = BT ? tr_addr<TBN * 2>(smem + A_BYTES, wn + 32 * j, lane) : 0u;
   for (int kt = 0; kt < nk; ++kt) {
     wait_vmcnt<LPT>();                         // tile kt has landed (the batch issued last iteration may be in flight)
     __builtin_amdgcn_s_barrier();              // ... for every wave; stage (kt+2)%3 is free again
@@ -480,47 +502,66 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(const GemmArgs 
     const char* la = smem + st * STAGE;
     const char* lb = la + A_BYTES;
     const uint32_t soff = (uint32_t)(st * STAGE);
-    typename HT<T>::v8 fa[2][2], fb[2][2];
-    TrRaw ta[2], tb[2];
-    u32x4 na[2], nb[2];
+    typename HT<T>::v8 fa[2][MI], fb[2][NJ];
+    TrRaw ta[MI], tb[NJ];
+    u32x4 na[MI], nb[NJ];
     constexpr bool ASM_ALL = AT || BT;         // mixed kernels: every fragment read is asm-issued
     auto fetch = [&](int ks, int buf) {        // fragments of k-step ks -> fa[buf], fb[buf] (asm reads stay raw)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm + 32 * i + fr;
         if (AT) tr_issue<TBM * 2>(trA[i] + soff, ks, ta[i]);
-        else if (ASM_ALL) { const int row = wm + 32 * i + fr; nat_issue((uint32_t)(uintptr_t)la + row * 128 + (((2 * ks + fg) ^ swz(row)) << 4), na[i]); }
-        else fa[buf][i] = frag_nat<T>(la, wm + 32 * i + fr, ks, fg);
+        else if (ASM_ALL) nat_issue((uint32_t)(uintptr_t)la + nat_off<BKT>(row, 2 * ks + fg), na[i]);
+        else fa[buf][i] = *reinterpret_cast<const typename HT<T>::v8*>(la + nat_off<BKT>(row, 2 * ks + fg));
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
+        const int row = wn + 32 * j + fr;
         if (BT) tr_issue<TBN * 2>(trB[j] + soff, ks, tb[j]);
-        else if (ASM_ALL) { const int row = wn + 32 * j + fr; nat_issue((uint32_t)(uintptr_t)lb + row * 128 + (((2 * ks + fg) ^ swz(row)) << 4), nb[j]); }
-        else fb[buf][j] = frag_nat<T>(lb, wn + 32 * j + fr, ks, fg);
+        else if (ASM_ALL) nat_issue((uint32_t)(uintptr_t)lb + nat_off<BKT>(row, 2 * ks + fg), nb[j]);
+        else fb[buf][j] = *reinterpret_cast<const typename HT<T>::v8*>(lb + nat_off<BKT>(row, 2 * ks + fg));
       }
     };
     auto land = [&](int buf) {                 // explicit wait + pack for the asm-issued reads
-      if (AT) { tr_wait2(ta[0], ta[1]); fa[buf][0] = tr_pack<T>(ta[0]); fa[buf][1] = tr_pack<T>(ta[1]); }
-      else if (ASM_ALL) { nat_wait2(na[0], na[1]); __builtin_memcpy(&fa[buf][0], &na[0], 16); __builtin_memcpy(&fa[buf][1], &na[1], 16); }
-      if (BT) { tr_wait2(tb[0], tb[1]); fb[buf][0] = tr_pack<T>(tb[0]); fb[buf][1] = tr_pack<T>(tb[1]); }
-      else if (ASM_ALL) { nat_wait2(nb[0], nb[1]); __builtin_memcpy(&fb[buf][0], &nb[0], 16); __builtin_memcpy(&fb[buf][1], &nb[1], 16); }
+      if (ASM_ALL) {
+        // one wait for everything issued by fetch(); every raw register is an in/out operand of some wait statement
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (AT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[i].lo), "+v"(ta[i].hi) : : "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na[i]) : : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (BT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[j].lo), "+v"(tb[j].hi) : : "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nb[j]) : : "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (AT) fa[buf][i] = tr_pack<T>(ta[i]); else __builtin_memcpy(&fa[buf][i], &na[i], 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (BT) fb[buf][j] = tr_pack<T>(tb[j]); else __builtin_memcpy(&fb[buf][j], &nb[j], 16);
+        }
+      }
     };
     fetch(0, 0);
     land(0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks < 3) fetch(ks + 1, nxt);
+      if (ks < KS - 1) fetch(ks + 1, nxt);
       if (AT || BT) __builtin_amdgcn_sched_barrier(0);     // keep the read issue ahead of the MFMA group
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = HT<T>::mfma32(fa[cur][i], fb[cur][j], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = HT<T>::mfma32(fa[cur][i], fb[cur][j], acc[i][j]);
 #pragma unroll
       for (int q2 = 0; q2 < PPS; ++q2)
         if (ks * PPS + q2 < LPT) issue_piece(kpf, pst, ks * PPS + q2);
       // pin the issue order inside this group: next fragments first (their LDS latency hides under the
       // MFMAs), DMA pieces between MFMAs.  Masks: 0x100 DS read, 0x008 MFMA, 0x010 VMEM.
-      if (ks < 3 && DSR > 0) {
+      if (ks < KS - 1 && DSR > 0) {
         __builtin_amdgcn_sched_group_barrier(0x100, DSR / 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, DSR - DSR / 2, 0);
@@ -528,50 +569,65 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(const GemmArgs 
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
 #pragma unroll
-      for (int q2 = 0; q2 < 3; ++q2) {
+      for (int q2 = 0; q2 < MI * NJ - 1; ++q2) {
         if (ks * PPS + q2 < LPT && q2 < PPS) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
-      if (ks < 3 && (AT || BT)) { __builtin_amdgcn_sched_barrier(0); land(nxt); }
+      if (ks < KS - 1 && (AT || BT)) { __builtin_amdgcn_sched_barrier(0); land(nxt); }
     }
     st = (st == 2) ? 0 : st + 1;
   }
   wait_vmcnt<0>();   // drain the (redundant) tail prefetches before the ring is reused
-  __syncthreads();   // every wave is done reading the ring: reuse it for the fp32 C tile [TBM][TBN]
+  __syncthreads();   // every wave is done reading the ring: reuse it for the fp32 C tile
 
+  // ---- epilogue: the fp32 C tile goes through the ring's LDS in NH row slabs of SLAB rows (the ring of the
+  //      BKT = 32 variants is smaller than the full C tile), then out with coalesced 16-byte accesses
+  constexpr int RING = 3 * STAGE;
+  constexpr int NH0 = (TBM * TBN * 4 + RING - 1) / RING;
+  constexpr int NH = NH0 <= 1 ? 1 : NH0 <= 2 ? 2 : 4;         // power of two so that SLAB divides the tile
+  constexpr int SLAB = TBM / NH;
+  static_assert(SLAB * TBN * 4 <= RING && SLAB % 32 == 0, "C slab does not fit the ring");
   float* ct = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        ct[(wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * fg) * TBN + wn + 32 * j + fr] = acc[i][j][e];
-  __syncthreads();
   float amax = 0.f; bool nan = false;
   constexpr int CPR = TBN / 8;                       // 8-column chunks per row
   constexpr int RPP = NW * 64 / CPR;                 // rows per pass
   const int cchunk = (threadIdx.x % CPR) * 8;
 #pragma unroll 1
-  for (int row = threadIdx.x / CPR; row < TBM; row += RPP) {
-    const int m = m0 + row, n = n0 + cchunk;
-    if (m < p.M && n < p.N) {
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(ct + row * TBN + cchunk);
-      const f32x4 x1 = *reinterpret_cast<const f32x4*>(ct + row * TBN + cchunk + 4);
-      if (p.splitk > 1) {
-        float* w = p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n;
-        *reinterpret_cast<f32x4*>(w) = x0;
-        *reinterpret_cast<f32x4*>(w + 4) = x1;
-      } else {
-        float v[8];
-        v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
-        v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
-        const float a = epilogue8<T>(p, m, n, v);
-        if (a != a) nan = true; else amax = fmaxf(amax, a);
+  for (int hs = 0; hs < NH; ++hs) {
+    if (hs > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if ((wm + 32 * i) / SLAB == hs) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            ct[((wm + 32 * i) % SLAB + (e & 3) + 8 * (e >> 2) + 4 * fg) * TBN + wn + 32 * j + fr] = acc[i][j][e];
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int row = threadIdx.x / CPR; row < SLAB; row += RPP) {
+      const int m = m0 + hs * SLAB + row, n = n0 + cchunk;
+      if (m < p.M && n < p.N) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(ct + row * TBN + cchunk);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(ct + row * TBN + cchunk + 4);
+        if (p.splitk > 1) {
+          float* w = p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n;
+          *reinterpret_cast<f32x4*>(w) = x0;
+          *reinterpret_cast<f32x4*>(w + 4) = x1;
+        } else {
+          float v[8];
+          v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
+          v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+          const float a = epilogue8<T>(p, m, n, v);
+          if (a != a) nan = true; else amax = fmaxf(amax, a);
+        }
       }
     }
   }
   if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
+    __syncthreads();
     float bm = block_max(amax, reinterpret_cast<float*>(smem));
     const bool any_nan = __syncthreads_or(nan);
     if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, any_nan ? __uint_as_float(0x7fc00000u) : bm);
@@ -604,26 +660,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
-template <typename T, bool AT, bool BT, int WM, int WN>
+template <typename T, bool AT, bool BT, int WM, int WN, int MI, int NJ, int BKT>
 void launch_glds(GemmArgs& a, hipStream_t st) {
-  constexpr int TBM = WM * 64, TBN = WN * 64;
-  constexpr int shmem = 3 * (TBM + TBN) * 128;
+  constexpr int TBM = WM * 32 * MI, TBN = WN * 32 * NJ;
+  constexpr int shmem = 3 * (TBM + TBN) * 2 * BKT;
   a.tiles_m = (a.M + TBM - 1) / TBM; a.tiles_n = (a.N + TBN - 1) / TBN;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, AT, BT, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, AT, BT, WM, WN, MI, NJ, BKT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<T, AT, BT, WM, WN>), dim3(a.tiles_m * a.tiles_n, a.splitk), dim3(WM * WN * 64),
-                     shmem, st, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, AT, BT, WM, WN, MI, NJ, BKT>), dim3(a.tiles_m * a.tiles_n, a.splitk),
+                     dim3(WM * WN * 64), shmem, st, a);
 }
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int MI, int NJ, int BKT>
 void launch_glds_layout(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
-  if (!d->trans_a && !d->trans_b) launch_glds<T, false, false, WM, WN>(a, st);
-  else if (!d->trans_a && d->trans_b) launch_glds<T, false, true, WM, WN>(a, st);
-  else if (d->trans_a && d->trans_b) launch_glds<T, true, true, WM, WN>(a, st);
-  else launch_glds<T, true, false, WM, WN>(a, st);
+  if (!d->trans_a && !d->trans_b) launch_glds<T, false, false, WM, WN, MI, NJ, BKT>(a, st);
+  else if (!d->trans_a && d->trans_b) launch_glds<T, false, true, WM, WN, MI, NJ, BKT>(a, st);
+  else if (d->trans_a && d->trans_b) launch_glds<T, true, true, WM, WN, MI, NJ, BKT>(a, st);
+  else launch_glds<T, true, false, WM, WN, MI, NJ, BKT>(a, st);
 }
 
 template <typename T>
@@ -631,7 +687,17 @@ int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
   const bool glds_ok = (a.K % BK) == 0 && a.M >= 64 && a.N >= 64 && (!d->trans_a || (a.M & 7) == 0) &&
                        (!d->trans_b || (a.N & 7) == 0) && d->kernel_variant != 1;
   if (glds_ok) {
-    launch_glds_layout<T, 4, 2>(d, a, st);
+    // variant 2: 256x128x64, 8 waves (64x64 each), one workgroup per CU   -- best for long-K NT (measured)
+    // variant 3: 256x128x32, 4 waves (128x64 each), two workgroups per CU -- default: the two workgroups' barrier
+    //            phases interleave on each SIMD, and a fat wave reads 6 fragments per 8 MFMAs instead of 4 per 4
+    // variant 4: 128x128x32, 4 waves (64x64 each), three workgroups per CU
+    // variant 5: 256x256x32, 8 waves (128x64 each), one workgroup per CU -- least L2->LDS traffic per flop: long-K NT
+    int variant = d->kernel_variant;
+    if (variant == 0) variant = (!d->trans_a && !d->trans_b && a.K >= 2048 && a.M >= 1024 && a.N >= 1024) ? 5 : 3;
+    if (variant == 3) launch_glds_layout<T, 2, 2, 4, 2, 32>(d, a, st);
+    else if (variant == 5) launch_glds_layout<T, 2, 4, 4, 2, 32>(d, a, st);   // 256x256x32, 8 fat waves, one WG per CU
+    else if (variant == 4) launch_glds_layout<T, 2, 2, 2, 2, 32>(d, a, st);
+    else launch_glds_layout<T, 4, 2, 2, 2, 64>(d, a, st);
     if (a.splitk > 1) {
       const size_t nvec = (size_t)a.M * (a.N / 8);
       int blocks = (int)((nvec + 255) / 256); if (blocks > 2048) blocks = 2048;
@@ -674,15 +740,20 @@ extern "C" size_t cogv_gemm_workspace_bytes(const cogv_gemm_desc* d) {
 // Heuristic used by the host side: split the contraction when the output has too few tiles to fill 256 CUs
 // (weight-gradient GEMMs of the 336M config: 64..256 tiles, contraction = b*1088 tokens).
 extern "C" int cogv_gemm_pick_splitk(int M, int N, int K) {
-  // generation-2 kernel: 256x128 tiles, one workgroup per CU (256 CUs).  Split when fewer than 1.5 rounds of
-  // tiles exist, to about 3 rounds, keeping >= 8 k-tiles per split.
+  // 256x128 tiles, two workgroups per CU => 512 concurrent workgroups per round.  Pick the split that fills
+  // whole rounds best; a split costs one fp32 slab write + a reduce pass, so it must pay for itself.
   const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
   const int nk = (K + BK - 1) / BK;
-  if (tiles >= 384 || nk < 16) return 1;
-  int s = (768 + tiles - 1) / tiles;
-  if (s > nk / 8) s = nk / 8;
-  if (s > 64) s = 64;
-  return s < 1 ? 1 : s;
+  if (tiles >= 1024 || nk < 16) return 1;
+  int best = 1; float best_score = -1.f;
+  for (int s = 1; s <= 16 && nk / s >= 8; ++s) {
+    const int items = tiles * s;
+    const int rounds = (items + 511) / 512;
+    const float eff = (float)items / (float)(rounds * 512);
+    const float score = eff - (s > 1 ? 0.04f : 0.f) - 0.004f * s;
+    if (score > best_score) { best_score = score; best = s; }
+  }
+  return best;
 }
 
 extern "C" int cogv_gemm(const cogv_gemm_desc* d, void* stream) {

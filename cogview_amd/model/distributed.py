@@ -23,7 +23,7 @@ from ..arena import arena_of, flatten_module
 class DistributedDataParallel(Module):
 
     def __init__(self, module, device_ids=None, output_device=None, process_group=None, overlap=True,
-                 bucket_layers=4):
+                 bucket_layers=4, force_collectives=False):
         super().__init__()
         self.module = module
         self.data_parallel_group = process_group if process_group is not None else mpu.get_data_parallel_group()
@@ -42,7 +42,10 @@ class DistributedDataParallel(Module):
                 for p in params:
                     dist.broadcast(p.data, src, group=self.data_parallel_group)
         self.needs_reduction = False
-        self.overlap = overlap and self.arena is not None and self.world > 1
+        # force_collectives: run the full bucketed / overlapped exchange even in a group of one rank (single-GPU
+        # test of the RCCL plumbing; a one-rank mean all-reduce is the identity)
+        self.force = bool(force_collectives)
+        self.overlap = overlap and self.arena is not None and (self.world > 1 or self.force)
         self.bucket_layers = max(1, bucket_layers)
         self._comm_stream = None
         self._pending, self._reduced_upto, self._layers_done = [], None, 0
@@ -106,7 +109,7 @@ class DistributedDataParallel(Module):
             return
         self.needs_reduction = False
         self._layers_done = 0
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.arena is None:
             for p in self.module.parameters():

@@ -88,17 +88,18 @@ def collect_gemm_timing():
     global _GEMM_TIMING
     rec, _GEMM_TIMING = _GEMM_TIMING, None
     torch.cuda.synchronize()
-    tot_ms, tot_fl, by = 0.0, 0.0, {}
-    for variant, fl, s, e in rec:
+    tot_ms, tot_fl, tot_by, by = 0.0, 0.0, 0.0, {}
+    for variant, fl, nbytes, s, e in rec:
         ms = s.elapsed_time(e)
         tot_ms += ms
         tot_fl += fl
+        tot_by += nbytes
         a = by.setdefault(variant, [0.0, 0.0, 0])
         a[0] += fl
         a[1] += ms
         a[2] += 1
     n = max(len(rec), 1)
-    return {"launches": len(rec), "total_ms": tot_ms, "avg_ms": tot_ms / n,
+    return {"launches": len(rec), "total_ms": tot_ms, "avg_ms": tot_ms / n, "algo_bytes": tot_by,
             "tflops": tot_fl / max(tot_ms, 1e-9) / 1e9,
             "by_variant": {k: {"tflops": v[0] / max(v[1], 1e-9) / 1e9, "launches": v[2], "avg_ms": v[1] / v[2]}
                            for k, v in by.items()}}
@@ -168,7 +169,7 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
         ev1.record()
         variant = ("T" if trans_a else "N") + ("T" if trans_b else "N")
         _GEMM_TIMING.append(({"NN": "NT_fwd", "NT": "NN_dgrad", "TT": "TN_wgrad", "TN": "TN_other"}[variant],
-                             2.0 * M * N * K, ev0, ev1))
+                             2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev0, ev1))
     else:
         L.check(lib.cogv_gemm(C.byref(d), _stream()), "cogv_gemm")
     return out

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_symbol():
     assert lib.cogv_version() == 1
     assert lib.cogv_arch() == b"gfx950"
     # pure host helpers are callable without a device
-    assert lib.cogv_gemm_pick_splitk(17408, 3072, 1024) == 1
+    assert lib.cogv_gemm_pick_splitk(32640, 3072, 1024) == 1
     assert lib.cogv_gemm_pick_splitk(1024, 1024, 17408) > 1
     assert lib.cogv_ln_bwd_workspace_bytes(1088, 1024) == lib.cogv_ln_bwd_num_blocks(1088) * 3 * 1024 * 4
 

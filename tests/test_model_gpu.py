@@ -208,3 +208,41 @@ def test_standalone_modules_autograd():
     for (n, p) in [("cw", col.weight), ("cb", col.bias), ("rw", row.weight), ("rb", row.bias), ("lw", ln.weight), ("lb", ln.bias)]:
         assert rel(p.grad, P[n].grad) < 1.5e-2, n
     assert all(hasattr(p, "model_parallel") for p in (col.weight, col.bias, row.weight))
+
+
+def test_data_parallel_wrapper_on_one_gpu(golden_dir):
+    """The bucketed, backward-overlapped gradient exchange (arena slices all-reduced on a side stream as groups of
+    layers finish) run for real over RCCL in a one-rank group: gradients must be bit-identical to the unwrapped
+    model (a one-rank mean is the identity) and every bucket must have been launched during backward."""
+    import torch.distributed as dist
+    from cogview_amd import mpu, training
+    from cogview_amd.model import PyTorchDistributedDataParallel
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29591")
+        dist.init_process_group("nccl", init_method="env://", world_size=1, rank=0)
+    if not mpu.model_parallel_is_initialized():
+        mpu.initialize_model_parallel(1)
+    g = _golden(golden_dir)
+    S_, B_ = int(g["cfg"][5]), int(g["cfg"][6])
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    batch = (g["tokens"].cuda(), g["labels"].cuda(), g["loss_mask"].cuda(), 0, pos)
+    ref = _build(g, torch.float16)
+    loss, _, _, _ = training.forward_step(batch, ref, log=False)
+    loss.backward()
+    want = ref.module._cogv_arena.grad.clone()
+    model = _build(g, torch.float16)
+    ddp = PyTorchDistributedDataParallel(model, process_group=mpu.get_data_parallel_group(), bucket_layers=1,
+                                         force_collectives=True)
+    assert ddp.overlap and len(ddp._buckets) == 2
+    loss2, _, _, _ = training.forward_step(batch, ddp, log=False)
+    loss2.backward()
+    assert len(ddp._pending) == 2, "layer buckets were not launched during backward"
+    ddp.allreduce_params(reduce_after=False)
+    torch.cuda.synchronize()
+    arena = model.module._cogv_arena
+    n_word = model.module.word_embeddings.weight.numel()
+    assert loss2.item() == loss.item()
+    assert torch.equal(arena.grad[n_word:], want[n_word:])
+    assert rel(arena.grad[:n_word], want[:n_word]) < 2e-3
+    assert not ddp.needs_reduction and ddp._pending == []
