@@ -7,9 +7,11 @@
 
 One "step" = one full training step of pretrain_gpt2.py's loop on one synthetic batch already resident in
 HBM: forward (GPT2Model) + fused cross entropy + backward + data-parallel gradient all-reduce + overflow check /
-global-norm clip / AdamW + 16-bit parameter write.  Workload at N=1: BASELINE.json configs[1] -- "336M"
-CogView-small, 24 layers / 1024 hidden / 16 heads, rows of 1089 random tokens (1088 model positions), vocab
-58240, weak scaling (per-GPU micro-batch fixed).  Prints ONE JSON line on stdout (rank 0).
+global-norm clip / AdamW + 16-bit parameter write.  Default workload: the configuration BASELINE.json's metric is
+quoted on -- the 4B CogView-base GPT (48 layers / 2560 hidden / 40 heads; 16 B/param of weights, master copy,
+Adam moments and gradients = 64 GB, so the whole model fits one 288-GB MI355X and every rank is a full data-parallel
+replica, BASELINE.json configs[3]) -- rows of 1089 random tokens (1088 model positions), vocab 58240, weak scaling
+(per-GPU micro-batch fixed).  `--config cogview-small-336M` runs configs[1].  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -29,6 +31,12 @@ CONFIGS = {
     "cogview-small-336M": (24, 1024, 16),
     "cogview-base-4B": (48, 2560, 40),
 }
+# per-GPU micro-batch (sequences): b x 1088 rows must fill whole rounds of 256-row GEMM tiles on 256 CUs.
+#   336M: 30 x 1088 = 127.5 -> 128 row tiles;  4B: 24 x 1088 = 102 row tiles exactly, and 102 x {10, 30, 40}
+#   column tiles of 256 are 3.98 / 11.95 / 15.94 rounds (activations 129 GB + 64 GB of model state < 288 GB)
+DEFAULT_BATCH = {"cogview-small-336M": 30, "cogview-base-4B": 24}
+METRIC = {"cogview-base-4B": "train tokens/sec/node (seq1089, 4B GPT) at 1/2/4/8 MI355X; % MFMA roofline",
+          "cogview-small-336M": "train tokens/sec/node (seq1089, 336M GPT) at 1/2/4/8 MI355X; % MFMA roofline"}
 VOCAB = 58240            # 58219 tokens padded to a multiple of 128 (arguments.py --make-vocab-size-divisible-by)
 N_TOKEN_IDS = 58219
 ROW = 1089               # tokens per data row; the model sees ROW-1 = 1088 positions (pretrain_gpt2.py:273-275)
@@ -96,10 +104,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="cogview-small-336M", choices=list(CONFIGS))
-    ap.add_argument("--batch", type=int, default=30,
-                    help="micro-batch per GPU (sequences of 1089 tokens); 30 x 1088 rows = 127.5 -> 128 row-tiles of 256, i.e. "
-                         "whole rounds of 256-row x 128-column GEMM tiles on 256 CUs for every N of the 336M config")
+    ap.add_argument("--config", default="cogview-base-4B", choices=list(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0,
+                    help="micro-batch per GPU (sequences of 1089 tokens); default per config (DEFAULT_BATCH)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--dropout", type=float, default=0.1, help="reference default (arguments.py:30,40)")
     ap.add_argument("--checkpoint-activations", action="store_true",
@@ -107,6 +114,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = DEFAULT_BATCH[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -193,7 +202,7 @@ def main():
     value = tokens_per_step * args.steps / elapsed
     fpt = flops_per_token(L, h, VOCAB)
     out = {
-        "metric": "train tokens/sec/node (seq1089, GPT) on MI355X", "value": value, "unit": "tokens/s",
+        "metric": METRIC[args.config], "value": value, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.config} ({L}L/{h}h/{heads} heads, {n_params / 1e6:.1f}M params), rows of 1089 "
@@ -207,7 +216,8 @@ def main():
         "mfma_roofline_frac_end_to_end": value / world * fpt / 1e12 / PEAK_MFMA_TFLOPS,
     }
     if gemm_stats is not None:
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_glds_kernel<%s> (NT fwd + NN dgrad + TN wgrad; 256x128x64 tiles, LDS-DMA 3-stage ring)" % args.dtype,
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp64_kernel / gemm_glds_kernel <%s> (NT fwd + NN dgrad: 256x256x64 ping-pong persistent; "
+                                                       "TN wgrad: 256x128x32 LDS-DMA ring + split-K)" % args.dtype,
                            "achieved": gemm_stats["tflops"], "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": gemm_stats["tflops"] / PEAK_MFMA_TFLOPS, "traffic": None,
                            "launches": gemm_stats["launches"], "avg_launch_ms": gemm_stats["avg_ms"],
@@ -216,11 +226,11 @@ def main():
     if gemm_stats is not None:
         # HBM-side traffic of the dominant kernel: measured off-line with rocprofv3 PMC passes (tools/collect_traffic.sh,
         # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read correction) for the DEFAULT workload only.
-        tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic_pmc_336M_b30.json")
-        if os.path.exists(tpath) and args.config == "cogview-small-336M" and args.batch == 30:
+        tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic_pmc_%s_b%d.json" % (args.config.split("-")[-1], args.batch))
+        if os.path.exists(tpath):
             t = json.load(open(tpath))
             algo = gemm_stats["algo_bytes"] / max(gemm_stats["launches"], 1)
-            out["roofline"]["traffic"] = t["gemm_glds_hbm_bytes_per_launch_corrected"]
+            out["roofline"]["traffic"] = t["gemm_hbm_bytes_per_launch_corrected"]
             out["roofline"]["traffic_unit"] = "bytes per launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE, includes Infinity-Cache hits)"
             out["roofline"]["algorithmic_bytes_per_launch"] = algo
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

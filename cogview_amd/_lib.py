@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcogview_hip.so")
+# COGVIEW_HIP_LIB points the loader at another build of the same ABI (kernel experiments); default: in-tree
+LIB_PATH = os.environ.get("COGVIEW_HIP_LIB") or os.path.join(_HERE, "lib", "libcogview_hip.so")
 
 F16, BF16, F32 = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_DROPOUT, EPI_ABSMAX, EPI_ACCUM = 1, 2, 4, 8, 16, 32

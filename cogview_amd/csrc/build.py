@@ -39,20 +39,75 @@ def _deps_mtime():
 
 # Kernels that issue LDS reads through inline asm and wait for them in a LATER statement: a compiler spill of
 # the destination register between the two would store garbage.  They must be spill-free.
-NO_SPILL_KERNELS = ("attn_fwd_kernel", "attn_bwd_dq_kernel", "gemm_glds_kernel")
+NO_SPILL_KERNELS = ("attn_fwd_kernel", "attn_bwd_dq_kernel", "gemm_glds_kernel", "gemm_pp64_kernel")
+
+
+def _scratch_in_mfma_loops(src):
+    """Compile `src` to device assembly and return the kernels that touch scratch INSIDE an innermost loop
+    containing MFMAs (the k-loop, where the asynchronous asm LDS reads live).  A spill outside it -- e.g. a value
+    parked across the persistent tile loop and reloaded at the top of each item -- cannot sit between an asm read
+    and its wait, so it is tolerated."""
+    import re, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        r = subprocess.run([_hipcc()] + FLAGS + ["--cuda-device-only", "-S", src, "-o", asm], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
+        lines = open(asm).read().splitlines()
+    bad, func, start = [], None, 0
+    bounds = []
+    for i, ln in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            if func:
+                bounds.append((func, start, i))
+            func, start = m.group(1), i
+    if func:
+        bounds.append((func, start, len(lines)))
+    for func, a, b in bounds:
+        if not any(k in func for k in NO_SPILL_KERNELS):
+            continue
+        body = lines[a:b]
+        labels = {}
+        for i, ln in enumerate(body):
+            m = re.match(r"^(\.LBB\d+_\d+):", ln)
+            if m:
+                labels[m.group(1)] = i
+        loops = []          # (head, backedge) line intervals
+        for j, ln in enumerate(body):
+            m = re.search(r"\bs_cbranch_\w+\s+(\.LBB\d+_\d+)|\bs_branch\s+(\.LBB\d+_\d+)", ln)
+            if m:
+                tgt = labels.get(m.group(1) or m.group(2))
+                if tgt is not None and tgt < j:
+                    loops.append((tgt, j))
+        mfma = [i for i, ln in enumerate(body) if "v_mfma" in ln]
+        inner = set()
+        for i in mfma:
+            enclosing = [(h, e) for h, e in loops if h < i < e]
+            if enclosing:
+                inner.add(min(enclosing, key=lambda he: he[1] - he[0]))
+        for h, e in inner:
+            if any("scratch_" in ln for ln in body[h:e + 1]):
+                bad.append(func)
+                break
+    return bad
 
 
 def _check_no_spill(src, log):
     import re
-    name = None
+    name, spilling = None, []
     for line in log.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = m.group(1)
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m and name and any(k in name for k in NO_SPILL_KERNELS) and int(m.group(1)) != 0:
-            raise RuntimeError(f"{src}: kernel {name} uses asynchronous asm LDS reads but has "
-                               f"{m.group(1)} B/lane of scratch (register spills): unsafe, refusing to build")
+            spilling.append((name, m.group(1)))
+    if spilling:
+        bad = _scratch_in_mfma_loops(src)
+        if bad:
+            raise RuntimeError(f"{src}: kernel(s) {bad} use asynchronous asm LDS reads and spill registers inside the "
+                               f"MFMA loop: unsafe, refusing to build")
 
 
 def _compile(src, obj):

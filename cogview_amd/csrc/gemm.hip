@@ -18,6 +18,10 @@
 #include "common.cuh"
 #include "cogview_hip.h"
 
+#ifndef COGV_EXP
+#define COGV_EXP 0     // schedule experiments of tools/probes/gemm_exp.py (bit 0: no DMA, 1: no reads, 2: no MFMA, 3: DMA re-reads k-tiles 0..3)
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -374,6 +378,64 @@ __device__ __forceinline__ typename HT<T>::v8 tr_pack(const TrRaw& r) {
   return out;
 }
 
+// ---- epilogue shared by the LDS-DMA kernels: the fp32 C tile goes through the (now idle) ring in NH row slabs,
+//      then out with coalesced 16-byte accesses through the fused epilogue8.  Call after a workgroup barrier.
+template <typename T, int NW, int TBM, int TBN, int MI, int NJ, int RING>
+__device__ __forceinline__ void store_c_tile(const GemmArgs& p, f32x16 (&acc)[MI][NJ], char* smem, int m0, int n0,
+                                             int wm, int wn, int fr, int fg, int ksplit) {
+  // ---- epilogue: the fp32 C tile goes through the ring's LDS in NH row slabs of SLAB rows (the ring of the
+  //      BKT = 32 variants is smaller than the full C tile), then out with coalesced 16-byte accesses
+  constexpr int NH0 = (TBM * TBN * 4 + RING - 1) / RING;
+  constexpr int NH = NH0 <= 1 ? 1 : NH0 <= 2 ? 2 : 4;         // power of two so that SLAB divides the tile
+  constexpr int SLAB = TBM / NH;
+  static_assert(SLAB * TBN * 4 <= RING && SLAB % 32 == 0, "C slab does not fit the ring");
+  float* ct = reinterpret_cast<float*>(smem);
+  float amax = 0.f; bool nan = false;
+  constexpr int CPR = TBN / 8;                       // 8-column chunks per row
+  constexpr int RPP = NW * 64 / CPR;                 // rows per pass
+  const int cchunk = (threadIdx.x % CPR) * 8;
+#pragma unroll 1
+  for (int hs = 0; hs < NH; ++hs) {
+    if (hs > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if ((wm + 32 * i) / SLAB == hs) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            ct[((wm + 32 * i) % SLAB + (e & 3) + 8 * (e >> 2) + 4 * fg) * TBN + wn + 32 * j + fr] = acc[i][j][e];
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int row = threadIdx.x / CPR; row < SLAB; row += RPP) {
+      const int m = m0 + hs * SLAB + row, n = n0 + cchunk;
+      if (m < p.M && n < p.N) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(ct + row * TBN + cchunk);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(ct + row * TBN + cchunk + 4);
+        if (p.splitk > 1) {
+          float* w = p.ws + ((size_t)ksplit * p.M + m) * p.N + n;
+          *reinterpret_cast<f32x4*>(w) = x0;
+          *reinterpret_cast<f32x4*>(w + 4) = x1;
+        } else {
+          float v[8];
+          v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
+          v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+          const float a = epilogue8<T>(p, m, n, v);
+          if (a != a) nan = true; else amax = fmaxf(amax, a);
+        }
+      }
+    }
+  }
+  if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
+    __syncthreads();
+    float bm = block_max(amax, reinterpret_cast<float*>(smem));
+    const bool any_nan = __syncthreads_or(nan);
+    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, any_nan ? __uint_as_float(0x7fc00000u) : bm);
+  }
+}
+
 // waves per SIMD the register allocation must allow: BKT = 64 -> one 8-wave workgroup per CU (2);
 // BKT = 32 -> two 8-wave workgroups (4) or three 4-wave workgroups (3) per CU
 // Workgroups per CU the register allocation must allow (expressed as waves per SIMD):
@@ -383,18 +445,32 @@ constexpr int glds_min_waves(int nw, int ring_bytes) {
 }
 
 // per-wave tile = (32*MI) x (32*NJ); workgroup tile = (WM*32*MI) x (WN*32*NJ); WM*WN waves
-template <typename T, bool AT, bool BT, int WM, int WN, int MI, int NJ, int BKT>
-__global__ __launch_bounds__(WM * WN * 64, glds_min_waves(WM * WN, 3 * (WM * 32 * MI + WN * 32 * NJ) * 2 * BKT))
+//
+// PP = true ("ping-pong", 8 waves, one workgroup per CU, NST-stage ring): the two halves of the workgroup run
+// one barrier apart.  A workgroup's waves w and w + 4 share a SIMD, so on every SIMD one wave is in its READ
+// phase (all fragment reads of a k-tile + the DMA issue of tile kt + NST - 1) while the other is in its MFMA phase
+// (16 back-to-back MFMAs at raised priority); two barriers per k-tile swap the roles.  Ordering argument (global
+// barrier index g; group 0 passes B1(kt) = 2kt, B2(kt) = 2kt + 1, group 1 one later):
+//   RAW  every wave certifies ITS pieces of tile kt+1 (counted vmcnt) before its B2(kt) <= 2kt + 2, and nobody
+//        reads tile kt+1 before passing 2kt + 2;
+//   WAR  tile kt + NST - 1 overwrites the stage of tile kt - 1, is issued after B1(kt) >= 2kt, and every read of
+//        tile kt - 1 was retired (lgkmcnt(0)) before that wave's B2(kt-1) <= 2kt.
+template <typename T, bool AT, bool BT, int WM, int WN, int MI, int NJ, int BKT, int NST = 3, bool PP = false>
+__global__ __launch_bounds__(WM * WN * 64, glds_min_waves(WM * WN, NST * (WM * 32 * MI + WN * 32 * NJ) * 2 * BKT))
 void gemm_glds_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN, TBM = WM * 32 * MI, TBN = WN * 32 * NJ;
+  static_assert(!PP || (NW == 8 && NST >= 3), "ping-pong schedule: 8 waves, >= 3 stages");
+  static_assert(PP || NST == 3, "the single-barrier schedule uses a 3-stage ring");
   constexpr int A_BYTES = TBM * 2 * BKT, B_BYTES = TBN * 2 * BKT, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PER = A_BYTES / 1024 / NW, B_PER = B_BYTES / 1024 / NW;      // 1-KiB DMA pieces per wave per k-tile
   constexpr int LPT = A_PER + B_PER;
   constexpr int KS = BKT / 16;                                                 // MFMA k-steps per k-tile
   constexpr int RPP_N = 1024 / (2 * BKT);                                      // natural rows per DMA piece
   static_assert(A_PER >= 1 && B_PER >= 1, "tile too small for the wave count");
-  extern __shared__ __attribute__((aligned(16))) char smem[];     // 3 * STAGE
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // NST * STAGE
 
+  uint64_t exp_t0 = 0, exp_r0 = 0;
+  if (COGV_EXP & 16) { exp_t0 = __builtin_readcyclecounter(); exp_r0 = __builtin_amdgcn_s_memrealtime(); }
   const int nwg = p.tiles_m * p.tiles_n;
   const int bid = blockIdx.x;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
@@ -481,17 +557,105 @@ void gemm_glds_kernel(const GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  issue(0, 0);
-  issue(nk > 1 ? 1 : 0, 1);
-  int st = 0;
-  constexpr int PPS = (LPT + KS - 1) / KS;    // DMA pieces issued behind each MFMA group
-  constexpr int DSR = (AT || BT) ? 0 : MI + NJ;     // compiler-visible LDS reads per k-step
   // LDS byte addresses (stage 0) of this lane's transposing reads
   uint32_t trA[MI], trB[NJ];
 #pragma unroll
   for (int i = 0; i < MI; ++i) trA[i] = AT ? tr_addr<TBM * 2>(smem, wm + 32 * i, lane) : 0u;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) trB[j] = BT ? tr_addr<TBN * 2>(smem + A_BYTES, wn + 32 * j, lane) : 0u;
+
+  if constexpr (PP) {
+    constexpr int D = NST - 1;                 // prefetch distance in k-tiles
+#pragma unroll
+    for (int t = 0; t < D; ++t) issue(min(t, nk - 1), t);
+    wait_vmcnt<(D - 1) * LPT>();               // this wave's pieces of tile 0 have landed
+    __builtin_amdgcn_s_barrier();              // ... and everybody's
+    const int grp = wave / (NW / 2);
+    if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger
+    int st = 0;
+    uint32_t nA[MI], nB[NJ];                   // natural-region read addresses (stage 0, k-step 0)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) nA[i] = (uint32_t)(uintptr_t)smem + nat_off<BKT>(wm + 32 * i + fr, fg);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) nB[j] = (uint32_t)(uintptr_t)(smem + A_BYTES) + nat_off<BKT>(wn + 32 * j + fr, fg);
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();            // B1: READ phase
+      __builtin_amdgcn_sched_barrier(0);
+      const uint32_t soff = (uint32_t)(st * STAGE);
+      TrRaw ta[KS][MI], tb[KS][NJ];
+      u32x4 na[KS][MI], nb[KS][NJ];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (COGV_EXP & 2) break;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (BT) tr_issue<TBN * 2>(trB[j] + soff, ks, tb[ks][j]);
+          else nat_issue((nB[j] + soff) ^ (uint32_t)(ks << 5), nb[ks][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (AT) tr_issue<TBM * 2>(trA[i] + soff, ks, ta[ks][i]);
+          else nat_issue((nA[i] + soff) ^ (uint32_t)(ks << 5), na[ks][i]);
+        }
+      }
+      {
+        const int kpf = min(kt + D, nk - 1);
+        const int pst = st == 0 ? NST - 1 : st - 1;        // == (st + D) % NST
+        if (!(COGV_EXP & 1)) issue(kpf, pst);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (AT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[ks][i].lo), "+v"(ta[ks][i].hi) : : "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na[ks][i]) : : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (BT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[ks][j].lo), "+v"(tb[ks][j].hi) : : "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nb[ks][j]) : : "memory");
+        }
+      }
+      wait_vmcnt<(D - 1) * LPT>();             // this wave's pieces of tile kt+1 have landed
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();            // B2: MFMA phase
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        typename HT<T>::v8 fa[MI], fb[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (AT) fa[i] = tr_pack<T>(ta[ks][i]); else __builtin_memcpy(&fa[i], &na[ks][i], 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (BT) fb[j] = tr_pack<T>(tb[ks][j]); else __builtin_memcpy(&fb[j], &nb[ks][j], 16);
+        }
+        if (COGV_EXP & 4) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(fa[i]));
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(fb[j]));
+          continue;
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = HT<T>::mfma32(fa[i], fb[j], acc[i][j]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      st = (st == NST - 1) ? 0 : st + 1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) __builtin_amdgcn_s_barrier();            // even out the barrier count
+  } else {
+  issue(0, 0);
+  issue(nk > 1 ? 1 : 0, 1);
+  int st = 0;
+  constexpr int PPS = (LPT + KS - 1) / KS;    // DMA pieces issued behind each MFMA group
+  constexpr int DSR = (AT || BT) ? 0 : MI + NJ;     // compiler-visible LDS reads per k-step
   for (int kt = 0; kt < nk; ++kt) {
     wait_vmcnt<LPT>();                         // tile kt has landed (the batch issued last iteration may be in flight)
     __builtin_amdgcn_s_barrier();              // ... for every wave; stage (kt+2)%3 is free again
@@ -577,60 +741,283 @@ void gemm_glds_kernel(const GemmArgs p) {
     }
     st = (st == 2) ? 0 : st + 1;
   }
+  }
   wait_vmcnt<0>();   // drain the (redundant) tail prefetches before the ring is reused
   __syncthreads();   // every wave is done reading the ring: reuse it for the fp32 C tile
 
-  // ---- epilogue: the fp32 C tile goes through the ring's LDS in NH row slabs of SLAB rows (the ring of the
-  //      BKT = 32 variants is smaller than the full C tile), then out with coalesced 16-byte accesses
-  constexpr int RING = 3 * STAGE;
-  constexpr int NH0 = (TBM * TBN * 4 + RING - 1) / RING;
-  constexpr int NH = NH0 <= 1 ? 1 : NH0 <= 2 ? 2 : 4;         // power of two so that SLAB divides the tile
-  constexpr int SLAB = TBM / NH;
-  static_assert(SLAB * TBN * 4 <= RING && SLAB % 32 == 0, "C slab does not fit the ring");
-  float* ct = reinterpret_cast<float*>(smem);
-  float amax = 0.f; bool nan = false;
-  constexpr int CPR = TBN / 8;                       // 8-column chunks per row
-  constexpr int RPP = NW * 64 / CPR;                 // rows per pass
-  const int cchunk = (threadIdx.x % CPR) * 8;
-#pragma unroll 1
-  for (int hs = 0; hs < NH; ++hs) {
-    if (hs > 0) __syncthreads();
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      if ((wm + 32 * i) / SLAB == hs) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            ct[((wm + 32 * i) % SLAB + (e & 3) + 8 * (e >> 2) + 4 * fg) * TBN + wn + 32 * j + fr] = acc[i][j][e];
-      }
-    }
+  store_c_tile<T, NW, TBM, TBN, MI, NJ, NST * STAGE>(p, acc, smem, m0, n0, wm, wn, fr, fg, blockIdx.y);
+  if ((COGV_EXP & 16) && p.out_f32 && threadIdx.x == 0 && (bid == 0 || bid == nwg - 1)) {
+    const uint64_t dt = __builtin_readcyclecounter() - exp_t0, dr = __builtin_amdgcn_s_memrealtime() - exp_r0;
     __syncthreads();
+    reinterpret_cast<float*>(p.C)[(size_t)m0 * p.ldc + n0] = 100.f * (float)dt / (float)dr;
+  }
+}
+
+// =====================================================================================================
+// Generation-3 kernel: 256x256 tile, 64-deep k-tiles, 8 waves (2 x 4, 128x64 each), ping-pong schedule.
+//
+// Why: the DMA-only experiment (tools/probes/gemm_exp.py) showed the generation-2 loop is bound by the
+// global->LDS request stream, not by MFMA or LDS reads: with 32-deep tiles a K-contiguous operand arrives as
+// 64-byte row segments (half an L2 line per request, 11.9 TB/s chip-wide); 128-byte segments move 1.5x the
+// bytes in the same time.  A 64-deep 256x256 k-tile is 64 KiB, so only two fit in LDS -- a whole-tile ring would
+// have prefetch distance one.  Instead the k-tile is cut into three granules with different deadlines and the
+// two half-steps of a k-tile read DIFFERENT data (quadrant order), so every granule is resident for exactly one
+// READ phase and the prefetch distance is three half-steps for all of them:
+//
+//   granule   content (64 k deep)                      bytes   read in      re-issued (for tile)   needed
+//   B         all 256 B rows                           32 KiB  R(2T)        R(2T+1)  (T+2)          R(2T+4)
+//   A01       A rows [0,64) u [128,192)                16 KiB  R(2T)        R(2T+1)  (T+2)          R(2T+4)
+//   A23       A rows [64,128) u [192,256)              16 KiB  R(2T+1)      R(2T+2)  (T+2)          R(2T+5)
+//
+//   half-step 2T  : READ  B fragments of the whole k-tile (kept in registers for both half-steps) + A01 fragments,
+//                   issue A23(T+1);          MFMA acc[0..1][*] += A01 x B   (16 MFMAs, 4 k-steps)
+//   half-step 2T+1: READ  A23 fragments, issue B(T+2), A01(T+2);  MFMA acc[2..3][*] += A23 x B
+//
+// LDS: 2 buffers x (B 32 KiB | A01 16 KiB | A23 16 KiB) = 128 KiB.  Two barriers per half-step; waves 0-3 and
+// 4-7 (one of each per SIMD) run one barrier apart, so one wave of every SIMD is in its MFMA phase while the
+// other reads/issues.  Ordering (same argument as the PP variant of generation 2): a granule issued in R(h)
+// replaces data whose last reads were retired (lgkmcnt(0)) before every wave's B2(h-1); a granule needed in
+// R(h+1) is certified by every wave's counted vmcnt before its B2(h).  Each wave always has exactly 8 DMA
+// instructions issued after the ones it must certify (6 + 2), so the wait is vmcnt(8) in both half-steps.
+template <typename T, bool AT, bool BT>
+__global__ __launch_bounds__(512, 2)
+void gemm_pp64_kernel(const GemmArgs p) {
+  constexpr int NW = 8, TBM = 256, TBN = 256, KT = 64, KS = 4;
+  constexpr int B_OFF = 0, A01_OFF = 32768, A23_OFF = 49152, BUF = 65536;
+  constexpr int ROWB_A = 256, ROWB_B = 512;            // k-row bytes of a contraction-strided granule
+  extern __shared__ __attribute__((aligned(1024))) char smem[];     // 2 * BUF
+
+  uint64_t exp_t0 = 0, exp_r0 = 0;
+  if (COGV_EXP & 16) { exp_t0 = __builtin_readcyclecounter(); exp_r0 = __builtin_amdgcn_s_memrealtime(); }
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int wm = wr * 128, wn = wc * 64;
+  const int fr = lane & 31, fg = lane >> 5;
+  // Persistent: one workgroup per CU walks the (tile, k-split) items with stride gridDim.x.  The C stores of
+  // one item are still draining while the next item's prologue loads are in flight (a 256x256 bf16 tile per CU
+  // is 32 MiB per round chip-wide: ~6 us of HBM write time that a one-workgroup-per-CU grid would expose).
+  const int nitems = nwg * p.splitk;
 #pragma unroll 1
-    for (int row = threadIdx.x / CPR; row < SLAB; row += RPP) {
-      const int m = m0 + hs * SLAB + row, n = n0 + cchunk;
-      if (m < p.M && n < p.N) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(ct + row * TBN + cchunk);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(ct + row * TBN + cchunk + 4);
-        if (p.splitk > 1) {
-          float* w = p.ws + ((size_t)blockIdx.y * p.M + m) * p.N + n;
-          *reinterpret_cast<f32x4*>(w) = x0;
-          *reinterpret_cast<f32x4*>(w + 4) = x1;
-        } else {
-          float v[8];
-          v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
-          v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
-          const float a = epilogue8<T>(p, m, n, v);
-          if (a != a) nan = true; else amax = fmaxf(amax, a);
-        }
-      }
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  const int bid = item % nwg, ksplit = item / nwg;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  constexpr int GROUP_M = 4;
+  const int in_group = GROUP_M * p.tiles_n;
+  const int group_id = wgid / in_group;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tile_m = first_m + (wgid % in_group) % gsz;
+  const int tile_n = (wgid % in_group) / gsz;
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+
+  const int kt0 = ksplit * p.ktiles_per_split;
+  const int nk = min(p.K / KT, kt0 + p.ktiles_per_split) - kt0;       // >= 1 by construction
+
+  // ---- per-lane DMA sources.  Piece = one 1-KiB LDS-DMA instruction; wave w owns pieces i*8 + w.
+  //      B: 32 pieces (4 per wave); A01, A23: 16 pieces each (2 + 2 per wave).
+  // (32-bit per-lane byte offsets against a wave-uniform base: the SGPR-base form of global_load_lds, 8 VGPRs)
+  uint32_t offB[4], offA[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = i * NW + wave;
+    if (!BT) {
+      const int row = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz(row);
+      const int gn = min(n0 + row, p.N - 1);
+      offB[i] = (uint32_t)(((size_t)gn * p.ldb + c * 8) * 2);
+    } else {
+      const int off = piece * 1024 + lane * 16;
+      const int krow = off / ROWB_B, pc = (off % ROWB_B) >> 4;
+      const int c = pc ^ ((krow & 3) << 2);
+      const int col = min(n0 + c * 8, p.N - 8);
+      offB[i] = (uint32_t)(((size_t)krow * p.ldb + col) * 2);
     }
   }
-  if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = i * NW + wave;
+      if (!AT) {
+        const int row = piece * 8 + (lane >> 3);                 // granule row 0..127
+        const int c = (lane & 7) ^ swz(row);
+        const int tr = (row & 63) + 128 * (row >> 6) + 64 * g;   // tile row
+        const int gm = min(m0 + tr, p.M - 1);
+        offA[g][i] = (uint32_t)(((size_t)gm * p.lda + c * 8) * 2);
+      } else {
+        const int off = piece * 1024 + lane * 16;
+        const int krow = off / ROWB_A, pc = (off % ROWB_A) >> 4;
+        const int c = pc ^ ((krow & 3) << 2);
+        const int gc = c * 8;                                    // granule column 0..127
+        const int tcol = (gc & 63) + 128 * (gc >> 6) + 64 * g;   // tile row (= column of the stored A)
+        const int col = min(m0 + tcol, p.M - 8);
+        offA[g][i] = (uint32_t)(((size_t)krow * p.lda + col) * 2);
+      }
+    }
+  const size_t kstrideA = AT ? (size_t)KT * p.lda * 2 : (size_t)KT * 2;
+  const size_t kstrideB = BT ? (size_t)KT * p.ldb * 2 : (size_t)KT * 2;
+  const char* baseA = reinterpret_cast<const char*>(p.A) + (size_t)kt0 * kstrideA;
+  const char* baseB = reinterpret_cast<const char*>(p.B) + (size_t)kt0 * kstrideB;
+  auto issue_B = [&](int kt, int buf) {
+    if (COGV_EXP & 1) return;
+    if (COGV_EXP & 8) kt &= 3;              // re-read the first k-tiles: every request an L2 hit
+    char* l = smem + buf * BUF + B_OFF;
+    const char* g = baseB + (size_t)kt * kstrideB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(g + offB[i]), (lds_void_t*)(l + (i * NW + wave) * 1024), 16, 0, 0);
+  };
+  auto issue_A = [&](int gi, int kt, int buf) {
+    if (COGV_EXP & 1) return;
+    if (COGV_EXP & 8) kt &= 3;
+    char* l = smem + buf * BUF + (gi ? A23_OFF : A01_OFF);
+    const char* g = baseA + (size_t)kt * kstrideA;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(g + offA[gi][i]), (lds_void_t*)(l + (i * NW + wave) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- per-lane fragment read addresses (buffer 0, k-step 0)
+  uint32_t adB[2], adA[2];           // adA is relative to the A granule (A01 and A23 share the in-granule layout)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    adB[j] = BT ? tr_addr<ROWB_B>(smem + B_OFF, wn + 32 * j, lane)
+                : (uint32_t)(uintptr_t)(smem + B_OFF) + (uint32_t)((wn + 32 * j + fr) * 128 + ((fg ^ swz(wn + 32 * j + fr)) << 4));
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    adA[i] = AT ? tr_addr<ROWB_A>(smem, wr * 64 + 32 * i, lane)
+                : (uint32_t)(uintptr_t)smem + (uint32_t)((wr * 64 + 32 * i + fr) * 128 + ((fg ^ swz(wr * 64 + 32 * i + fr)) << 4));
+
+  // prologue: tile 0 complete, B + A01 of tile 1
+  issue_B(0, 0); issue_A(0, 0, 0);
+  issue_A(1, 0, 0);
+  { const int t1 = min(1, nk - 1); issue_B(t1, 1); issue_A(0, t1, 1); }
+  wait_vmcnt<8>();                           // this wave's pieces of B(0), A01(0)
+  __builtin_amdgcn_s_barrier();
+  const int grp = wr;
+  if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger
+
+  TrRaw tb[KS][2], ta[KS][2];
+  u32x4 nb[KS][2], na[KS][2];
+  auto read_B = [&](uint32_t boff) {
+    if (COGV_EXP & 2) return;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (BT) tr_issue<ROWB_B>(adB[j] + boff, ks, tb[ks][j]);
+        else nat_issue((adB[j] + boff) ^ (uint32_t)(ks << 5), nb[ks][j]);
+      }
+  };
+  auto read_A = [&](uint32_t goff) {
+    if (COGV_EXP & 2) return;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (AT) tr_issue<ROWB_A>(adA[i] + goff, ks, ta[ks][i]);
+        else nat_issue((adA[i] + goff) ^ (uint32_t)(ks << 5), na[ks][i]);
+      }
+  };
+  auto land_A = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (AT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[ks][i].lo), "+v"(ta[ks][i].hi) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na[ks][i]) : : "memory");
+      }
+  };
+  auto land_B = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (BT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[ks][j].lo), "+v"(tb[ks][j].hi) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nb[ks][j]) : : "memory");
+      }
+  };
+  auto mma = [&](int half) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      typename HT<T>::v8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (AT) fa[i] = tr_pack<T>(ta[ks][i]); else __builtin_memcpy(&fa[i], &na[ks][i], 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (BT) fb[j] = tr_pack<T>(tb[ks][j]); else __builtin_memcpy(&fb[j], &nb[ks][j], 16);
+      }
+      if (COGV_EXP & 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(fa[i]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(fb[j]));
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[2 * half + i][j] = HT<T>::mfma32(fa[i], fb[j], acc[2 * half + i][j]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const uint32_t boff = (uint32_t)(buf * BUF);
+    // ---------------- half-step 2T
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_B(boff);
+    read_A(boff + A01_OFF);
+    issue_A(1, min(kt + 1, nk - 1), buf ^ 1);
+    land_B(); land_A();
+    wait_vmcnt<8>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    // ---------------- half-step 2T + 1
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_A(boff + A23_OFF);
+    { const int t2 = min(kt + 2, nk - 1); issue_B(t2, buf); issue_A(0, t2, buf); }
+    land_A();
+    wait_vmcnt<8>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (grp == 0) __builtin_amdgcn_s_barrier();              // even out the barrier count
+  wait_vmcnt<0>();   // drain the (redundant) tail prefetches before the ring is reused
+  __syncthreads();
+  store_c_tile<T, NW, TBM, TBN, 4, 2, 2 * BUF>(p, acc, smem, m0, n0, wm, wn, fr, fg, ksplit);
+  __syncthreads();   // the C staging reads are done: the next item's DMA may overwrite the ring
+  if ((COGV_EXP & 16) && p.out_f32 && threadIdx.x == 0 && (bid == 0 || bid == nwg - 1)) {
+    // shader clock in MHz over this workgroup's lifetime (s_memrealtime ticks at 100 MHz)
+    const uint64_t dt = __builtin_readcyclecounter() - exp_t0, dr = __builtin_amdgcn_s_memrealtime() - exp_r0;
     __syncthreads();
-    float bm = block_max(amax, reinterpret_cast<float*>(smem));
-    const bool any_nan = __syncthreads_or(nan);
-    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, any_nan ? __uint_as_float(0x7fc00000u) : bm);
+    reinterpret_cast<float*>(p.C)[(size_t)m0 * p.ldc + n0] = 100.f * (float)dt / (float)dr;
+  }
   }
 }
 
@@ -660,26 +1047,58 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
-template <typename T, bool AT, bool BT, int WM, int WN, int MI, int NJ, int BKT>
+template <typename T, bool AT, bool BT, int WM, int WN, int MI, int NJ, int BKT, int NST = 3, bool PP = false>
 void launch_glds(GemmArgs& a, hipStream_t st) {
   constexpr int TBM = WM * 32 * MI, TBN = WN * 32 * NJ;
-  constexpr int shmem = 3 * (TBM + TBN) * 2 * BKT;
+  constexpr int shmem = NST * (TBM + TBN) * 2 * BKT;
   a.tiles_m = (a.M + TBM - 1) / TBM; a.tiles_n = (a.N + TBN - 1) / TBN;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, AT, BT, WM, WN, MI, NJ, BKT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, AT, BT, WM, WN, MI, NJ, BKT, NST, PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<T, AT, BT, WM, WN, MI, NJ, BKT>), dim3(a.tiles_m * a.tiles_n, a.splitk),
+  hipLaunchKernelGGL((gemm_glds_kernel<T, AT, BT, WM, WN, MI, NJ, BKT, NST, PP>), dim3(a.tiles_m * a.tiles_n, a.splitk),
                      dim3(WM * WN * 64), shmem, st, a);
 }
-template <typename T, int WM, int WN, int MI, int NJ, int BKT>
+template <typename T, int WM, int WN, int MI, int NJ, int BKT, int NST = 3, bool PP = false>
 void launch_glds_layout(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
-  if (!d->trans_a && !d->trans_b) launch_glds<T, false, false, WM, WN, MI, NJ, BKT>(a, st);
-  else if (!d->trans_a && d->trans_b) launch_glds<T, false, true, WM, WN, MI, NJ, BKT>(a, st);
-  else if (d->trans_a && d->trans_b) launch_glds<T, true, true, WM, WN, MI, NJ, BKT>(a, st);
-  else launch_glds<T, true, false, WM, WN, MI, NJ, BKT>(a, st);
+  if (!d->trans_a && !d->trans_b) launch_glds<T, false, false, WM, WN, MI, NJ, BKT, NST, PP>(a, st);
+  else if (!d->trans_a && d->trans_b) launch_glds<T, false, true, WM, WN, MI, NJ, BKT, NST, PP>(a, st);
+  else if (d->trans_a && d->trans_b) launch_glds<T, true, true, WM, WN, MI, NJ, BKT, NST, PP>(a, st);
+  else launch_glds<T, true, false, WM, WN, MI, NJ, BKT, NST, PP>(a, st);
+}
+
+int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0; hipDeviceProp_t prop;
+    (void)hipGetDevice(&dev);
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <typename T, bool AT, bool BT>
+void launch_pp64(GemmArgs& a, hipStream_t st) {
+  constexpr int shmem = 2 * 65536;
+  a.tiles_m = (a.M + 255) / 256; a.tiles_n = (a.N + 255) / 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp64_kernel<T, AT, BT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    attr_set = true;
+  }
+  const int num_cu = num_cus();
+  const int items = a.tiles_m * a.tiles_n * a.splitk;
+  hipLaunchKernelGGL((gemm_pp64_kernel<T, AT, BT>), dim3(items < num_cu ? items : num_cu), dim3(512), shmem, st, a);
+}
+template <typename T>
+void launch_pp64_layout(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
+  if (!d->trans_a && !d->trans_b) launch_pp64<T, false, false>(a, st);
+  else if (!d->trans_a && d->trans_b) launch_pp64<T, false, true>(a, st);
+  else if (d->trans_a && d->trans_b) launch_pp64<T, true, true>(a, st);
+  else launch_pp64<T, true, false>(a, st);
 }
 
 template <typename T>
@@ -692,11 +1111,29 @@ int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
     //            phases interleave on each SIMD, and a fat wave reads 6 fragments per 8 MFMAs instead of 4 per 4
     // variant 4: 128x128x32, 4 waves (64x64 each), three workgroups per CU
     // variant 5: 256x256x32, 8 waves (128x64 each), one workgroup per CU -- least L2->LDS traffic per flop: long-K NT
+    // variant 9: generation 3 (256x256x64 ping-pong, persistent) -- best for K-contiguous A (forward, dgrad); for
+    //            the weight gradient (both operands contraction-strided) only when it fills the chip better
     int variant = d->kernel_variant;
-    if (variant == 0) variant = (!d->trans_a && !d->trans_b && a.K >= 2048 && a.M >= 1024 && a.N >= 1024) ? 5 : 3;
+    const size_t a_span = (size_t)(d->trans_a ? a.K : a.M) * a.lda * 2, b_span = (size_t)(d->trans_b ? a.K : a.N) * a.ldb * 2;
+    const bool v9_ok = a.M >= 256 && a.N >= 256 && a_span < (1ull << 32) && b_span < (1ull << 32);   // 32-bit DMA offsets
+    if (variant == 9 && !v9_ok) variant = 0;
+    if (variant == 0) {
+      variant = 3;
+      if (v9_ok) {
+        const int cu = num_cus();
+        const int i3 = ((a.M + 255) / 256) * ((a.N + 127) / 128) * a.splitk, i9 = ((a.M + 255) / 256) * ((a.N + 255) / 256) * a.splitk;
+        const float e3 = (float)i3 / (float)(((i3 + 2 * cu - 1) / (2 * cu)) * 2 * cu);
+        const float e9 = (float)i9 / (float)(((i9 + cu - 1) / cu) * cu);
+        if (d->trans_a ? (e9 > e3 + 0.1f) : (e9 * 1.06f >= e3)) variant = 9;
+      }
+    }
     if (variant == 3) launch_glds_layout<T, 2, 2, 4, 2, 32>(d, a, st);
     else if (variant == 5) launch_glds_layout<T, 2, 4, 4, 2, 32>(d, a, st);   // 256x256x32, 8 fat waves, one WG per CU
     else if (variant == 4) launch_glds_layout<T, 2, 2, 2, 2, 32>(d, a, st);
+    else if (variant == 6) launch_glds_layout<T, 2, 4, 4, 2, 32, 4, true>(d, a, st);   // 256x256x32 ping-pong, 4-stage ring
+    else if (variant == 7) launch_glds_layout<T, 2, 4, 4, 2, 32, 3, true>(d, a, st);   // same, 3-stage ring
+    else if (variant == 8) launch_glds_layout<T, 2, 4, 4, 1, 64, 3, true>(d, a, st);   // 256x128x64 ping-pong (128-B rows)
+    else if (variant == 9) launch_pp64_layout<T>(d, a, st);                             // generation 3 (operands < 4 GiB)
     else launch_glds_layout<T, 4, 2, 2, 2, 64>(d, a, st);
     if (a.splitk > 1) {
       const size_t nvec = (size_t)a.M * (a.N / 8);
