@@ -358,6 +358,23 @@ __device__ __forceinline__ void tr_issue(uint32_t addr0, int ks, TrRaw& o) {
   asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
                : "=&v"(o.lo), "=&v"(o.hi) : "v"(a), "n"(4 * ROWB) : "memory");
 }
+// ---- the same for v_mfma_f32_16x16x32 operands: 16-wide column block at col0; lane group G = lane >> 4 is the
+//      k-block (8 contraction rows 8G .. 8G+7, two reads of 4 rows).  All four groups read the same 32 bytes of
+//      a k-row, so rows k and k + 8 (same k & 3) must not share banks: the chunk XOR also takes bit 3 of k.
+__device__ __forceinline__ int trswz16(int k) { return ((k & 3) << 2) | (((k >> 3) & 1) << 1); }
+template <int ROWB>
+__device__ __forceinline__ uint32_t tr_addr16(const char* reg, int col0, int lane) {
+  const int G = lane >> 4, r = (lane & 15) >> 2, qq = lane & 3;
+  const int k = 8 * G + r;
+  const int c = (col0 >> 3) + (qq >> 1);
+  return (uint32_t)(uintptr_t)(reg) + k * ROWB + ((c ^ trswz16(k)) << 4) + (qq & 1) * 8;
+}
+template <int ROWB>
+__device__ __forceinline__ void tr_issue16(uint32_t addr0, int ks, TrRaw& o) {
+  const uint32_t a = addr0 + ks * 32 * ROWB;
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+               : "=&v"(o.lo), "=&v"(o.hi) : "v"(a), "n"(4 * ROWB) : "memory");
+}
 // natural-region fragment through asm as well (used only in kernels that also have asm transposing reads, so that
 // no compiler-generated lgkmcnt wait -- which cannot see the asm reads queued behind its own -- lands between
 // the read issue and the MFMA group)
@@ -380,15 +397,18 @@ __device__ __forceinline__ typename HT<T>::v8 tr_pack(const TrRaw& r) {
 
 // ---- epilogue shared by the LDS-DMA kernels: the fp32 C tile goes through the (now idle) ring in NH row slabs,
 //      then out with coalesced 16-byte accesses through the fused epilogue8.  Call after a workgroup barrier.
-template <typename T, int NW, int TBM, int TBN, int MI, int NJ, int RING>
-__device__ __forceinline__ void store_c_tile(const GemmArgs& p, f32x16 (&acc)[MI][NJ], char* smem, int m0, int n0,
-                                             int wm, int wn, int fr, int fg, int ksplit) {
+template <typename T, int NW, int TBM, int TBN, int MI, int NJ, int RING, typename ACC>
+__device__ __forceinline__ void store_c_tile_impl(const GemmArgs& p, ACC (&acc)[MI][NJ], char* smem, int m0, int n0,
+                                                  int wm, int wn, int lane, int ksplit) {
+  constexpr bool B32 = sizeof(ACC) == 64;            // 32x32 blocks (f32x16) or 16x16 blocks (f32x4)
+  constexpr int BLK = B32 ? 32 : 16;
+  const int fr = lane & 31, fg = lane >> 5;
   // ---- epilogue: the fp32 C tile goes through the ring's LDS in NH row slabs of SLAB rows (the ring of the
   //      BKT = 32 variants is smaller than the full C tile), then out with coalesced 16-byte accesses
   constexpr int NH0 = (TBM * TBN * 4 + RING - 1) / RING;
   constexpr int NH = NH0 <= 1 ? 1 : NH0 <= 2 ? 2 : 4;         // power of two so that SLAB divides the tile
   constexpr int SLAB = TBM / NH;
-  static_assert(SLAB * TBN * 4 <= RING && SLAB % 32 == 0, "C slab does not fit the ring");
+  static_assert(SLAB * TBN * 4 <= RING && SLAB % 32 == 0 && MI * BLK * NW * NJ * BLK == TBM * TBN, "C slab does not fit the ring");
   float* ct = reinterpret_cast<float*>(smem);
   float amax = 0.f; bool nan = false;
   constexpr int CPR = TBN / 8;                       // 8-column chunks per row
@@ -399,12 +419,19 @@ __device__ __forceinline__ void store_c_tile(const GemmArgs& p, f32x16 (&acc)[MI
     if (hs > 0) __syncthreads();
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      if ((wm + 32 * i) / SLAB == hs) {
+      if ((wm + BLK * i) / SLAB == hs) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j) {
+          if constexpr (B32) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            ct[((wm + 32 * i) % SLAB + (e & 3) + 8 * (e >> 2) + 4 * fg) * TBN + wn + 32 * j + fr] = acc[i][j][e];
+            for (int e = 0; e < 16; ++e)
+              ct[((wm + 32 * i) % SLAB + (e & 3) + 8 * (e >> 2) + 4 * fg) * TBN + wn + 32 * j + fr] = acc[i][j][e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              ct[((wm + 16 * i) % SLAB + 4 * (lane >> 4) + e) * TBN + wn + 16 * j + (lane & 15)] = acc[i][j][e];
+          }
+        }
       }
     }
     __syncthreads();
@@ -434,6 +461,17 @@ __device__ __forceinline__ void store_c_tile(const GemmArgs& p, f32x16 (&acc)[MI
     const bool any_nan = __syncthreads_or(nan);
     if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, any_nan ? __uint_as_float(0x7fc00000u) : bm);
   }
+}
+
+template <typename T, int NW, int TBM, int TBN, int MI, int NJ, int RING>
+__device__ __forceinline__ void store_c_tile(const GemmArgs& p, f32x16 (&acc)[MI][NJ], char* smem, int m0, int n0,
+                                             int wm, int wn, int fr, int fg, int ksplit) {
+  store_c_tile_impl<T, NW, TBM, TBN, MI, NJ, RING>(p, acc, smem, m0, n0, wm, wn, fr + 32 * fg, ksplit);
+}
+template <typename T, int NW, int TBM, int TBN, int MI, int NJ, int RING>
+__device__ __forceinline__ void store_c_tile(const GemmArgs& p, f32x4 (&acc)[MI][NJ], char* smem, int m0, int n0,
+                                             int wm, int wn, int lane, int ksplit) {
+  store_c_tile_impl<T, NW, TBM, TBN, MI, NJ, RING>(p, acc, smem, m0, n0, wm, wn, lane, ksplit);
 }
 
 // waves per SIMD the register allocation must allow: BKT = 64 -> one 8-wave workgroup per CU (2);
@@ -782,7 +820,7 @@ void gemm_glds_kernel(const GemmArgs p) {
 template <typename T, bool AT, bool BT>
 __global__ __launch_bounds__(512, 2)
 void gemm_pp64_kernel(const GemmArgs p) {
-  constexpr int NW = 8, TBM = 256, TBN = 256, KT = 64, KS = 4;
+  constexpr int NW = 8, TBM = 256, TBN = 256, KT = 64, KS = 2;
   constexpr int B_OFF = 0, A01_OFF = 32768, A23_OFF = 49152, BUF = 65536;
   constexpr int ROWB_A = 256, ROWB_B = 512;            // k-row bytes of a contraction-strided granule
   extern __shared__ __attribute__((aligned(1024))) char smem[];     // 2 * BUF
@@ -794,7 +832,6 @@ void gemm_pp64_kernel(const GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int wm = wr * 128, wn = wc * 64;
-  const int fr = lane & 31, fg = lane >> 5;
   // Persistent: one workgroup per CU walks the (tile, k-split) items with stride gridDim.x.  The C stores of
   // one item are still draining while the next item's prologue loads are in flight (a 256x256 bf16 tile per CU
   // is 32 MiB per round chip-wide: ~6 us of HBM write time that a one-workgroup-per-CU grid would expose).
@@ -831,7 +868,7 @@ void gemm_pp64_kernel(const GemmArgs p) {
     } else {
       const int off = piece * 1024 + lane * 16;
       const int krow = off / ROWB_B, pc = (off % ROWB_B) >> 4;
-      const int c = pc ^ ((krow & 3) << 2);
+      const int c = pc ^ trswz16(krow);
       const int col = min(n0 + c * 8, p.N - 8);
       offB[i] = (uint32_t)(((size_t)krow * p.ldb + col) * 2);
     }
@@ -850,7 +887,7 @@ void gemm_pp64_kernel(const GemmArgs p) {
       } else {
         const int off = piece * 1024 + lane * 16;
         const int krow = off / ROWB_A, pc = (off % ROWB_A) >> 4;
-        const int c = pc ^ ((krow & 3) << 2);
+        const int c = pc ^ trswz16(krow);
         const int gc = c * 8;                                    // granule column 0..127
         const int tcol = (gc & 63) + 128 * (gc >> 6) + 64 * g;   // tile row (= column of the stored A)
         const int col = min(m0 + tcol, p.M - 8);
@@ -880,24 +917,24 @@ void gemm_pp64_kernel(const GemmArgs p) {
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(g + offA[gi][i]), (lds_void_t*)(l + (i * NW + wave) * 1024), 16, 0, 0);
   };
 
-  f32x16 acc[4][2];
+  f32x4 acc[8][4];                   // 16x16 blocks of this wave's 128x64: acc[row block][column block]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- per-lane fragment read addresses (buffer 0, k-step 0).  v_mfma_f32_16x16x32: lane l supplies row
+  //      (l & 15) of a 16-row block and the 8 contraction slots of k-block (l >> 4).
+  const int l15 = lane & 15, kb = lane >> 4;
+  uint32_t adB[4], adA[4];           // adA is relative to the A granule (A01 and A23 share the in-granule layout)
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    adB[j] = BT ? tr_addr16<ROWB_B>(smem + B_OFF, wn + 16 * j, lane)
+                : (uint32_t)(uintptr_t)(smem + B_OFF) + (uint32_t)((wn + 16 * j + l15) * 128 + ((kb ^ swz(wn + 16 * j + l15)) << 4));
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // ---- per-lane fragment read addresses (buffer 0, k-step 0)
-  uint32_t adB[2], adA[2];           // adA is relative to the A granule (A01 and A23 share the in-granule layout)
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-    adB[j] = BT ? tr_addr<ROWB_B>(smem + B_OFF, wn + 32 * j, lane)
-                : (uint32_t)(uintptr_t)(smem + B_OFF) + (uint32_t)((wn + 32 * j + fr) * 128 + ((fg ^ swz(wn + 32 * j + fr)) << 4));
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-    adA[i] = AT ? tr_addr<ROWB_A>(smem, wr * 64 + 32 * i, lane)
-                : (uint32_t)(uintptr_t)smem + (uint32_t)((wr * 64 + 32 * i + fr) * 128 + ((fg ^ swz(wr * 64 + 32 * i + fr)) << 4));
+    adA[i] = AT ? tr_addr16<ROWB_A>(smem, wr * 64 + 16 * i, lane)
+                : (uint32_t)(uintptr_t)smem + (uint32_t)((wr * 64 + 16 * i + l15) * 128 + ((kb ^ swz(wr * 64 + 16 * i + l15)) << 4));
 
   // prologue: tile 0 complete, B + A01 of tile 1
   issue_B(0, 0); issue_A(0, 0, 0);
@@ -908,16 +945,16 @@ void gemm_pp64_kernel(const GemmArgs p) {
   const int grp = wr;
   if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger
 
-  TrRaw tb[KS][2], ta[KS][2];
-  u32x4 nb[KS][2], na[KS][2];
+  TrRaw tb[KS][4], ta[KS][4];          // KS = 2 k-steps of 32 per k-tile
+  u32x4 nb[KS][4], na[KS][4];
   auto read_B = [&](uint32_t boff) {
     if (COGV_EXP & 2) return;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (BT) tr_issue<ROWB_B>(adB[j] + boff, ks, tb[ks][j]);
-        else nat_issue((adB[j] + boff) ^ (uint32_t)(ks << 5), nb[ks][j]);
+      for (int j = 0; j < 4; ++j) {
+        if (BT) tr_issue16<ROWB_B>(adB[j] + boff, ks, tb[ks][j]);
+        else nat_issue((adB[j] + boff) ^ (uint32_t)(ks << 6), nb[ks][j]);
       }
   };
   auto read_A = [&](uint32_t goff) {
@@ -925,16 +962,16 @@ void gemm_pp64_kernel(const GemmArgs p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (AT) tr_issue<ROWB_A>(adA[i] + goff, ks, ta[ks][i]);
-        else nat_issue((adA[i] + goff) ^ (uint32_t)(ks << 5), na[ks][i]);
+      for (int i = 0; i < 4; ++i) {
+        if (AT) tr_issue16<ROWB_A>(adA[i] + goff, ks, ta[ks][i]);
+        else nat_issue((adA[i] + goff) ^ (uint32_t)(ks << 6), na[ks][i]);
       }
   };
   auto land_A = [&]() {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 4; ++i) {
         if (AT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[ks][i].lo), "+v"(ta[ks][i].hi) : : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na[ks][i]) : : "memory");
       }
@@ -943,7 +980,7 @@ void gemm_pp64_kernel(const GemmArgs p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < 4; ++j) {
         if (BT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[ks][j].lo), "+v"(tb[ks][j].hi) : : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nb[ks][j]) : : "memory");
       }
@@ -952,27 +989,27 @@ void gemm_pp64_kernel(const GemmArgs p) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      typename HT<T>::v8 fa[2], fb[2];
+      typename HT<T>::v8 fa[4], fb[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 4; ++i) {
         if (AT) fa[i] = tr_pack<T>(ta[ks][i]); else __builtin_memcpy(&fa[i], &na[ks][i], 16);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < 4; ++j) {
         if (BT) fb[j] = tr_pack<T>(tb[ks][j]); else __builtin_memcpy(&fb[j], &nb[ks][j], 16);
       }
       if (COGV_EXP & 4) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(fa[i]));
+        for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(fa[i]));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(fb[j]));
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(fb[j]));
         continue;
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[2 * half + i][j] = HT<T>::mfma32(fa[i], fb[j], acc[2 * half + i][j]);
+        for (int j = 0; j < 4; ++j)
+          acc[4 * half + i][j] = HT<T>::mfma16(fa[i], fb[j], acc[4 * half + i][j]);
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -1010,7 +1047,7 @@ void gemm_pp64_kernel(const GemmArgs p) {
   if (grp == 0) __builtin_amdgcn_s_barrier();              // even out the barrier count
   wait_vmcnt<0>();   // drain the (redundant) tail prefetches before the ring is reused
   __syncthreads();
-  store_c_tile<T, NW, TBM, TBN, 4, 2, 2 * BUF>(p, acc, smem, m0, n0, wm, wn, fr, fg, ksplit);
+  store_c_tile<T, NW, TBM, TBN, 8, 4, 2 * BUF>(p, acc, smem, m0, n0, wm, wn, lane, ksplit);
   __syncthreads();   // the C staging reads are done: the next item's DMA may overwrite the ring
   if ((COGV_EXP & 16) && p.out_f32 && threadIdx.x == 0 && (bid == 0 || bid == nwg - 1)) {
     // shader clock in MHz over this workgroup's lifetime (s_memrealtime ticks at 100 MHz)
@@ -1111,8 +1148,8 @@ int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
     //            phases interleave on each SIMD, and a fat wave reads 6 fragments per 8 MFMAs instead of 4 per 4
     // variant 4: 128x128x32, 4 waves (64x64 each), three workgroups per CU
     // variant 5: 256x256x32, 8 waves (128x64 each), one workgroup per CU -- least L2->LDS traffic per flop: long-K NT
-    // variant 9: generation 3 (256x256x64 ping-pong, persistent) -- best for K-contiguous A (forward, dgrad); for
-    //            the weight gradient (both operands contraction-strided) only when it fills the chip better
+    // variant 9: generation 3 (256x256x64 ping-pong, persistent, 16x16x32 MFMAs) -- default whenever its 256 tile
+    //            slots per round are filled about as well as variant 3's 512
     int variant = d->kernel_variant;
     const size_t a_span = (size_t)(d->trans_a ? a.K : a.M) * a.lda * 2, b_span = (size_t)(d->trans_b ? a.K : a.N) * a.ldb * 2;
     const bool v9_ok = a.M >= 256 && a.N >= 256 && a_span < (1ull << 32) && b_span < (1ull << 32);   // 32-bit DMA offsets
@@ -1124,7 +1161,7 @@ int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
         const int i3 = ((a.M + 255) / 256) * ((a.N + 127) / 128) * a.splitk, i9 = ((a.M + 255) / 256) * ((a.N + 255) / 256) * a.splitk;
         const float e3 = (float)i3 / (float)(((i3 + 2 * cu - 1) / (2 * cu)) * 2 * cu);
         const float e9 = (float)i9 / (float)(((i9 + cu - 1) / cu) * cu);
-        if (d->trans_a ? (e9 > e3 + 0.1f) : (e9 * 1.06f >= e3)) variant = 9;
+        if (e9 * 1.1f >= e3) variant = 9;      // measured 1.1-1.4x at equal fill (16x16x32 MFMAs: less power per flop)
       }
     }
     if (variant == 3) launch_glds_layout<T, 2, 2, 4, 2, 32>(d, a, st);
