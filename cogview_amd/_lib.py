@@ -85,6 +85,8 @@ SIGNATURES = {
     "cogv_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "cogv_gemm_workspace_bytes": (_sz, [C.POINTER(GemmDesc)]),
     "cogv_gemm_pick_splitk": (_i, [_i, _i, _i]),
+    "cogv_gemm_grouped": (_i, [C.POINTER(GemmDesc), _i, _vp]),
+    "cogv_gemm_pick_splitk_tiles": (_i, [_i, _i]),
     "cogv_sandwich_ln_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "cogv_sandwich_ln_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64,
                                   _vp, _sz, _vp]),

@@ -46,6 +46,16 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
+// Up to MAX_GROUP independent problems of one layout in ONE persistent launch (the four weight gradients of a
+// transformer layer: 300 + 100 + 400 + 400 tiles of 256x256 fill 4.7 rounds of 256 CUs together, where each one
+// alone leaves its last round half empty or needs split-K slabs).
+constexpr int MAX_GROUP = 4;
+struct GroupArgs {
+  GemmArgs g[MAX_GROUP];
+  int item_start[MAX_GROUP + 1];     // prefix sums of tiles_m * tiles_n * splitk
+  int count;
+};
+
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
 
 // ---- staging: K-contiguous operand.  Tile rows = output index (m or n), 64 k per row.
@@ -819,7 +829,7 @@ void gemm_glds_kernel(const GemmArgs p) {
 // instructions issued after the ones it must certify (6 + 2), so the wait is vmcnt(8) in both half-steps.
 template <typename T, bool AT, bool BT>
 __global__ __launch_bounds__(512, 2)
-void gemm_pp64_kernel(const GemmArgs p) {
+void gemm_pp64_kernel(const GroupArgs ga) {
   constexpr int NW = 8, TBM = 256, TBN = 256, KT = 64, KS = 2;
   constexpr int B_OFF = 0, A01_OFF = 32768, A23_OFF = 49152, BUF = 65536;
   constexpr int ROWB_A = 256, ROWB_B = 512;            // k-row bytes of a contraction-strided granule
@@ -827,7 +837,6 @@ void gemm_pp64_kernel(const GemmArgs p) {
 
   uint64_t exp_t0 = 0, exp_r0 = 0;
   if (COGV_EXP & 16) { exp_t0 = __builtin_readcyclecounter(); exp_r0 = __builtin_amdgcn_s_memrealtime(); }
-  const int nwg = p.tiles_m * p.tiles_n;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -835,10 +844,16 @@ void gemm_pp64_kernel(const GemmArgs p) {
   // Persistent: one workgroup per CU walks the (tile, k-split) items with stride gridDim.x.  The C stores of
   // one item are still draining while the next item's prologue loads are in flight (a 256x256 bf16 tile per CU
   // is 32 MiB per round chip-wide: ~6 us of HBM write time that a one-workgroup-per-CU grid would expose).
-  const int nitems = nwg * p.splitk;
+  const int nitems = ga.item_start[ga.count];
 #pragma unroll 1
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-  const int bid = item % nwg, ksplit = item / nwg;
+  int pi = 0;
+#pragma unroll
+  for (int t = 1; t < MAX_GROUP; ++t) pi += (t < ga.count && item >= ga.item_start[t]) ? 1 : 0;
+  const GemmArgs& p = ga.g[pi];
+  const int local = item - ga.item_start[pi];
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = local % nwg, ksplit = local / nwg;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
   constexpr int GROUP_M = 4;
@@ -1117,9 +1132,15 @@ int num_cus() {
 }
 
 template <typename T, bool AT, bool BT>
-void launch_pp64(GemmArgs& a, hipStream_t st) {
+void launch_pp64(GroupArgs& ga, hipStream_t st) {
   constexpr int shmem = 2 * 65536;
-  a.tiles_m = (a.M + 255) / 256; a.tiles_n = (a.N + 255) / 256;
+  ga.item_start[0] = 0;
+  for (int i = 0; i < ga.count; ++i) {
+    GemmArgs& a = ga.g[i];
+    a.tiles_m = (a.M + 255) / 256; a.tiles_n = (a.N + 255) / 256;
+    ga.item_start[i + 1] = ga.item_start[i] + a.tiles_m * a.tiles_n * a.splitk;
+  }
+  for (int i = ga.count; i < MAX_GROUP; ++i) ga.item_start[i + 1] = ga.item_start[ga.count];
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp64_kernel<T, AT, BT>),
@@ -1127,15 +1148,21 @@ void launch_pp64(GemmArgs& a, hipStream_t st) {
     attr_set = true;
   }
   const int num_cu = num_cus();
-  const int items = a.tiles_m * a.tiles_n * a.splitk;
-  hipLaunchKernelGGL((gemm_pp64_kernel<T, AT, BT>), dim3(items < num_cu ? items : num_cu), dim3(512), shmem, st, a);
+  const int items = ga.item_start[ga.count];
+  hipLaunchKernelGGL((gemm_pp64_kernel<T, AT, BT>), dim3(items < num_cu ? items : num_cu), dim3(512), shmem, st, ga);
 }
 template <typename T>
-void launch_pp64_layout(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
-  if (!d->trans_a && !d->trans_b) launch_pp64<T, false, false>(a, st);
-  else if (!d->trans_a && d->trans_b) launch_pp64<T, false, true>(a, st);
-  else if (d->trans_a && d->trans_b) launch_pp64<T, true, true>(a, st);
-  else launch_pp64<T, true, false>(a, st);
+void launch_pp64_layout(int trans_a, int trans_b, GroupArgs& ga, hipStream_t st) {
+  if (!trans_a && !trans_b) launch_pp64<T, false, false>(ga, st);
+  else if (!trans_a && trans_b) launch_pp64<T, false, true>(ga, st);
+  else if (trans_a && trans_b) launch_pp64<T, true, true>(ga, st);
+  else launch_pp64<T, true, false>(ga, st);
+}
+template <typename T>
+void launch_splitk_reduce(GemmArgs& a, hipStream_t st) {
+  const size_t nvec = (size_t)a.M * (a.N / 8);
+  int blocks = (int)((nvec + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, a);
 }
 
 template <typename T>
@@ -1170,7 +1197,11 @@ int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
     else if (variant == 6) launch_glds_layout<T, 2, 4, 4, 2, 32, 4, true>(d, a, st);   // 256x256x32 ping-pong, 4-stage ring
     else if (variant == 7) launch_glds_layout<T, 2, 4, 4, 2, 32, 3, true>(d, a, st);   // same, 3-stage ring
     else if (variant == 8) launch_glds_layout<T, 2, 4, 4, 1, 64, 3, true>(d, a, st);   // 256x128x64 ping-pong (128-B rows)
-    else if (variant == 9) launch_pp64_layout<T>(d, a, st);                             // generation 3 (operands < 4 GiB)
+    else if (variant == 9) {                                                            // generation 3 (operands < 4 GiB)
+      GroupArgs ga; ga.count = 1; ga.g[0] = a;
+      launch_pp64_layout<T>(d->trans_a, d->trans_b, ga, st);
+      a.tiles_m = ga.g[0].tiles_m; a.tiles_n = ga.g[0].tiles_n;
+    }
     else launch_glds_layout<T, 4, 2, 2, 2, 64>(d, a, st);
     if (a.splitk > 1) {
       const size_t nvec = (size_t)a.M * (a.N / 8);
@@ -1214,23 +1245,29 @@ extern "C" size_t cogv_gemm_workspace_bytes(const cogv_gemm_desc* d) {
 // Heuristic used by the host side: split the contraction when the output has too few tiles to fill 256 CUs
 // (weight-gradient GEMMs of the 336M config: 64..256 tiles, contraction = b*1088 tokens).
 extern "C" int cogv_gemm_pick_splitk(int M, int N, int K) {
-  // 256x128 tiles, two workgroups per CU => 512 concurrent workgroups per round.  Pick the split that fills
-  // whole rounds best; a split costs one fp32 slab write + a reduce pass, so it must pay for itself.
-  const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
+  // 256x256 tiles on one persistent workgroup per CU.  Pick the split that fills whole rounds best; every split
+  // costs an fp32 slab write + read (8 M N bytes at ~4 TB/s) against 2 M N K flops at ~1.1 PFLOP/s: 1100 / K each.
+  return cogv_gemm_pick_splitk_tiles(((M + 255) / 256) * ((N + 255) / 256), K);
+}
+
+// the same for `tiles` 256x256 output tiles in total (a grouped launch): one split count for all problems
+extern "C" int cogv_gemm_pick_splitk_tiles(int tiles, int K) {
   const int nk = (K + BK - 1) / BK;
-  if (tiles >= 1024 || nk < 16) return 1;
+  const int slots = 256;
+  if (tiles >= 4 * slots || nk < 16) return 1;
+  const float cost = 1100.f / (float)K;
   int best = 1; float best_score = -1.f;
   for (int s = 1; s <= 16 && nk / s >= 8; ++s) {
     const int items = tiles * s;
-    const int rounds = (items + 511) / 512;
-    const float eff = (float)items / (float)(rounds * 512);
-    const float score = eff - (s > 1 ? 0.04f : 0.f) - 0.004f * s;
+    const int rounds = (items + slots - 1) / slots;
+    const float eff = (float)items / (float)(rounds * slots);
+    const float score = eff / (1.f + (s > 1 ? cost * s : 0.f));
     if (score > best_score) { best_score = score; best = s; }
   }
   return best;
 }
 
-extern "C" int cogv_gemm(const cogv_gemm_desc* d, void* stream) {
+static int build_gemm_args(const cogv_gemm_desc* d, GemmArgs& a) {
   if (!d) return COGV_ERR_ARG;
   if (d->dtype != COGV_F16 && d->dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return COGV_ERR_ARG;
@@ -1247,7 +1284,6 @@ extern "C" int cogv_gemm(const cogv_gemm_desc* d, void* stream) {
   if ((d->flags & COGV_EPI_ABSMAX) && !d->absmax) return COGV_ERR_ARG;
   if ((d->flags & COGV_EPI_DROPOUT) && !(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return COGV_ERR_ARG;
 
-  GemmArgs a;
   a.A = d->A; a.B = d->B; a.C = d->C;
   a.M = d->M; a.N = d->N; a.K = d->K;
   a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
@@ -1267,7 +1303,42 @@ extern "C" int cogv_gemm(const cogv_gemm_desc* d, void* stream) {
     if (!a.ws || d->workspace_bytes < (size_t)a.splitk * a.M * a.N * sizeof(float)) return COGV_ERR_ARG;
     if ((uintptr_t)a.ws & 15) return COGV_ERR_ARG;
   }
+  return COGV_OK;
+}
+
+extern "C" int cogv_gemm(const cogv_gemm_desc* d, void* stream) {
+  GemmArgs a;
+  const int rc = build_gemm_args(d, a);
+  if (rc != COGV_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == COGV_F16) return launch_gemm<f16_t>(d, a, st);
   return launch_gemm<bf16_t>(d, a, st);
+}
+
+// Several GEMMs of the same dtype and layout in one persistent launch of the generation-3 kernel (see GroupArgs).
+// Every problem must satisfy that kernel's requirements (M, N >= 256, K % 64 == 0, operands < 4 GiB); otherwise
+// COGV_ERR_UNSUPPORTED and the caller issues them one by one.
+extern "C" int cogv_gemm_grouped(const cogv_gemm_desc* descs, int count, void* stream) {
+  if (!descs || count < 1 || count > MAX_GROUP) return COGV_ERR_ARG;
+  GroupArgs ga; ga.count = count;
+  for (int i = 0; i < count; ++i) {
+    const cogv_gemm_desc* d = descs + i;
+    const int rc = build_gemm_args(d, ga.g[i]);
+    if (rc != COGV_OK) return rc;
+    if (d->dtype != descs[0].dtype || d->trans_a != descs[0].trans_a || d->trans_b != descs[0].trans_b) return COGV_ERR_ARG;
+    const GemmArgs& a = ga.g[i];
+    const size_t a_span = (size_t)(d->trans_a ? a.K : a.M) * a.lda * 2, b_span = (size_t)(d->trans_b ? a.K : a.N) * a.ldb * 2;
+    if ((a.K % BK) || a.M < 256 || a.N < 256 || a_span >= (1ull << 32) || b_span >= (1ull << 32)) return COGV_ERR_UNSUPPORTED;
+    if (d->trans_a && (a.M & 7)) return COGV_ERR_UNSUPPORTED;
+    if (d->trans_b && (a.N & 7)) return COGV_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (descs[0].dtype == COGV_F16) launch_pp64_layout<f16_t>(descs[0].trans_a, descs[0].trans_b, ga, st);
+  else launch_pp64_layout<bf16_t>(descs[0].trans_a, descs[0].trans_b, ga, st);
+  for (int i = 0; i < count; ++i)
+    if (ga.g[i].splitk > 1) {
+      if (descs[0].dtype == COGV_F16) launch_splitk_reduce<f16_t>(ga.g[i], st);
+      else launch_splitk_reduce<bf16_t>(ga.g[i], st);
+    }
+  return cogv_check_launch();
 }

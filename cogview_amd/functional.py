@@ -408,10 +408,13 @@ def _layer_backward(layer, kp, dout, sep):
     # out = y + LN4(mo):  d_mo = mask(LN4'(dout)); bias grad of 4h->h = column sums of d_mo
     d_mo = ops.sandwich_ln_bwd(dout, kp.mo, ln4.weight, *kp.st4, dropout=kp.d_mo, dgamma=G(ln4.weight),
                                dbeta=G(ln4.bias), colsum=G(b2), accumulate=True).view(rows, h)
+    # The four weight gradients dW = dY^T X are deferred to ONE grouped launch at the end of the layer: together
+    # their 256x256 tiles fill whole rounds of the 256 CUs (each alone needs split-K slabs or idles half a round).
+    wgrads = []
     du = ops.gemm(d_mo, W2, trans_b=True, dgelu_aux=kp.u)                       # dgrad fused with dGeLU
-    ops.gemm(d_mo, kp.g, trans_a=True, trans_b=True, out=G(W2), accumulate=True)
+    wgrads.append((d_mo, kp.g, G(W2)))
     dc = _mp_allreduce(ops.gemm(du, W1, trans_b=True))
-    ops.gemm(du, kp.c.view(rows, h), trans_a=True, trans_b=True, out=G(W1), accumulate=True)
+    wgrads.append((du, kp.c.view(rows, h), G(W1)))
     ops.colsum(du, out=G(b1), accumulate=True)
     # y feeds LN2 and the second residual:  dy = dout + LN2'(dc)
     dy = ops.sandwich_ln_bwd(dc.view(b, s, h), kp.y, ln2.weight, *kp.st2, add_in=dout, dgamma=G(ln2.weight),
@@ -420,7 +423,7 @@ def _layer_backward(layer, kp, dout, sep):
     d_ao = ops.sandwich_ln_bwd(dy, kp.ao, ln3.weight, *kp.st3, dropout=kp.d_ao, dgamma=G(ln3.weight),
                                dbeta=G(ln3.bias), colsum=G(bo), accumulate=True).view(rows, h)
     d_att = ops.gemm(d_ao, Wo, trans_b=True).view(b, s, npp, 64)
-    ops.gemm(d_ao, kp.att.view(rows, hp), trans_a=True, trans_b=True, out=G(Wo), accumulate=True)
+    wgrads.append((d_ao, kp.att.view(rows, hp), G(Wo)))
     qkv = kp.qkv
     q = qkv[:, :, 0:hp].view(b, s, npp, 64)
     k = qkv[:, :, hp:2 * hp].view(b, s, npp, 64)
@@ -431,10 +434,11 @@ def _layer_backward(layer, kp, dout, sep):
                       dv=dqkv[:, :, 2 * hp:].view(b, s, npp, 64))
     dqkv2 = dqkv.view(rows, 3 * hp)
     da = _mp_allreduce(ops.gemm(dqkv2, Wq, trans_b=True))
-    ops.gemm(dqkv2, kp.a.view(rows, h), trans_a=True, trans_b=True, out=G(Wq), accumulate=True)
+    wgrads.append((dqkv2, kp.a.view(rows, h), G(Wq)))
     ops.colsum(dqkv2, out=G(bq), accumulate=True)
     dx = ops.sandwich_ln_bwd(da.view(b, s, h), kp.x, ln1.weight, *kp.st1, add_in=dy, dgamma=G(ln1.weight),
                              dbeta=G(ln1.bias), accumulate=True)
+    ops.gemm_grouped(wgrads, trans_a=True, trans_b=True, accumulate=True)
     return dx
 
 

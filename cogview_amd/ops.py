@@ -175,6 +175,61 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
     return out
 
 
+def gemm_grouped(problems, trans_a=True, trans_b=True, accumulate=True):
+    """Up to four GEMMs of one layout in ONE persistent launch (cogv_gemm_grouped): `problems` is a list of
+    (a, b, out).  Used for the four weight gradients of a transformer layer, which fill the 256 CUs together.
+    Falls back to one cogv_gemm per problem when the library reports a shape the grouped kernel does not take."""
+    assert 1 <= len(problems) <= 4
+    lib = L.lib()
+    descs = (L.GemmDesc * len(problems))()
+    tiles, kmin, flops, nbytes = 0, None, 0.0, 0.0
+    shapes = []
+    for d, (a, b, out) in zip(descs, problems):
+        _need_gpu(a, b, out)
+        assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+        K, M = a.shape if trans_a else a.shape[::-1]
+        Kb, N = b.shape if trans_b else b.shape[::-1]
+        assert K == Kb and out.shape == (M, N)
+        d.dtype = dt_code(a)
+        d.trans_a, d.trans_b = int(trans_a), int(trans_b)
+        d.M, d.N, d.K = M, N, K
+        d.A, d.lda = a.data_ptr(), a.stride(0)
+        d.B, d.ldb = b.data_ptr(), b.stride(0)
+        d.C, d.ldc = out.data_ptr(), out.stride(0)
+        d.out_f32 = int(out.dtype == torch.float32)
+        d.flags = L.EPI_ACCUM if accumulate else 0
+        shapes.append((M, N, K))
+        tiles += ((M + 255) // 256) * ((N + 255) // 256)
+        kmin = K if kmin is None else min(kmin, K)
+        flops += 2.0 * M * N * K
+        nbytes += 2.0 * (M * K + N * K + M * N)
+    ok = all(M >= 256 and N >= 256 and K % 64 == 0 for M, N, K in shapes)
+    if not ok:
+        for a, b, out in problems:
+            gemm(a, b, trans_a=trans_a, trans_b=trans_b, out=out, accumulate=accumulate)
+        return
+    splitk = lib.cogv_gemm_pick_splitk_tiles(tiles, kmin)
+    if splitk > 1:
+        sizes = [splitk * M * N * 4 for M, N, _ in shapes]
+        ws = workspace("gemm_grouped_splitk", sum(sizes), problems[0][0].device)
+        off = 0
+        for d, sz in zip(descs, sizes):
+            d.splitk, d.workspace, d.workspace_bytes = splitk, ws.data_ptr() + off, sz
+            off += sz
+    else:
+        for d in descs:
+            d.splitk = 1
+    if _GEMM_TIMING is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        L.check(lib.cogv_gemm_grouped(descs, len(problems), _stream()), "cogv_gemm_grouped")
+        ev1.record()
+        key = {(False, False): "NT_fwd", (False, True): "NN_dgrad", (True, True): "TN_wgrad"}.get((trans_a, trans_b), "TN_other")
+        _GEMM_TIMING.append((key, flops, nbytes, ev0, ev1))
+    else:
+        L.check(lib.cogv_gemm_grouped(descs, len(problems), _stream()), "cogv_gemm_grouped")
+
+
 # ------------------------------------------------------------------------------------------ Sandwich-LN
 def sandwich_ln_fwd(x, gamma, beta, eps, absmax_in, residual=None, absmax_out=None, save_stats=True):
     _need_gpu(x, gamma, beta)

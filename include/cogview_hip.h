@@ -77,6 +77,12 @@ typedef struct cogv_gemm_desc {
 int cogv_gemm(const cogv_gemm_desc* d, void* stream);
 size_t cogv_gemm_workspace_bytes(const cogv_gemm_desc* d);
 int cogv_gemm_pick_splitk(int M, int N, int K);
+/* Up to 4 GEMMs of one dtype and layout (same trans_a / trans_b) in ONE persistent launch: the weight gradients
+ * dW = dY^T X of the four linears of a layer (autograd of mpu/layers.py:243,319) fill the 256 CUs together where
+ * each alone would leave a partial last round.  COGV_ERR_UNSUPPORTED when a problem does not fit the 256x256x64
+ * kernel (M, N >= 256, K % 64 == 0): issue them one by one then.  Split-K as in cogv_gemm, per problem. */
+int cogv_gemm_grouped(const cogv_gemm_desc* descs, int count, void* stream);
+int cogv_gemm_pick_splitk_tiles(int tiles_256x256, int K);
 
 /* ------------------------------------------------------------------ Sandwich-LN
  * y = [residual +] LayerNorm_{eps*(amax/8)^2}(x) * gamma + beta ; amax = *absmax_in (NULL: plain LN).

@@ -88,6 +88,32 @@ def test_gemm_wgrad_tn(ops, dtype, M, N, K, splitk):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("K", [1088, 4352])
+def test_gemm_grouped_wgrads(ops, dtype, K):
+    """The four weight gradients of a layer in one persistent launch (cogv_gemm_grouped) == four separate GEMMs,
+    bit for bit when no split is chosen, and within tolerance of the fp32 reference either way."""
+    g = torch.Generator().manual_seed(K)
+    shapes = [(768, 256), (256, 256), (1024, 256), (256, 1024)]          # (out features, in features)
+    probs, refs, singles = [], [], []
+    for M, N in shapes:
+        dy, x, prev = rnd((K, M), dtype, g), rnd((K, N), dtype, g), rnd((M, N), dtype, g, 3.0)
+        refs.append(dy.float().t() @ x.float() + prev.float())
+        probs.append((dev(dy), dev(x), dev(prev.clone())))
+        one = dev(prev.clone())
+        ops.gemm(dev(dy), dev(x), trans_a=True, trans_b=True, out=one, accumulate=True, splitk=1, variant=9)
+        singles.append(one)
+    ops.gemm_grouped(probs, trans_a=True, trans_b=True, accumulate=True)
+    for (_, _, out), ref, one in zip(probs, refs, singles):
+        assert rel(out, ref) < TOL[dtype]
+        assert rel(out, one.float()) < 2e-3
+    # shapes the grouped kernel does not take fall back to one launch per problem
+    dy, x = rnd((300, 72), dtype, g), rnd((300, 136), dtype, g)
+    out = torch.zeros(72, 136, dtype=dtype).cuda()
+    ops.gemm_grouped([(dev(dy), dev(x), out)], trans_a=True, trans_b=True, accumulate=True)
+    assert rel(out, dy.float().t() @ x.float()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_gelu_dgelu_epilogues(ops, dtype):
     g = torch.Generator().manual_seed(3)
     M, N, K = 320, 512, 128
