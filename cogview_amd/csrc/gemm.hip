@@ -19,7 +19,7 @@
 #include "cogview_hip.h"
 
 #ifndef COGV_EXP
-#define COGV_EXP 0     // schedule experiments of tools/probes/gemm_exp.py (bit 0: no DMA, 1: no reads, 2: no MFMA, 3: DMA re-reads k-tiles 0..3)
+#define COGV_EXP 0     // schedule experiments of tools/probes/gemm_exp.py (bit 0: no DMA, 1: no reads, 2: no MFMA, 3: DMA re-reads k-tiles 0..3, 4: clock probe, 6: no epilogue)
 #endif
 
 namespace {
@@ -801,16 +801,92 @@ void gemm_glds_kernel(const GemmArgs p) {
   }
 }
 
+// ---- fused epilogue on 4 consecutive columns of one row: the same element-wise pipeline as epilogue8 (bias ->
+//      rounded pre-activation [+ aux store] -> GeLU | dGeLU -> dropout -> + C -> round -> abs-max), 8-byte accesses.
+//      Dropout bits follow the 8-element group convention of common.cuh: this quad is half (n >> 2) & 1 of its group.
+template <typename T>
+__device__ __forceinline__ float epilogue4(const GemmArgs& p, int m, int n, float (&v)[4]) {
+  if (p.flags & COGV_EPI_BIAS) {
+    const u32x2 bv = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.bias) + n);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      v[2 * i] += bits_to_f<T>((uint16_t)(bv[i] & 0xffffu));
+      v[2 * i + 1] += bits_to_f<T>((uint16_t)(bv[i] >> 16));
+    }
+  }
+  if (p.flags & COGV_EPI_GELU) {
+    u32x2 rv; rv[0] = pack2<T>(v[0], v[1]); rv[1] = pack2<T>(v[2], v[3]);
+    if (p.aux) *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n) = rv;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      v[2 * i] = gelu_f(bits_to_f<T>((uint16_t)(rv[i] & 0xffffu)));
+      v[2 * i + 1] = gelu_f(bits_to_f<T>((uint16_t)(rv[i] >> 16)));
+    }
+  }
+  if (p.flags & COGV_EPI_DGELU) {
+    const u32x2 uv = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      v[2 * i] *= gelu_grad_f(bits_to_f<T>((uint16_t)(uv[i] & 0xffffu)));
+      v[2 * i + 1] *= gelu_grad_f(bits_to_f<T>((uint16_t)(uv[i] >> 16)));
+    }
+  }
+  if ((p.flags & COGV_EPI_DROPOUT) && p.thr16) {
+    const uint64_t e = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;   // n % 4 == 0
+    const u32x4 r = Philox::gen(p.seed, p.stream_id, e >> 3);
+    const int h4 = (n >> 2) & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (drop_bits16(r, 4 * h4 + i) >= p.thr16) ? v[i] * p.keep_scale : 0.f;
+  }
+  if (p.flags & COGV_EPI_ACCUM) {
+    if (p.out_f32) {
+      const f32x4 c = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + (size_t)m * p.ldc + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += c[i];
+    } else {
+      const u32x2 cv = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        v[2 * i] += bits_to_f<T>((uint16_t)(cv[i] & 0xffffu));
+        v[2 * i + 1] += bits_to_f<T>((uint16_t)(cv[i] >> 16));
+      }
+    }
+  }
+  float amax = 0.f;
+  if (p.out_f32) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf(v[i]));
+  } else {
+    u32x2 o; o[0] = pack2<T>(v[0], v[1]); o[1] = pack2<T>(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = o;
+    if (p.flags & COGV_EPI_ABSMAX) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float r0 = bits_to_f<T>((uint16_t)(o[i] & 0xffffu)), r1 = bits_to_f<T>((uint16_t)(o[i] >> 16));
+        amax = fmaxf(amax, fmaxf(fabsf(r0), fabsf(r1)));          // NaN-ignoring max
+        if (r0 != r0) amax = r0;
+        if (r1 != r1) amax = r1;
+      }
+    }
+  }
+  return amax;
+}
+
 // =====================================================================================================
-// Generation-3 kernel: 256x256 tile, 64-deep k-tiles, 8 waves (2 x 4, 128x64 each), ping-pong schedule.
+// Generation-3 kernel: 256x256 tile, 64-deep k-tiles, 8 waves (2 x 4, 128x64 each), ping-pong schedule,
+// v_mfma_f32_16x16x32, persistent over (tile, k-split) items of up to four problems.
 //
-// Why: the DMA-only experiment (tools/probes/gemm_exp.py) showed the generation-2 loop is bound by the
-// global->LDS request stream, not by MFMA or LDS reads: with 32-deep tiles a K-contiguous operand arrives as
-// 64-byte row segments (half an L2 line per request, 11.9 TB/s chip-wide); 128-byte segments move 1.5x the
-// bytes in the same time.  A 64-deep 256x256 k-tile is 64 KiB, so only two fit in LDS -- a whole-tile ring would
-// have prefetch distance one.  Instead the k-tile is cut into three granules with different deadlines and the
-// two half-steps of a k-tile read DIFFERENT data (quadrant order), so every granule is resident for exactly one
-// READ phase and the prefetch distance is three half-steps for all of them:
+// Why this shape (measured with tools/probes/gemm_exp.py, which compiles the loop with parts removed):
+//  * the chip is POWER limited in a dense GEMM: the shader clock falls from 2.4 GHz to 1.3-1.8 GHz as soon as
+//    MFMA, LDS reads and LDS-DMA run together, so throughput follows energy per flop.  The 16x16x32 MFMA moves
+//    half the accumulator bytes per flop of the 32x32x16 one and measured +15 % on the whole loop;
+//  * a K-contiguous operand must arrive as 128-byte row segments (64-deep k-tiles): with 32-deep tiles every
+//    L2 request is half a line and the global->LDS stream alone cannot keep up (11.9 vs 18.3 TB/s chip-wide).
+// A 64-deep 256x256 k-tile is 64 KiB, so only two fit in LDS -- a whole-tile ring would have prefetch distance
+// one.  Instead the k-tile is cut into three granules with different deadlines and the two half-steps of a k-tile
+// read DIFFERENT data (quadrant order), so every granule is resident for exactly one READ phase and the prefetch
+// distance is three half-steps for all of them:
 //
 //   granule   content (64 k deep)                      bytes   read in      re-issued (for tile)   needed
 //   B         all 256 B rows                           32 KiB  R(2T)        R(2T+1)  (T+2)          R(2T+4)
@@ -818,15 +894,21 @@ void gemm_glds_kernel(const GemmArgs p) {
 //   A23       A rows [64,128) u [192,256)              16 KiB  R(2T+1)      R(2T+2)  (T+2)          R(2T+5)
 //
 //   half-step 2T  : READ  B fragments of the whole k-tile (kept in registers for both half-steps) + A01 fragments,
-//                   issue A23(T+1);          MFMA acc[0..1][*] += A01 x B   (16 MFMAs, 4 k-steps)
-//   half-step 2T+1: READ  A23 fragments, issue B(T+2), A01(T+2);  MFMA acc[2..3][*] += A23 x B
+//                   issue A23(T+1);          MFMA acc[0..3][*] += A01 x B   (32 MFMAs, 2 k-steps of 32)
+//   half-step 2T+1: READ  A23 fragments, issue B(T+2), A01(T+2);  MFMA acc[4..7][*] += A23 x B
 //
 // LDS: 2 buffers x (B 32 KiB | A01 16 KiB | A23 16 KiB) = 128 KiB.  Two barriers per half-step; waves 0-3 and
 // 4-7 (one of each per SIMD) run one barrier apart, so one wave of every SIMD is in its MFMA phase while the
-// other reads/issues.  Ordering (same argument as the PP variant of generation 2): a granule issued in R(h)
-// replaces data whose last reads were retired (lgkmcnt(0)) before every wave's B2(h-1); a granule needed in
-// R(h+1) is certified by every wave's counted vmcnt before its B2(h).  Each wave always has exactly 8 DMA
-// instructions issued after the ones it must certify (6 + 2), so the wait is vmcnt(8) in both half-steps.
+// other reads/issues.  Ordering: a granule issued in R(h) replaces data whose last reads were retired
+// (lgkmcnt(0)) before every wave's B2(h-1); a granule needed in R(h+1) is certified by every wave's counted vmcnt
+// before its B2(h).  Each wave always has exactly 8 DMA instructions issued after the ones it must certify
+// (6 + 2), so the wait is vmcnt(8) in both half-steps.
+//
+// The MFMA operands are SWAPPED (D = B_frag x A_frag), so a lane ends up with 4 consecutive COLUMNS of one
+// output row (one ds_write_b128 per 16x16 block), and the epilogue transposes through a private 2-KiB LDS strip
+// per wave without any workgroup barrier.  That leaves the ring free after the last READ phase: the NEXT item's
+// first 1.75 k-tiles are issued before the epilogue of the current one, so their latency and the draining C
+// stores overlap.
 template <typename T, bool AT, bool BT>
 __global__ __launch_bounds__(512, 2)
 void gemm_pp64_kernel(const GroupArgs ga) {
@@ -841,106 +923,107 @@ void gemm_pp64_kernel(const GroupArgs ga) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int wm = wr * 128, wn = wc * 64;
-  // Persistent: one workgroup per CU walks the (tile, k-split) items with stride gridDim.x.  The C stores of
-  // one item are still draining while the next item's prologue loads are in flight (a 256x256 bf16 tile per CU
-  // is 32 MiB per round chip-wide: ~6 us of HBM write time that a one-workgroup-per-CU grid would expose).
+  const int l15 = lane & 15, kb = lane >> 4;
   const int nitems = ga.item_start[ga.count];
-#pragma unroll 1
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-  int pi = 0;
-#pragma unroll
-  for (int t = 1; t < MAX_GROUP; ++t) pi += (t < ga.count && item >= ga.item_start[t]) ? 1 : 0;
-  const GemmArgs& p = ga.g[pi];
-  const int local = item - ga.item_start[pi];
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int bid = local % nwg, ksplit = local / nwg;
-  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-  constexpr int GROUP_M = 4;
-  const int in_group = GROUP_M * p.tiles_n;
-  const int group_id = wgid / in_group;
-  const int first_m = group_id * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int tile_m = first_m + (wgid % in_group) % gsz;
-  const int tile_n = (wgid % in_group) / gsz;
-  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
 
-  const int kt0 = ksplit * p.ktiles_per_split;
-  const int nk = min(p.K / KT, kt0 + p.ktiles_per_split) - kt0;       // >= 1 by construction
-
-  // ---- per-lane DMA sources.  Piece = one 1-KiB LDS-DMA instruction; wave w owns pieces i*8 + w.
-  //      B: 32 pieces (4 per wave); A01, A23: 16 pieces each (2 + 2 per wave).
-  // (32-bit per-lane byte offsets against a wave-uniform base: the SGPR-base form of global_load_lds, 8 VGPRs)
-  uint32_t offB[4], offA[2][2];
+  // ---- everything that depends on the work item: which problem, which tile, which k range, DMA sources
+  struct Item {
+    int pi, m0, n0, ksplit, kt0, nk;
+    uint32_t offB[4], offA[2][2];      // per-lane byte offsets against a wave-uniform base (SGPR-base DMA form)
+  };
+  auto setup = [&](int item, Item& it) {
+    int pi = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = i * NW + wave;
-    if (!BT) {
-      const int row = piece * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ swz(row);
-      const int gn = min(n0 + row, p.N - 1);
-      offB[i] = (uint32_t)(((size_t)gn * p.ldb + c * 8) * 2);
-    } else {
-      const int off = piece * 1024 + lane * 16;
-      const int krow = off / ROWB_B, pc = (off % ROWB_B) >> 4;
-      const int c = pc ^ trswz16(krow);
-      const int col = min(n0 + c * 8, p.N - 8);
-      offB[i] = (uint32_t)(((size_t)krow * p.ldb + col) * 2);
-    }
-  }
+    for (int t = 1; t < MAX_GROUP; ++t) pi += (t < ga.count && item >= ga.item_start[t]) ? 1 : 0;
+    const GemmArgs& p = ga.g[pi];
+    const int local = item - ga.item_start[pi];
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = local % nwg;
+    it.pi = pi; it.ksplit = local / nwg;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    constexpr int GROUP_M = 4;
+    const int in_group = GROUP_M * p.tiles_n;
+    const int group_id = wgid / in_group;
+    const int first_m = group_id * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tile_m = first_m + (wgid % in_group) % gsz;
+    const int tile_n = (wgid % in_group) / gsz;
+    const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+    it.m0 = m0; it.n0 = n0;
+    it.kt0 = it.ksplit * p.ktiles_per_split;
+    it.nk = min(p.K / KT, it.kt0 + p.ktiles_per_split) - it.kt0;       // >= 1 by construction
+    // Piece = one 1-KiB LDS-DMA instruction; wave w owns pieces i*8 + w.  B: 32 pieces (4 per wave); A01, A23: 16 each.
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const int piece = i * NW + wave;
-      if (!AT) {
-        const int row = piece * 8 + (lane >> 3);                 // granule row 0..127
+      if (!BT) {
+        const int row = piece * 8 + (lane >> 3);
         const int c = (lane & 7) ^ swz(row);
-        const int tr = (row & 63) + 128 * (row >> 6) + 64 * g;   // tile row
-        const int gm = min(m0 + tr, p.M - 1);
-        offA[g][i] = (uint32_t)(((size_t)gm * p.lda + c * 8) * 2);
+        const int gn = min(n0 + row, p.N - 1);
+        it.offB[i] = (uint32_t)(((size_t)gn * p.ldb + c * 8) * 2);
       } else {
         const int off = piece * 1024 + lane * 16;
-        const int krow = off / ROWB_A, pc = (off % ROWB_A) >> 4;
+        const int krow = off / ROWB_B, pc = (off % ROWB_B) >> 4;
         const int c = pc ^ trswz16(krow);
-        const int gc = c * 8;                                    // granule column 0..127
-        const int tcol = (gc & 63) + 128 * (gc >> 6) + 64 * g;   // tile row (= column of the stored A)
-        const int col = min(m0 + tcol, p.M - 8);
-        offA[g][i] = (uint32_t)(((size_t)krow * p.lda + col) * 2);
+        const int col = min(n0 + c * 8, p.N - 8);
+        it.offB[i] = (uint32_t)(((size_t)krow * p.ldb + col) * 2);
       }
     }
-  const size_t kstrideA = AT ? (size_t)KT * p.lda * 2 : (size_t)KT * 2;
-  const size_t kstrideB = BT ? (size_t)KT * p.ldb * 2 : (size_t)KT * 2;
-  const char* baseA = reinterpret_cast<const char*>(p.A) + (size_t)kt0 * kstrideA;
-  const char* baseB = reinterpret_cast<const char*>(p.B) + (size_t)kt0 * kstrideB;
-  auto issue_B = [&](int kt, int buf) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int piece = i * NW + wave;
+        if (!AT) {
+          const int row = piece * 8 + (lane >> 3);                 // granule row 0..127
+          const int c = (lane & 7) ^ swz(row);
+          const int tr = (row & 63) + 128 * (row >> 6) + 64 * g;   // tile row
+          const int gm = min(m0 + tr, p.M - 1);
+          it.offA[g][i] = (uint32_t)(((size_t)gm * p.lda + c * 8) * 2);
+        } else {
+          const int off = piece * 1024 + lane * 16;
+          const int krow = off / ROWB_A, pc = (off % ROWB_A) >> 4;
+          const int c = pc ^ trswz16(krow);
+          const int gc = c * 8;                                    // granule column 0..127
+          const int tcol = (gc & 63) + 128 * (gc >> 6) + 64 * g;   // tile row (= column of the stored A)
+          const int col = min(m0 + tcol, p.M - 8);
+          it.offA[g][i] = (uint32_t)(((size_t)krow * p.lda + col) * 2);
+        }
+      }
+  };
+  auto issue_B = [&](const Item& it, int kt, int buf) {
     if (COGV_EXP & 1) return;
     if (COGV_EXP & 8) kt &= 3;              // re-read the first k-tiles: every request an L2 hit
+    const GemmArgs& p = ga.g[it.pi];
+    const size_t kstride = BT ? (size_t)KT * p.ldb * 2 : (size_t)KT * 2;
+    const char* g = reinterpret_cast<const char*>(p.B) + (size_t)(it.kt0 + kt) * kstride;
     char* l = smem + buf * BUF + B_OFF;
-    const char* g = baseB + (size_t)kt * kstrideB;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(g + offB[i]), (lds_void_t*)(l + (i * NW + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(g + it.offB[i]), (lds_void_t*)(l + (i * NW + wave) * 1024), 16, 0, 0);
   };
-  auto issue_A = [&](int gi, int kt, int buf) {
+  auto issue_A = [&](const Item& it, int gi, int kt, int buf) {
     if (COGV_EXP & 1) return;
     if (COGV_EXP & 8) kt &= 3;
+    const GemmArgs& p = ga.g[it.pi];
+    const size_t kstride = AT ? (size_t)KT * p.lda * 2 : (size_t)KT * 2;
+    const char* g = reinterpret_cast<const char*>(p.A) + (size_t)(it.kt0 + kt) * kstride;
     char* l = smem + buf * BUF + (gi ? A23_OFF : A01_OFF);
-    const char* g = baseA + (size_t)kt * kstrideA;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(g + offA[gi][i]), (lds_void_t*)(l + (i * NW + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(g + it.offA[gi][i]), (lds_void_t*)(l + (i * NW + wave) * 1024), 16, 0, 0);
   };
-
-  f32x4 acc[8][4];                   // 16x16 blocks of this wave's 128x64: acc[row block][column block]
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // tile 0 complete + B, A01 of tile 1: 14 DMA instructions per wave, in the order the k-loop certifies them
+  auto prologue = [&](const Item& it) {
+    issue_B(it, 0, 0); issue_A(it, 0, 0, 0);
+    issue_A(it, 1, 0, 0);
+    const int t1 = min(1, it.nk - 1);
+    issue_B(it, t1, 1); issue_A(it, 0, t1, 1);
+  };
 
   // ---- per-lane fragment read addresses (buffer 0, k-step 0).  v_mfma_f32_16x16x32: lane l supplies row
   //      (l & 15) of a 16-row block and the 8 contraction slots of k-block (l >> 4).
-  const int l15 = lane & 15, kb = lane >> 4;
   uint32_t adB[4], adA[4];           // adA is relative to the A granule (A01 and A23 share the in-granule layout)
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -951,125 +1034,181 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     adA[i] = AT ? tr_addr16<ROWB_A>(smem, wr * 64 + 16 * i, lane)
                 : (uint32_t)(uintptr_t)smem + (uint32_t)((wr * 64 + 16 * i + l15) * 128 + ((kb ^ swz(wr * 64 + 16 * i + l15)) << 4));
 
-  // prologue: tile 0 complete, B + A01 of tile 1
-  issue_B(0, 0); issue_A(0, 0, 0);
-  issue_A(1, 0, 0);
-  { const int t1 = min(1, nk - 1); issue_B(t1, 1); issue_A(0, t1, 1); }
-  wait_vmcnt<8>();                           // this wave's pieces of B(0), A01(0)
-  __builtin_amdgcn_s_barrier();
-  const int grp = wr;
-  if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger
+  Item cur;
+  if ((int)blockIdx.x < nitems) { setup(blockIdx.x, cur); prologue(cur); }
+#pragma unroll 1
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const GemmArgs& p = ga.g[cur.pi];
+    const int nk = cur.nk;
+    f32x4 acc[8][4];                   // 16x16 blocks of this wave's 128x64: acc[row block][column block]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  TrRaw tb[KS][4], ta[KS][4];          // KS = 2 k-steps of 32 per k-tile
-  u32x4 nb[KS][4], na[KS][4];
-  auto read_B = [&](uint32_t boff) {
-    if (COGV_EXP & 2) return;
+    // Outstanding per wave, oldest first: [C stores of the previous item] [B(0) A01(0): 6] [A23(0): 2] [B(1) A01(1): 6].
+    // Loads retire in order among loads, so "at most 8 outstanding" means the first 6 have landed (and every store).
+    wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();             // the stagger
+
+    TrRaw tb[KS][4], ta[KS][4];          // KS = 2 k-steps of 32 per k-tile
+    u32x4 nb[KS][4], na[KS][4];
+    auto read_B = [&](uint32_t boff) {
+      if (COGV_EXP & 2) return;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (BT) tr_issue16<ROWB_B>(adB[j] + boff, ks, tb[ks][j]);
-        else nat_issue((adB[j] + boff) ^ (uint32_t)(ks << 6), nb[ks][j]);
+        for (int j = 0; j < 4; ++j) {
+          if (BT) tr_issue16<ROWB_B>(adB[j] + boff, ks, tb[ks][j]);
+          else nat_issue((adB[j] + boff) ^ (uint32_t)(ks << 6), nb[ks][j]);
+        }
+    };
+    auto read_A = [&](uint32_t goff) {
+      if (COGV_EXP & 2) return;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (AT) tr_issue16<ROWB_A>(adA[i] + goff, ks, ta[ks][i]);
+          else nat_issue((adA[i] + goff) ^ (uint32_t)(ks << 6), na[ks][i]);
+        }
+    };
+    auto land_A = [&]() {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (AT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[ks][i].lo), "+v"(ta[ks][i].hi) : : "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na[ks][i]) : : "memory");
+        }
+    };
+    auto land_B = [&]() {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (BT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[ks][j].lo), "+v"(tb[ks][j].hi) : : "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nb[ks][j]) : : "memory");
+        }
+    };
+    auto mma = [&](int half) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        typename HT<T>::v8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (AT) fa[i] = tr_pack<T>(ta[ks][i]); else __builtin_memcpy(&fa[i], &na[ks][i], 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (BT) fb[j] = tr_pack<T>(tb[ks][j]); else __builtin_memcpy(&fb[j], &nb[ks][j], 16);
+        }
+        if (COGV_EXP & 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(fa[i]));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(fb[j]));
+          continue;
+        }
+        // operands swapped: D[n][m] -> lane (m = l & 15) holds columns n = 4 (l >> 4) .. +3 of its row
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[4 * half + i][j] = HT<T>::mfma16(fb[j], fa[i], acc[4 * half + i][j]);
       }
-  };
-  auto read_A = [&](uint32_t goff) {
-    if (COGV_EXP & 2) return;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (AT) tr_issue16<ROWB_A>(adA[i] + goff, ks, ta[ks][i]);
-        else nat_issue((adA[i] + goff) ^ (uint32_t)(ks << 6), na[ks][i]);
-      }
-  };
-  auto land_A = [&]() {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (AT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[ks][i].lo), "+v"(ta[ks][i].hi) : : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na[ks][i]) : : "memory");
-      }
-  };
-  auto land_B = [&]() {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (BT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[ks][j].lo), "+v"(tb[ks][j].hi) : : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nb[ks][j]) : : "memory");
-      }
-  };
-  auto mma = [&](int half) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      typename HT<T>::v8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (AT) fa[i] = tr_pack<T>(ta[ks][i]); else __builtin_memcpy(&fa[i], &na[ks][i], 16);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (BT) fb[j] = tr_pack<T>(tb[ks][j]); else __builtin_memcpy(&fb[j], &nb[ks][j], 16);
-      }
-      if (COGV_EXP & 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(fa[i]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(fb[j]));
-        continue;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[4 * half + i][j] = HT<T>::mfma16(fa[i], fb[j], acc[4 * half + i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      const uint32_t boff = (uint32_t)(buf * BUF);
+      // ---------------- half-step 2T
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      read_B(boff);
+      read_A(boff + A01_OFF);
+      issue_A(cur, 1, min(kt + 1, nk - 1), buf ^ 1);
+      land_B(); land_A();
+      wait_vmcnt<8>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0);
+      // ---------------- half-step 2T + 1
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      read_A(boff + A23_OFF);
+      { const int t2 = min(kt + 2, nk - 1); issue_B(cur, t2, buf); issue_A(cur, 0, t2, buf); }
+      land_A();
+      wait_vmcnt<8>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(1);
     }
-    __builtin_amdgcn_s_setprio(0);
-  };
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 0) __builtin_amdgcn_s_barrier();              // even out the barrier count
+    // Every wave has passed its last READ phase here (group 1's final B2 is the barrier above): the ring is free.
+    wait_vmcnt<0>();                                        // the (redundant) tail prefetches of this item
+    __builtin_amdgcn_sched_barrier(0);
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const uint32_t boff = (uint32_t)(buf * BUF);
-    // ---------------- half-step 2T
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    read_B(boff);
-    read_A(boff + A01_OFF);
-    issue_A(1, min(kt + 1, nk - 1), buf ^ 1);
-    land_B(); land_A();
-    wait_vmcnt<8>();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0);
-    // ---------------- half-step 2T + 1
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    read_A(boff + A23_OFF);
-    { const int t2 = min(kt + 2, nk - 1); issue_B(t2, buf); issue_A(0, t2, buf); }
-    land_A();
-    wait_vmcnt<8>();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    mma(1);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if (grp == 0) __builtin_amdgcn_s_barrier();              // even out the barrier count
-  wait_vmcnt<0>();   // drain the (redundant) tail prefetches before the ring is reused
-  __syncthreads();
-  store_c_tile<T, NW, TBM, TBN, 8, 4, 2 * BUF>(p, acc, smem, m0, n0, wm, wn, lane, ksplit);
-  __syncthreads();   // the C staging reads are done: the next item's DMA may overwrite the ring
-  if ((COGV_EXP & 16) && p.out_f32 && threadIdx.x == 0 && (bid == 0 || bid == nwg - 1)) {
-    // shader clock in MHz over this workgroup's lifetime (s_memrealtime ticks at 100 MHz)
-    const uint64_t dt = __builtin_readcyclecounter() - exp_t0, dr = __builtin_amdgcn_s_memrealtime() - exp_r0;
-    __syncthreads();
-    reinterpret_cast<float*>(p.C)[(size_t)m0 * p.ldc + n0] = 100.f * (float)dt / (float)dr;
-  }
+    // ---- next item's prologue goes out BEFORE this item's epilogue
+    const Item done = cur;
+    if (item + (int)gridDim.x < nitems) { setup(item + gridDim.x, cur); prologue(cur); }
+
+    // ---- epilogue.  The accumulators hold, per lane, 4 consecutive columns of row (l & 15) of each 16x16 block.
+    //      Each wave transposes its own 128x64 sub-tile through a PRIVATE 2-KiB strip of LDS (8 rows x 64 fp32
+    //      columns at a time; the A23 slot of buffer 1, which the next item's prologue does not touch) into
+    //      "8 lanes x 16 bytes = one 128-byte line per row" order for the fused epilogue8: no workgroup barrier,
+    //      full-line stores.  (Storing straight from the MFMA layout -- 8 bytes per lane, 32-byte row segments --
+    //      measured 4x slower than this: 16 us per tile.)  16-byte chunk c of strip row r sits at chunk c ^ r.
+    float amax = 0.f; bool nan = false;
+    float* strip = reinterpret_cast<float*>(smem + BUF + A23_OFF + wave * 2048);
+    const int sr = lane >> 3, sc = lane & 7;           // read side: strip row, 8-column group
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        if ((l15 >> 3) == hh) {
+          const int r = l15 & 7;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(strip + r * 64 + (((4 * j + kb) ^ r) << 2)) = acc[i][j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc) ^ sr) << 2));
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc + 1) ^ sr) << 2));
+        __builtin_amdgcn_wave_barrier();
+        const int m = done.m0 + wm + 16 * i + 8 * hh + sr, n = done.n0 + wn + 8 * sc;
+        if ((COGV_EXP & 64) && x0[0] != 12345.f) continue;      // probe: no epilogue
+        if (m < p.M && n < p.N) {
+          if (p.splitk > 1) {
+            float* w = p.ws + ((size_t)done.ksplit * p.M + m) * p.N + n;
+            *reinterpret_cast<f32x4*>(w) = x0;
+            *reinterpret_cast<f32x4*>(w + 4) = x1;
+          } else {
+            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            const float a = epilogue8<T>(p, m, n, v);
+            if (a != a) nan = true; else amax = fmaxf(amax, a);
+          }
+        }
+      }
+    }
+    if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
+      float wmx = wave_max(amax);
+      const bool wnan = __any(nan);
+      if (lane == 0) atomic_max_nonneg(p.absmax, wnan ? __uint_as_float(0x7fc00000u) : wmx);
+    }
+    if ((COGV_EXP & 16) && p.out_f32 && threadIdx.x == 0) {
+      // shader clock in MHz over this workgroup's lifetime so far (s_memrealtime ticks at 100 MHz)
+      const uint64_t dt = __builtin_readcyclecounter() - exp_t0, dr = __builtin_amdgcn_s_memrealtime() - exp_r0;
+      reinterpret_cast<float*>(p.C)[(size_t)done.m0 * p.ldc + done.n0] = 100.f * (float)dt / (float)dr;
+    }
   }
 }
 

@@ -4,7 +4,8 @@
 // so the kernel never divides the tensor: it reads the global abs-max scalar that the PRODUCER of x left
 // behind (GEMM epilogue / residual kernels / cogv_absmax) and folds it into epsilon.
 //
-// One wave (64 lanes) per row, row cached in registers, wave-shuffle reductions (no LDS, no barriers).
+// Forward: one wave (64 lanes) per row, row cached in registers, wave-shuffle reductions (no LDS, no barriers).
+// Backward: one workgroup of ceil(h/512) waves per row, 8 columns per lane (see ln_bwd_kernel).
 // HBM-bound: forward moves 2*h*2 B per row (+2*h*2 with the fused residual), backward 3*h*2 B.
 #include "common.cuh"
 #include "cogview_hip.h"
@@ -111,68 +112,96 @@ struct LnBwdArgs {
   uint64_t seed, stream_id; uint32_t thr16; float keep_scale;
 };
 
-template <typename T, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* red = reinterpret_cast<float*>(smem_raw);   // [4][h]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wave_global = blockIdx.x * 4 + wave;
-  const int nwaves = gridDim.x * 4;
+// Backward.  One workgroup of ceil(h / 512) waves covers a row: every lane owns 8 columns for the whole kernel, so
+// the three per-column accumulators (dgamma, dbeta, column sum of the output) are 24 registers per lane and need
+// no cross-wave reduction -- the wave-per-row form kept 3 * h / 64 of them per lane (120 at h = 2560), which capped
+// occupancy at two waves per SIMD and ran at 2 TB/s.  R rows are in flight per iteration (R * 2..3 16-byte
+// loads per lane); the two row statistics go through a double-buffered LDS exchange, one barrier per R rows.
+template <typename T, int R>
+__global__ __launch_bounds__(512) void ln_bwd_kernel(const LnBwdArgs p) {
+  __shared__ float red[2][R][8][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int col = threadIdx.x * 8;
+  const bool act = col < p.h;
   const T* DY = reinterpret_cast<const T*>(p.dy);
   const T* X = reinterpret_cast<const T*>(p.x);
   const T* AD = reinterpret_cast<const T*>(p.add_in);
   T* DX = reinterpret_cast<T*>(p.dx);
   const float inv_h = 1.0f / (float)p.h;
 
-  float g[NV][8], dg[NV][8], db[NV][8], cs[NV][8];
+  float g[8], dg[8], db[8], cs[8];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int col = (v * 64 + lane) * 8;
-    if (col < p.h) unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.gamma) + col), g[v]);
+  for (int i = 0; i < 8; ++i) { g[i] = 0.f; dg[i] = 0.f; db[i] = 0.f; cs[i] = 0.f; }
+  if (act) unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.gamma) + col), g);
+  int buf = 0;
+  u32x4 dyn[R], xn_[R], adn[R];      // the NEXT iteration's rows: loaded before this iteration's barrier and stores
+  float meann[R], rstdn[R];
+  auto fetch = [&](int row0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { dg[v][i] = 0.f; db[v][i] = 0.f; cs[v][i] = 0.f; }
-  }
-  for (int row = wave_global; row < p.rows; row += nwaves) {
-    const float mean = p.mean[row], rstd = p.rstd[row];
-    float xh[NV][8], gy[NV][8];
-    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      const bool ok = act && row < p.rows;
+      dyn[r] = ok ? *reinterpret_cast<const u32x4*>(DY + (size_t)row * p.h + col) : u32x4{0u, 0u, 0u, 0u};
+      xn_[r] = ok ? *reinterpret_cast<const u32x4*>(X + (size_t)row * p.h + col) : u32x4{0u, 0u, 0u, 0u};
+      if (AD) adn[r] = ok ? *reinterpret_cast<const u32x4*>(AD + (size_t)row * p.h + col) : u32x4{0u, 0u, 0u, 0u};
+      meann[r] = row < p.rows ? p.mean[row] : 0.f;
+      rstdn[r] = row < p.rows ? p.rstd[row] : 0.f;
+    }
+  };
+  fetch(blockIdx.x * R);
+  for (int row0 = blockIdx.x * R; row0 < p.rows; row0 += gridDim.x * R) {
+    u32x4 dyv[R], xv[R], adv[R];
+    float mean[R], rstd[R], s1[R], s2[R];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int col = (v * 64 + lane) * 8;
-      if (col < p.h) {
-        float dy[8];
-        unpack8<T>(*reinterpret_cast<const u32x4*>(DY + (size_t)row * p.h + col), dy);
-        unpack8<T>(*reinterpret_cast<const u32x4*>(X + (size_t)row * p.h + col), xh[v]);
+    for (int r = 0; r < R; ++r) {
+      dyv[r] = dyn[r]; xv[r] = xn_[r]; adv[r] = adn[r]; mean[r] = meann[r]; rstd[r] = rstdn[r];
+    }
+    fetch(row0 + gridDim.x * R);       // rows past the end load nothing
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float dy[8], xh[8];
+      unpack8<T>(dyv[r], dy); unpack8<T>(xv[r], xh);
+      float a1 = 0.f, a2 = 0.f;
+      if (act && row0 + r < p.rows) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          xh[v][i] = (xh[v][i] - mean) * rstd;
-          gy[v][i] = dy[i] * g[v][i];
-          s1 += gy[v][i];
-          s2 += gy[v][i] * xh[v][i];
-          dg[v][i] += dy[i] * xh[v][i];
-          db[v][i] += dy[i];
+          xh[i] = (xh[i] - mean[r]) * rstd[r];
+          const float gy = dy[i] * g[i];
+          a1 += gy;
+          a2 += gy * xh[i];
+          dg[i] += dy[i] * xh[i];
+          db[i] += dy[i];
         }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { xh[v][i] = 0.f; gy[v][i] = 0.f; }
       }
+      s1[r] = wave_sum(a1); s2[r] = wave_sum(a2);
     }
-    const float m1 = wave_sum(s1) * inv_h, m2 = wave_sum(s2) * inv_h;
+    if (lane == 0) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int col = (v * 64 + lane) * 8;
-      if (col < p.h) {
-        float o[8];
+      for (int r = 0; r < R; ++r) { red[buf][r][wave][0] = s1[r]; red[buf][r][wave][1] = s2[r]; }
+    }
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = rstd * (gy[v][i] - m1 - xh[v][i] * m2);
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      float m1 = 0.f, m2 = 0.f;
+      for (int w = 0; w < nw; ++w) { m1 += red[buf][r][w][0]; m2 += red[buf][r][w][1]; }
+      m1 *= inv_h; m2 *= inv_h;
+      if (act && row < p.rows) {
+        float dy[8], xh[8], o[8];
+        unpack8<T>(dyv[r], dy); unpack8<T>(xv[r], xh);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xn = (xh[i] - mean[r]) * rstd[r];
+          o[i] = rstd[r] * (dy[i] * g[i] - m1 - xn * m2);
+        }
         if (p.thr16) {
           const uint64_t e = (uint64_t)row * (uint64_t)p.h + (uint64_t)col;
-          const u32x4 r = Philox::gen(p.seed, p.stream_id, e >> 3);
+          const u32x4 rn = Philox::gen(p.seed, p.stream_id, e >> 3);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = (drop_bits16(r, i) >= p.thr16) ? o[i] * p.keep_scale : 0.f;
+          for (int i = 0; i < 8; ++i) o[i] = (drop_bits16(rn, i) >= p.thr16) ? o[i] * p.keep_scale : 0.f;
         }
         if (AD) {
-          float a[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(AD + (size_t)row * p.h + col), a);
+          float a[8]; unpack8<T>(adv[r], a);
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] += a[i];
         }
@@ -181,28 +210,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
         if (p.want_colsum) {
           float rr[8]; unpack8<T>(ov, rr);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) cs[v][i] += rr[i];
+          for (int i = 0; i < 8; ++i) cs[i] += rr[i];
         }
       }
     }
+    buf ^= 1;
   }
-  // cross-wave reduction of the three column accumulators, one set at a time through LDS
-  for (int set = 0; set < 3; ++set) {
-    if (set == 2 && !p.want_colsum) break;
-    __syncthreads();
+  if (act) {
+    float* out = p.partial + (size_t)blockIdx.x * 3 * p.h + col;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int col = (v * 64 + lane) * 8;
-      if (col < p.h) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          red[wave * p.h + col + i] = (set == 0) ? dg[v][i] : (set == 1) ? db[v][i] : cs[v][i];
-      }
-    }
-    __syncthreads();
-    float* out = p.partial + ((size_t)blockIdx.x * 3 + set) * p.h;
-    for (int c = threadIdx.x; c < p.h; c += 256)
-      out[c] = red[c] + red[p.h + c] + red[2 * p.h + c] + red[3 * p.h + c];
+    for (int i = 0; i < 8; ++i) { out[i] = dg[i]; out[p.h + i] = db[i]; if (p.want_colsum) out[2 * p.h + i] = cs[i]; }
   }
 }
 
@@ -232,15 +249,9 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* partia
 template <typename T, int NV> void launch_fwd(const LnFwdArgs& a, int blocks, hipStream_t st) {
   hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(blocks), dim3(256), 0, st, a);
 }
-template <typename T, int NV> void launch_bwd(const LnBwdArgs& a, int blocks, hipStream_t st) {
-  const size_t sh = (size_t)4 * a.h * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, NV>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * NV * (int)sizeof(float));
-    attr = true;
-  }
-  hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), dim3(blocks), dim3(256), sh, st, a);
+template <typename T> void launch_bwd(const LnBwdArgs& a, int blocks, hipStream_t st) {
+  const int nw = (a.h + 511) / 512;             // waves per row (h <= 4096 -> <= 8)
+  hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), dim3(blocks), dim3(nw * 64), 0, st, a);
 }
 
 #define NV_SWITCH(FN, T, nv, ...)                          \
@@ -260,7 +271,7 @@ constexpr int LN_BWD_MAX_BLOCKS = 512;
 }  // namespace
 
 extern "C" int cogv_ln_bwd_num_blocks(int rows) {
-  int b = (rows + 3) / 4;
+  int b = (rows + 3) / 4;                       // 4 rows per workgroup iteration
   return b < 1 ? 1 : (b > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : b);
 }
 extern "C" size_t cogv_ln_bwd_workspace_bytes(int rows, int h) {
@@ -300,9 +311,8 @@ extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, co
   a.thr16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
   const int blocks = cogv_ln_bwd_num_blocks(rows);
-  const int nv = (h + 511) / 512;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == COGV_F16) { NV_SWITCH(launch_bwd, f16_t, nv, a, blocks, st) } else { NV_SWITCH(launch_bwd, bf16_t, nv, a, blocks, st) }
+  if (dtype == COGV_F16) launch_bwd<f16_t>(a, blocks, st); else launch_bwd<bf16_t>(a, blocks, st);
   if (dgamma || dbeta || colsum) {
     dim3 grid((h + 63) / 64, 3);
     if (dtype == COGV_F16)
