@@ -1184,8 +1184,10 @@ void gemm_pp64_kernel(const GroupArgs ga) {
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc) ^ sr) << 2));
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc + 1) ^ sr) << 2));
         __builtin_amdgcn_wave_barrier();
-        const int m = done.m0 + wm + 16 * i + 8 * hh + sr, n = done.n0 + wn + 8 * sc;
+        int m = done.m0 + wm + 16 * i + 8 * hh + sr;
+        const int n = done.n0 + wn + 8 * sc;
         if ((COGV_EXP & 64) && x0[0] != 12345.f) continue;      // probe: no epilogue
+        if (COGV_EXP & 128) m &= 255;                           // probe: all tiles store to the same L2-resident rows
         if (m < p.M && n < p.N) {
           if (p.splitk > 1) {
             float* w = p.ws + ((size_t)done.ksplit * p.M + m) * p.N + n;
