@@ -18,6 +18,8 @@
 #include "common.cuh"
 #include "cogview_hip.h"
 
+#include <type_traits>
+
 #ifndef COGV_EXP
 #define COGV_EXP 0     // schedule experiments of tools/probes/gemm_exp.py (bit 0: no DMA, 1: no reads, 2: no MFMA, 3: DMA re-reads k-tiles 0..3, 4: clock probe, 6: no epilogue)
 #endif
@@ -123,15 +125,19 @@ __device__ __forceinline__ typename HT<T>::v8 read_frag(const char* lds, int row
 }
 
 // ---- fused epilogue on 8 consecutive columns of one row (fp32 in registers)
-template <typename T>
+//      F >= 0: the flag mask is a compile-time constant and the output is 16-bit (the generation-3 kernel dispatches
+//      the hot combinations to such instances so that one item's epilogue is a few KB of code, not all paths).
+template <typename T, int F = -1>
 __device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, float (&v)[8]) {
-  if (p.flags & COGV_EPI_BIAS) {
+  const int flags = F >= 0 ? F : p.flags;
+  const bool out_f32 = F >= 0 ? false : (p.out_f32 != 0);
+  if (flags & COGV_EPI_BIAS) {
     u32x4 bv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
     float b[8]; unpack8<T>(bv, b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += b[i];
   }
-  if (p.flags & COGV_EPI_GELU) {
+  if (flags & COGV_EPI_GELU) {
     // the activation is evaluated on the pre-activation ROUNDED to the storage type -- exactly what backward
     // (or a checkpoint recompute that does store it) reads -- whether or not it is stored now
     const u32x4 rv = pack8<T>(v);
@@ -140,20 +146,20 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, floa
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
   }
-  if (p.flags & COGV_EPI_DGELU) {
+  if (flags & COGV_EPI_DGELU) {
     u32x4 uv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
     float u[8]; unpack8<T>(uv, u);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(u[i]);
   }
-  if ((p.flags & COGV_EPI_DROPOUT) && p.thr16) {
+  if ((flags & COGV_EPI_DROPOUT) && p.thr16) {
     const uint64_t e = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;   // n % 8 == 0
     const u32x4 r = Philox::gen(p.seed, p.stream_id, e >> 3);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (drop_bits16(r, i) >= p.thr16) ? v[i] * p.keep_scale : 0.f;
   }
-  if (p.flags & COGV_EPI_ACCUM) {
-    if (p.out_f32) {
+  if (flags & COGV_EPI_ACCUM) {
+    if (out_f32) {
       const float* c = reinterpret_cast<const float*>(p.C) + (size_t)m * p.ldc + n;
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += c[i];
@@ -165,7 +171,7 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, floa
     }
   }
   float amax = 0.f;
-  if (p.out_f32) {
+  if (out_f32) {
     float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
     *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -174,7 +180,7 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, floa
   } else {
     u32x4 o = pack8<T>(v);
     *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = o;
-    if (p.flags & COGV_EPI_ABSMAX) {
+    if (flags & COGV_EPI_ABSMAX) {
       float r[8]; unpack8<T>(o, r);
 #pragma unroll
       for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(r[i]));   // NaN-ignoring max; NaNs handled below
@@ -801,76 +807,46 @@ void gemm_glds_kernel(const GemmArgs p) {
   }
 }
 
-// ---- fused epilogue on 4 consecutive columns of one row: the same element-wise pipeline as epilogue8 (bias ->
-//      rounded pre-activation [+ aux store] -> GeLU | dGeLU -> dropout -> + C -> round -> abs-max), 8-byte accesses.
-//      Dropout bits follow the 8-element group convention of common.cuh: this quad is half (n >> 2) & 1 of its group.
-template <typename T>
-__device__ __forceinline__ float epilogue4(const GemmArgs& p, int m, int n, float (&v)[4]) {
-  if (p.flags & COGV_EPI_BIAS) {
-    const u32x2 bv = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.bias) + n);
+// ---- epilogue of the generation-3 kernel for one wave's 128x64 sub-tile (16x16 accumulator blocks, lane = row
+//      l & 15, 4 columns at 4 (l >> 4)): transpose 8 rows at a time through the wave's private 2-KiB LDS strip into
+//      "8 lanes x 16 bytes = one 128-byte line per row" order, then epilogue8.  F: compile-time flag mask
+//      (-1: runtime flags / fp32 output, -2: split-K partial slab).
+template <typename T, int F>
+__device__ __forceinline__ void pp64_epilogue(const GemmArgs& p, f32x4 (&acc)[8][4], float* strip, int m_base, int n_base,
+                                              int ksplit, int lane, float& amax, bool& nan) {
+  const int l15 = lane & 15, kb = lane >> 4;
+  const int sr = lane >> 3, sc = lane & 7;           // read side: strip row, 8-column group
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      v[2 * i] += bits_to_f<T>((uint16_t)(bv[i] & 0xffffu));
-      v[2 * i + 1] += bits_to_f<T>((uint16_t)(bv[i] >> 16));
-    }
-  }
-  if (p.flags & COGV_EPI_GELU) {
-    u32x2 rv; rv[0] = pack2<T>(v[0], v[1]); rv[1] = pack2<T>(v[2], v[3]);
-    if (p.aux) *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n) = rv;
+  for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      v[2 * i] = gelu_f(bits_to_f<T>((uint16_t)(rv[i] & 0xffffu)));
-      v[2 * i + 1] = gelu_f(bits_to_f<T>((uint16_t)(rv[i] >> 16)));
-    }
-  }
-  if (p.flags & COGV_EPI_DGELU) {
-    const u32x2 uv = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
+    for (int hh = 0; hh < 2; ++hh) {
+      if ((l15 >> 3) == hh) {
+        const int r = l15 & 7;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      v[2 * i] *= gelu_grad_f(bits_to_f<T>((uint16_t)(uv[i] & 0xffffu)));
-      v[2 * i + 1] *= gelu_grad_f(bits_to_f<T>((uint16_t)(uv[i] >> 16)));
-    }
-  }
-  if ((p.flags & COGV_EPI_DROPOUT) && p.thr16) {
-    const uint64_t e = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;   // n % 4 == 0
-    const u32x4 r = Philox::gen(p.seed, p.stream_id, e >> 3);
-    const int h4 = (n >> 2) & 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (drop_bits16(r, 4 * h4 + i) >= p.thr16) ? v[i] * p.keep_scale : 0.f;
-  }
-  if (p.flags & COGV_EPI_ACCUM) {
-    if (p.out_f32) {
-      const f32x4 c = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + (size_t)m * p.ldc + n);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += c[i];
-    } else {
-      const u32x2 cv = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        v[2 * i] += bits_to_f<T>((uint16_t)(cv[i] & 0xffffu));
-        v[2 * i + 1] += bits_to_f<T>((uint16_t)(cv[i] >> 16));
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(strip + r * 64 + (((4 * j + kb) ^ r) << 2)) = acc[i][j];
+      }
+      __builtin_amdgcn_wave_barrier();
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc) ^ sr) << 2));
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc + 1) ^ sr) << 2));
+      __builtin_amdgcn_wave_barrier();
+      int m = m_base + 16 * i + 8 * hh + sr;
+      const int n = n_base + 8 * sc;
+      if ((COGV_EXP & 64) && x0[0] != 12345.f) continue;      // probe: no epilogue
+      if (COGV_EXP & 128) m &= 255;                           // probe: all tiles store to the same L2-resident rows
+      if (m < p.M && n < p.N) {
+        if (F == -2) {                                        // split-K partial: raw fp32 slab
+          float* w = p.ws + ((size_t)ksplit * p.M + m) * p.N + n;
+          *reinterpret_cast<f32x4*>(w) = x0;
+          *reinterpret_cast<f32x4*>(w + 4) = x1;
+        } else {
+          float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          const float a = epilogue8<T, (F < 0 ? -1 : F)>(p, m, n, v);
+          if (a != a) nan = true; else amax = fmaxf(amax, a);
+        }
       }
     }
   }
-  float amax = 0.f;
-  if (p.out_f32) {
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf(v[i]));
-  } else {
-    u32x2 o; o[0] = pack2<T>(v[0], v[1]); o[1] = pack2<T>(v[2], v[3]);
-    *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = o;
-    if (p.flags & COGV_EPI_ABSMAX) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float r0 = bits_to_f<T>((uint16_t)(o[i] & 0xffffu)), r1 = bits_to_f<T>((uint16_t)(o[i] >> 16));
-        amax = fmaxf(amax, fmaxf(fabsf(r0), fabsf(r1)));          // NaN-ignoring max
-        if (r0 != r0) amax = r0;
-        if (r1 != r1) amax = r1;
-      }
-    }
-  }
-  return amax;
 }
 
 // =====================================================================================================
@@ -1169,38 +1145,19 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     //      measured 4x slower than this: 16 us per tile.)  16-byte chunk c of strip row r sits at chunk c ^ r.
     float amax = 0.f; bool nan = false;
     float* strip = reinterpret_cast<float*>(smem + BUF + A23_OFF + wave * 2048);
-    const int sr = lane >> 3, sc = lane & 7;           // read side: strip row, 8-column group
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        if ((l15 >> 3) == hh) {
-          const int r = l15 & 7;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<f32x4*>(strip + r * 64 + (((4 * j + kb) ^ r) << 2)) = acc[i][j];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc) ^ sr) << 2));
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc + 1) ^ sr) << 2));
-        __builtin_amdgcn_wave_barrier();
-        int m = done.m0 + wm + 16 * i + 8 * hh + sr;
-        const int n = done.n0 + wn + 8 * sc;
-        if ((COGV_EXP & 64) && x0[0] != 12345.f) continue;      // probe: no epilogue
-        if (COGV_EXP & 128) m &= 255;                           // probe: all tiles store to the same L2-resident rows
-        if (m < p.M && n < p.N) {
-          if (p.splitk > 1) {
-            float* w = p.ws + ((size_t)done.ksplit * p.M + m) * p.N + n;
-            *reinterpret_cast<f32x4*>(w) = x0;
-            *reinterpret_cast<f32x4*>(w + 4) = x1;
-          } else {
-            float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-            const float a = epilogue8<T>(p, m, n, v);
-            if (a != a) nan = true; else amax = fmaxf(amax, a);
-          }
-        }
-      }
-    }
+    // One instance per hot flag combination (compile-time mask): the passes below are fully unrolled (the
+    // accumulators need static register indices), so a single runtime-flag body is ~100 KB of code per kernel
+    // and every item would stream it through the instruction cache.
+    constexpr int F_FWD_DROP = COGV_EPI_BIAS | COGV_EPI_DROPOUT | COGV_EPI_ABSMAX, F_FWD_GELU = COGV_EPI_BIAS | COGV_EPI_GELU;
+    if (p.splitk > 1) pp64_epilogue<T, -2>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
+    else if (p.out_f32) pp64_epilogue<T, -1>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
+    else if (p.flags == 0) pp64_epilogue<T, 0>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
+    else if (p.flags == COGV_EPI_BIAS) pp64_epilogue<T, COGV_EPI_BIAS>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
+    else if (p.flags == COGV_EPI_ACCUM) pp64_epilogue<T, COGV_EPI_ACCUM>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
+    else if (p.flags == F_FWD_DROP) pp64_epilogue<T, F_FWD_DROP>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
+    else if (p.flags == F_FWD_GELU) pp64_epilogue<T, F_FWD_GELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
+    else if (p.flags == COGV_EPI_DGELU) pp64_epilogue<T, COGV_EPI_DGELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
+    else pp64_epilogue<T, -1>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
     if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
       float wmx = wave_max(amax);
       const bool wnan = __any(nan);
