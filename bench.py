@@ -223,6 +223,9 @@ def main():
                            "launches": gemm_stats["launches"], "avg_launch_ms": gemm_stats["avg_ms"],
                            "share_of_step_time": gemm_stats["total_ms"] / (elapsed * 1e3),
                            "by_variant_tflops": gemm_stats["by_variant"]}
+        log("[bench] GEMM launches by shape (TFLOP/s, launches, avg ms):")
+        for k, v in gemm_stats["by_shape"].items():
+            log(f"    {k:44s} {v['tflops']:8.1f} {v['launches']:6d} {v['avg_ms']:9.4f}")
     if gemm_stats is not None:
         # HBM-side traffic of the dominant kernel: measured off-line with rocprofv3 PMC passes (tools/collect_traffic.sh,
         # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read correction) for the DEFAULT workload only.

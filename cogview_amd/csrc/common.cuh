@@ -180,17 +180,27 @@ __device__ __forceinline__ uint32_t drop_bits16(const u32x4& r, int j) {
 }
 
 // ---------------------------------------------------------------- misc
+// OpenAI tanh approximation, reference mpu/sparse_transformer.py:172-176:
+//     gelu(x) = 0.5 x (1 + tanh(u)),  u = 0.79788456 x (1 + 0.044715 x^2)
+// evaluated through the identity 0.5 (1 + tanh(u)) = sigmoid(2u) = 1 / (1 + 2^(-2 u log2 e)): one v_exp_f32 and one
+// v_rcp_f32 (1 ulp each) instead of libm's tanhf (~40 instructions); absolute error < 2e-7 |x|, far below the
+// 16-bit output rounding.  Saturates correctly (exp2 -> inf => 0, exp2 -> 0 => x).  These run inside the GEMM
+// epilogues of the h -> 4h layer, where 128 evaluations per lane per tile are not hidden behind MFMA work.
+__device__ __forceinline__ float gelu_sigmoid_f(float x, float x2) {
+  constexpr float K0 = -2.0f * 1.4426950408889634f * 0.7978845608028654f;      // -2 log2(e) sqrt(2/pi)
+  constexpr float K1 = K0 * 0.044715f;
+  const float e = __builtin_amdgcn_exp2f(x * fmaf(K1, x2, K0));
+  return __builtin_amdgcn_rcpf(1.0f + e);
+}
 __device__ __forceinline__ float gelu_f(float x) {
-  // OpenAI tanh approximation, reference mpu/sparse_transformer.py:172-176
-  const float u = 0.7978845608028654f * x * (1.0f + 0.044715f * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  return x * gelu_sigmoid_f(x, x * x);
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
+  // d/dx [x s(x)] = s + x s (1 - s) * 2 u'(x),   2 u' = 2 sqrt(2/pi) (1 + 3 * 0.044715 x^2)
   const float x2 = x * x;
-  const float u = 0.7978845608028654f * x * (1.0f + 0.044715f * x2);
-  const float t = tanhf(u);
-  const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x2);
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+  const float s = gelu_sigmoid_f(x, x2);
+  constexpr float C0 = 2.0f * 0.7978845608028654f, C1 = C0 * 3.0f * 0.044715f;
+  return fmaf(x * fmaf(-s, s, s), fmaf(C1, x2, C0), s);
 }
 
 static inline int cogv_check_launch() {

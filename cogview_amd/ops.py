@@ -88,8 +88,9 @@ def collect_gemm_timing():
     global _GEMM_TIMING
     rec, _GEMM_TIMING = _GEMM_TIMING, None
     torch.cuda.synchronize()
-    tot_ms, tot_fl, tot_by, by = 0.0, 0.0, 0.0, {}
-    for variant, fl, nbytes, s, e in rec:
+    tot_ms, tot_fl, tot_by, by, shapes = 0.0, 0.0, 0.0, {}, {}
+    for rec_i in rec:
+        variant, fl, nbytes, s, e = rec_i[:5]
         ms = s.elapsed_time(e)
         tot_ms += ms
         tot_fl += fl
@@ -98,11 +99,18 @@ def collect_gemm_timing():
         a[0] += fl
         a[1] += ms
         a[2] += 1
+        if len(rec_i) > 5:
+            a = shapes.setdefault(f"{variant} {rec_i[5]}", [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += ms
+            a[2] += 1
     n = max(len(rec), 1)
     return {"launches": len(rec), "total_ms": tot_ms, "avg_ms": tot_ms / n, "algo_bytes": tot_by,
             "tflops": tot_fl / max(tot_ms, 1e-9) / 1e9,
             "by_variant": {k: {"tflops": v[0] / max(v[1], 1e-9) / 1e9, "launches": v[2], "avg_ms": v[1] / v[2]}
-                           for k, v in by.items()}}
+                           for k, v in by.items()},
+            "by_shape": {k: {"tflops": round(v[0] / max(v[1], 1e-9) / 1e9, 1), "launches": v[2], "avg_ms": round(v[1] / v[2], 4)}
+                         for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}}
 
 
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, gelu_aux=None, dgelu_aux=None,
@@ -169,7 +177,7 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
         ev1.record()
         variant = ("T" if trans_a else "N") + ("T" if trans_b else "N")
         _GEMM_TIMING.append(({"NN": "NT_fwd", "NT": "NN_dgrad", "TT": "TN_wgrad", "TN": "TN_other"}[variant],
-                             2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev0, ev1))
+                             2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev0, ev1, f"{M}x{N}x{K} epi={flags}"))
     else:
         L.check(lib.cogv_gemm(C.byref(d), _stream()), "cogv_gemm")
     return out
@@ -225,7 +233,7 @@ def gemm_grouped(problems, trans_a=True, trans_b=True, accumulate=True):
         L.check(lib.cogv_gemm_grouped(descs, len(problems), _stream()), "cogv_gemm_grouped")
         ev1.record()
         key = {(False, False): "NT_fwd", (False, True): "NN_dgrad", (True, True): "TN_wgrad"}.get((trans_a, trans_b), "TN_other")
-        _GEMM_TIMING.append((key, flops, nbytes, ev0, ev1))
+        _GEMM_TIMING.append((key, flops, nbytes, ev0, ev1, "grouped " + "+".join(f"{M}x{N}" for M, N, _ in shapes) + f" K={kmin}"))
     else:
         L.check(lib.cogv_gemm_grouped(descs, len(problems), _stream()), "cogv_gemm_grouped")
 
