@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COGVIEW_HIP_LIB") or os.path.join(_HERE, "lib", "libcogview_hip.so")
 
 F16, BF16, F32 = 0, 1, 2
-EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_DROPOUT, EPI_ABSMAX, EPI_ACCUM = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_DROPOUT, EPI_ABSMAX, EPI_ACCUM, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
 
 _ERR = {1: "bad argument (shape / alignment / dtype)", 2: "kernel launch failure", 3: "unsupported combination"}
 
@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("dropout_p", C.c_float), ("seed", C.c_uint64), ("stream_id", C.c_uint64),
         ("splitk", C.c_int), ("kernel_variant", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("colsum_partial", C.c_void_p),
     ]
 
 
@@ -86,6 +87,8 @@ SIGNATURES = {
     "cogv_gemm_workspace_bytes": (_sz, [C.POINTER(GemmDesc)]),
     "cogv_gemm_pick_splitk": (_i, [_i, _i, _i]),
     "cogv_gemm_grouped": (_i, [C.POINTER(GemmDesc), _i, _vp]),
+    "cogv_gemm_colsum_rows": (_i, [_i]),
+    "cogv_colsum_finalize": (_i, [_i, _vp, _i, _i, _vp, _i, _vp]),
     "cogv_gemm_pick_splitk_tiles": (_i, [_i, _i]),
     "cogv_sandwich_ln_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "cogv_sandwich_ln_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64,

@@ -325,6 +325,15 @@ extern "C" int cogv_absmax(int dtype, const void* x, size_t n, float* out, void*
   return cogv_check_launch();
 }
 
+extern "C" int cogv_colsum_finalize(int dtype, const float* partial, int rows, int N, void* out, int accumulate, void* stream) {
+  if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
+  if (!partial || !out || rows <= 0 || N <= 0) return COGV_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == COGV_F16) hipLaunchKernelGGL((colsum_final_kernel<f16_t>), dim3((N + 255) / 256), dim3(256), 0, st, partial, rows, N, out, accumulate);
+  else hipLaunchKernelGGL((colsum_final_kernel<bf16_t>), dim3((N + 255) / 256), dim3(256), 0, st, partial, rows, N, out, accumulate);
+  return cogv_check_launch();
+}
+
 extern "C" size_t cogv_colsum_workspace_bytes(int M, int N) {
   int nslab = (M + 255) / 256; if (nslab > 64) nslab = 64; if (nslab < 1) nslab = 1;
   return (size_t)nslab * (size_t)N * sizeof(float);

@@ -42,6 +42,7 @@ struct GemmArgs {
   uint64_t seed, stream_id;
   uint32_t thr16;       // dropout threshold (0 => keep all)
   float keep_scale;
+  float* colsum_ws;     // COGV_EPI_COLSUM partial sums [2 * tiles_m(256)][N] fp32
   float* ws;            // split-K slabs [S][M][N] fp32
   int splitk;
   int ktiles_per_split;
@@ -128,11 +129,14 @@ __device__ __forceinline__ typename HT<T>::v8 read_frag(const char* lds, int row
 //      F >= 0: the flag mask is a compile-time constant and the output is 16-bit (the generation-3 kernel dispatches
 //      the hot combinations to such instances so that one item's epilogue is a few KB of code, not all paths).
 template <typename T, int F = -1>
-__device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, float (&v)[8]) {
+//      bias_pre / aux_pre / c_pre: values the caller already loaded (the generation-3 epilogue issues all of a
+//      sub-tile's dGeLU / accumulate reads up front instead of one exposed global-load latency per pass).
+__device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, float (&v)[8], const u32x4* bias_pre = nullptr,
+                                           const u32x4* aux_pre = nullptr, const u32x4* c_pre = nullptr, float* rounded = nullptr) {
   const int flags = F >= 0 ? F : p.flags;
   const bool out_f32 = F >= 0 ? false : (p.out_f32 != 0);
   if (flags & COGV_EPI_BIAS) {
-    u32x4 bv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
+    u32x4 bv = bias_pre ? *bias_pre : *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
     float b[8]; unpack8<T>(bv, b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += b[i];
@@ -147,7 +151,7 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, floa
     for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
   }
   if (flags & COGV_EPI_DGELU) {
-    u32x4 uv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
+    u32x4 uv = aux_pre ? *aux_pre : *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
     float u[8]; unpack8<T>(uv, u);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(u[i]);
@@ -164,7 +168,7 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, floa
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += c[i];
     } else {
-      u32x4 cv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n);
+      u32x4 cv = c_pre ? *c_pre : *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n);
       float c[8]; unpack8<T>(cv, c);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += c[i];
@@ -180,6 +184,7 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, floa
   } else {
     u32x4 o = pack8<T>(v);
     *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = o;
+    if (rounded) unpack8<T>(o, rounded);
     if (flags & COGV_EPI_ABSMAX) {
       float r[8]; unpack8<T>(o, r);
 #pragma unroll
@@ -813,9 +818,28 @@ void gemm_glds_kernel(const GemmArgs p) {
 //      (-1: runtime flags / fp32 output, -2: split-K partial slab).
 template <typename T, int F>
 __device__ __forceinline__ void pp64_epilogue(const GemmArgs& p, f32x4 (&acc)[8][4], float* strip, int m_base, int n_base,
-                                              int ksplit, int lane, float& amax, bool& nan) {
+                                              int ksplit, int lane, float& amax, bool& nan, int colsum_row) {
   const int l15 = lane & 15, kb = lane >> 4;
+  const bool want_cs = (F == -1) ? ((p.flags & COGV_EPI_COLSUM) != 0 && !p.out_f32) : (F >= 0 && (F & COGV_EPI_COLSUM));
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int sr = lane >> 3, sc = lane & 7;           // read side: strip row, 8-column group
+  // operands of the element-wise pipeline that live in global memory: bias once (the column group of a lane is
+  // the same in every pass), the dGeLU pre-activations / the accumulate target for all 16 passes up front
+  constexpr bool PRE_BIAS = F >= 0 && (F & COGV_EPI_BIAS), PRE_AUX = F >= 0 && (F & COGV_EPI_DGELU), PRE_C = F >= 0 && (F & COGV_EPI_ACCUM);
+  u32x4 bias_v = {0u, 0u, 0u, 0u}, aux_v[PRE_AUX ? 16 : 1], c_v[PRE_C ? 16 : 1];
+  {
+    const int n = n_base + 8 * sc;
+    if (PRE_BIAS && n < p.N) bias_v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
+    if (PRE_AUX || PRE_C) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int m = m_base + 8 * t + sr;
+        const bool ok = m < p.M && n < p.N;
+        if (PRE_AUX) aux_v[t] = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n) : u32x4{0u, 0u, 0u, 0u};
+        if (PRE_C) c_v[t] = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -841,10 +865,31 @@ __device__ __forceinline__ void pp64_epilogue(const GemmArgs& p, f32x4 (&acc)[8]
           *reinterpret_cast<f32x4*>(w + 4) = x1;
         } else {
           float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-          const float a = epilogue8<T, (F < 0 ? -1 : F)>(p, m, n, v);
+          float rv[8];
+          const float a = epilogue8<T, (F < 0 ? -1 : F)>(p, m, n, v, PRE_BIAS ? &bias_v : nullptr,
+                                                         PRE_AUX ? &aux_v[2 * i + hh] : nullptr, PRE_C ? &c_v[2 * i + hh] : nullptr,
+                                                         want_cs ? rv : nullptr);
           if (a != a) nan = true; else amax = fmaxf(amax, a);
+          if (want_cs) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] += rv[e];
+          }
         }
       }
+    }
+  }
+  if (want_cs) {     // lanes with the same (lane & 7) hold the same 8 columns: fold the 8 strip rows, lanes 0..7 write
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = cs[e];
+      t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+      cs[e] = t;
+    }
+    const int n = n_base + 8 * sc;
+    if (sr == 0 && n < p.N) {
+      float* w = p.colsum_ws + (size_t)colsum_row * p.N + n;
+      *reinterpret_cast<f32x4*>(w) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+      *reinterpret_cast<f32x4*>(w + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
     }
   }
 }
@@ -1149,15 +1194,16 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     // accumulators need static register indices), so a single runtime-flag body is ~100 KB of code per kernel
     // and every item would stream it through the instruction cache.
     constexpr int F_FWD_DROP = COGV_EPI_BIAS | COGV_EPI_DROPOUT | COGV_EPI_ABSMAX, F_FWD_GELU = COGV_EPI_BIAS | COGV_EPI_GELU;
-    if (p.splitk > 1) pp64_epilogue<T, -2>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
-    else if (p.out_f32) pp64_epilogue<T, -1>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
-    else if (p.flags == 0) pp64_epilogue<T, 0>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
-    else if (p.flags == COGV_EPI_BIAS) pp64_epilogue<T, COGV_EPI_BIAS>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
-    else if (p.flags == COGV_EPI_ACCUM) pp64_epilogue<T, COGV_EPI_ACCUM>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
-    else if (p.flags == F_FWD_DROP) pp64_epilogue<T, F_FWD_DROP>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
-    else if (p.flags == F_FWD_GELU) pp64_epilogue<T, F_FWD_GELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
-    else if (p.flags == COGV_EPI_DGELU) pp64_epilogue<T, COGV_EPI_DGELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
-    else pp64_epilogue<T, -1>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan);
+    if (p.splitk > 1) pp64_epilogue<T, -2>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
+    else if (p.out_f32) pp64_epilogue<T, -1>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
+    else if (p.flags == 0) pp64_epilogue<T, 0>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
+    else if (p.flags == COGV_EPI_BIAS) pp64_epilogue<T, COGV_EPI_BIAS>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
+    else if (p.flags == COGV_EPI_ACCUM) pp64_epilogue<T, COGV_EPI_ACCUM>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
+    else if (p.flags == F_FWD_DROP) pp64_epilogue<T, F_FWD_DROP>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
+    else if (p.flags == F_FWD_GELU) pp64_epilogue<T, F_FWD_GELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
+    else if (p.flags == (COGV_EPI_DGELU | COGV_EPI_COLSUM)) pp64_epilogue<T, COGV_EPI_DGELU | COGV_EPI_COLSUM>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
+    else if (p.flags == COGV_EPI_DGELU) pp64_epilogue<T, COGV_EPI_DGELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
+    else pp64_epilogue<T, -1>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
     if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
       float wmx = wave_max(amax);
       const bool wnan = __any(nan);
@@ -1267,6 +1313,7 @@ template <typename T>
 int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
   const bool glds_ok = (a.K % BK) == 0 && a.M >= 64 && a.N >= 64 && (!d->trans_a || (a.M & 7) == 0) &&
                        (!d->trans_b || (a.N & 7) == 0) && d->kernel_variant != 1;
+  if ((d->flags & COGV_EPI_COLSUM) && !glds_ok) return COGV_ERR_UNSUPPORTED;
   if (glds_ok) {
     // variant 2: 256x128x64, 8 waves (64x64 each), one workgroup per CU   -- best for long-K NT (measured)
     // variant 3: 256x128x32, 4 waves (128x64 each), two workgroups per CU -- default: the two workgroups' barrier
@@ -1278,6 +1325,8 @@ int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
     int variant = d->kernel_variant;
     const size_t a_span = (size_t)(d->trans_a ? a.K : a.M) * a.lda * 2, b_span = (size_t)(d->trans_b ? a.K : a.N) * a.ldb * 2;
     const bool v9_ok = a.M >= 256 && a.N >= 256 && a_span < (1ull << 32) && b_span < (1ull << 32);   // 32-bit DMA offsets
+    if ((d->flags & COGV_EPI_COLSUM) && (!v9_ok || (variant != 0 && variant != 9))) return COGV_ERR_UNSUPPORTED;
+    if (d->flags & COGV_EPI_COLSUM) variant = 9;
     if (variant == 9 && !v9_ok) variant = 0;
     if (variant == 0) {
       variant = 3;
@@ -1342,6 +1391,8 @@ extern "C" size_t cogv_gemm_workspace_bytes(const cogv_gemm_desc* d) {
 
 // Heuristic used by the host side: split the contraction when the output has too few tiles to fill 256 CUs
 // (weight-gradient GEMMs of the 336M config: 64..256 tiles, contraction = b*1088 tokens).
+extern "C" int cogv_gemm_colsum_rows(int M) { return 2 * ((M + 255) / 256); }
+
 extern "C" int cogv_gemm_pick_splitk(int M, int N, int K) {
   // 256x256 tiles on one persistent workgroup per CU.  Pick the split that fills whole rounds best; every split
   // costs an fp32 slab write + read (8 M N bytes at ~4 TB/s) against 2 M N K flops at ~1.1 PFLOP/s: 1100 / K each.
@@ -1396,6 +1447,8 @@ static int build_gemm_args(const cogv_gemm_desc* d, GemmArgs& a) {
   if (a.splitk > nk) a.splitk = nk;
   a.ktiles_per_split = (nk + a.splitk - 1) / a.splitk;
   a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;   // no empty splits
+  a.colsum_ws = d->colsum_partial;
+  if ((d->flags & COGV_EPI_COLSUM) && (!d->colsum_partial || ((uintptr_t)d->colsum_partial & 15) || d->splitk > 1 || d->out_f32)) return COGV_ERR_ARG;
   a.ws = reinterpret_cast<float*>(d->workspace);
   if (a.splitk > 1) {
     if (!a.ws || d->workspace_bytes < (size_t)a.splitk * a.M * a.N * sizeof(float)) return COGV_ERR_ARG;

@@ -411,11 +411,10 @@ def _layer_backward(layer, kp, dout, sep):
     # The four weight gradients dW = dY^T X are deferred to ONE grouped launch at the end of the layer: together
     # their 256x256 tiles fill whole rounds of the 256 CUs (each alone needs split-K slabs or idles half a round).
     wgrads = []
-    du = ops.gemm(d_mo, W2, trans_b=True, dgelu_aux=kp.u)                       # dgrad fused with dGeLU
+    du = ops.gemm(d_mo, W2, trans_b=True, dgelu_aux=kp.u, colsum_out=G(b1))     # dgrad fused with dGeLU + bias grad of h->4h
     wgrads.append((d_mo, kp.g, G(W2)))
     dc = _mp_allreduce(ops.gemm(du, W1, trans_b=True))
     wgrads.append((du, kp.c.view(rows, h), G(W1)))
-    ops.colsum(du, out=G(b1), accumulate=True)
     # y feeds LN2 and the second residual:  dy = dout + LN2'(dc)
     dy = ops.sandwich_ln_bwd(dc.view(b, s, h), kp.y, ln2.weight, *kp.st2, add_in=dout, dgamma=G(ln2.weight),
                              dbeta=G(ln2.bias), accumulate=True)

@@ -114,10 +114,12 @@ def collect_gemm_timing():
 
 
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, gelu_aux=None, dgelu_aux=None,
-         dropout=None, absmax=None, accumulate=False, splitk=None, out_dtype=None, variant=0):
+         dropout=None, absmax=None, accumulate=False, splitk=None, out_dtype=None, variant=0, colsum_out=None,
+         colsum_accumulate=True):
     """C[M,N] = epilogue(A_op[M,K] . B_op[N,K]^T); a, b 2-D, last dim contiguous.
     trans_a: `a` is stored [K, M];  trans_b: `b` is stored [K, N].
-    dropout = (p, seed, stream_id).  Returns C."""
+    dropout = (p, seed, stream_id).  colsum_out [N]: (+)= column sums of C (the bias gradient of the layer whose
+    output gradient C is), fused into the epilogue when the shape allows, otherwise a separate pass.  Returns C."""
     _need_gpu(a, b)
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     if trans_a:
@@ -160,8 +162,17 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
         d.absmax = absmax.data_ptr()
     if accumulate:
         flags |= L.EPI_ACCUM
-    d.flags = flags
     lib = L.lib()
+    fuse_colsum = (colsum_out is not None and M >= 256 and N >= 256 and K % 64 == 0 and variant in (0, 9)
+                   and out.dtype != torch.float32 and a.stride(0) * a.shape[0] * 2 < 2 ** 32
+                   and b.stride(0) * b.shape[0] * 2 < 2 ** 32 and (trans_b is False or N % 8 == 0) and not trans_a)
+    if fuse_colsum:
+        flags |= L.EPI_COLSUM
+        cs_rows = lib.cogv_gemm_colsum_rows(M)
+        cs_ws = workspace("gemm_colsum", cs_rows * N * 4, a.device)
+        d.colsum_partial = cs_ws.data_ptr()
+        splitk = 1
+    d.flags = flags
     if splitk is None:
         splitk = lib.cogv_gemm_pick_splitk(M, N, K)
     d.splitk = int(splitk)
@@ -180,6 +191,12 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
                              2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), ev0, ev1, f"{M}x{N}x{K} epi={flags}"))
     else:
         L.check(lib.cogv_gemm(C.byref(d), _stream()), "cogv_gemm")
+    if colsum_out is not None:
+        if fuse_colsum:
+            L.check(lib.cogv_colsum_finalize(dt_code(out), d.colsum_partial, cs_rows, N, _p(colsum_out), int(colsum_accumulate),
+                                             _stream()), "cogv_colsum_finalize")
+        else:
+            colsum(out, out=colsum_out, accumulate=colsum_accumulate)
     return out
 
 

@@ -55,6 +55,9 @@ const char* cogv_arch(void);            /* "gfx950" */
 #define COGV_EPI_DROPOUT 8  /* out = dropout(out), element index m*N+n                                */
 #define COGV_EPI_ABSMAX 16  /* atomicMax(*absmax, max|out|) -- feeds the Sandwich-LN scale            */
 #define COGV_EPI_ACCUM 32   /* out += C (gradient accumulation / tied embedding)                      */
+#define COGV_EPI_COLSUM 64  /* column sums of the (rounded) output per 128-row slab -> colsum_partial:      *
+                             * the bias gradient of the layer that produced the GEMM's A operand, without  *
+                             * re-reading the output (generation-3 kernel only: M, N >= 256, K % 64 == 0)  */
 
 typedef struct cogv_gemm_desc {
   int dtype;            /* COGV_F16 | COGV_BF16 : type of A, B, bias, aux and (unless out_f32) C */
@@ -72,11 +75,15 @@ typedef struct cogv_gemm_desc {
   int splitk;           /* >1: contraction split over this many workgroups + reduce pass */
   int kernel_variant;   /* 0 = auto; 1 = generation-1 (register-staged) kernel; 2/3/4 = DMA kernel 256x128x64 (8 waves) / 256x128x32 (4 fat waves, 2 WG/CU) / 128x128x32 (3 WG/CU) */
   void* workspace; size_t workspace_bytes;   /* >= cogv_gemm_workspace_bytes() when splitk > 1 */
+  float* colsum_partial;                     /* COGV_EPI_COLSUM: [cogv_gemm_colsum_rows(M)][N] fp32, fully written */
 } cogv_gemm_desc;
 
 int cogv_gemm(const cogv_gemm_desc* d, void* stream);
 size_t cogv_gemm_workspace_bytes(const cogv_gemm_desc* d);
 int cogv_gemm_pick_splitk(int M, int N, int K);
+int cogv_gemm_colsum_rows(int M);            /* slabs of COGV_EPI_COLSUM partial sums: 2 * ceil(M / 256) */
+/* out[n] (+)= sum over `rows` partial rows; the second half of cogv_colsum, also used after COGV_EPI_COLSUM */
+int cogv_colsum_finalize(int dtype, const float* partial, int rows, int N, void* out, int accumulate, void* stream);
 /* Up to 4 GEMMs of one dtype and layout (same trans_a / trans_b) in ONE persistent launch: the weight gradients
  * dW = dY^T X of the four linears of a layer (autograd of mpu/layers.py:243,319) fill the 256 CUs together where
  * each alone would leave a partial last round.  COGV_ERR_UNSUPPORTED when a problem does not fit the 256x256x64

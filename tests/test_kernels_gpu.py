@@ -114,6 +114,25 @@ def test_gemm_grouped_wgrads(ops, dtype, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1088, 1024, 256), (700, 512, 192), (300, 136, 72)])
+def test_gemm_fused_colsum(ops, dtype, M, N, K):
+    """COGV_EPI_COLSUM: the bias gradient (column sums of the rounded dgrad output) from the GEMM epilogue equals
+    the separate column-sum pass over the stored output; shapes the fused path does not take fall back to it."""
+    g = torch.Generator().manual_seed(N + K)
+    dy, w, u = rnd((M, K), dtype, g), rnd((K, N), dtype, g, 0.1), rnd((M, N), dtype, g)
+    prev = rnd((N,), dtype, g)
+    fused = dev(prev.clone())
+    out = ops.gemm(dev(dy), dev(w), trans_b=True, dgelu_aux=dev(u), colsum_out=fused)
+    ref_out = ops.gemm(dev(dy), dev(w), trans_b=True, dgelu_aux=dev(u))
+    assert torch.equal(out, ref_out)
+    sep = dev(prev.clone())
+    ops.colsum(ref_out, out=sep, accumulate=True)
+    expect = ref_out.float().sum(0).cpu() + prev.float()
+    assert rel(fused, expect) < TOL[dtype]
+    assert rel(fused, sep.float()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_gelu_dgelu_epilogues(ops, dtype):
     g = torch.Generator().manual_seed(3)
     M, N, K = 320, 512, 128
