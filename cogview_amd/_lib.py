@@ -49,6 +49,7 @@ class AttnDesc(C.Structure):
         ("do_bs", C.c_longlong), ("dq_bs", C.c_longlong), ("dk_bs", C.c_longlong), ("dv_bs", C.c_longlong),
         ("q_rs", C.c_int), ("k_rs", C.c_int), ("v_rs", C.c_int), ("o_rs", C.c_int),
         ("do_rs", C.c_int), ("dq_rs", C.c_int), ("dk_rs", C.c_int), ("dv_rs", C.c_int),
+        ("colsum_partial", C.c_void_p),
     ]
 
 

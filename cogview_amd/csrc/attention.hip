@@ -42,6 +42,7 @@ struct AttnArgs {
   const void* q; const void* k; const void* v; void* o;        // forward
   const void* dout; void* dq; void* dk; void* dv;              // backward
   float* lse; float* dvec;                                     // [b][H][s_q]
+  float* colsum_ws;                                            // optional [B * nblk][3 * H * 64]: sums of dq | dk | dv
   long long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs; // batch strides (elements)
   int q_rs, k_rs, v_rs, o_rs, do_rs, dq_rs, dk_rs, dv_rs;       // row strides (elements)
   int B, H, s_q, s_k, sep_k;   // sep_k: keys [0, sep_k) visible to every query
@@ -187,6 +188,37 @@ __device__ __forceinline__ void tr_frags_sync(uint32_t tile_addr, const uint32_t
         "=&v"(r[0][1].lo), "=&v"(r[0][1].hi), "=&v"(r[1][1].lo), "=&v"(r[1][1].hi)
       : "v"(a[0][0]), "v"(a[0][1]), "v"(a[0][2]), "v"(a[0][3]), "v"(a[1][0]), "v"(a[1][1]), "v"(a[1][2]), "v"(a[1][3])
       : "memory");
+}
+
+// Column sums of one workgroup's 128 rows x 64 head columns of a gradient that sits in the accumulators as
+// vals[d][e] <-> column 32 d + 8 (e >> 2) + 4 fg + (e & 3) of the lane's row (already rounded to the storage type,
+// zero for invalid rows).  Through LDS (the ring is free at the end of the kernels; needs 128 x 68 + 256 floats):
+// every lane stores its row (272-byte row pitch: conflict-free b128 stores), then thread t adds 32 rows of column
+// t & 63 and the four row slices are combined.  Deterministic.  (A butterfly of 160 dependent cross-lane shuffles
+// per wave cost 25 us per workgroup here.)
+__device__ __forceinline__ void tile_colsum(const float (&vals)[2][16], float* lds, float* dst, int lane, int wave) {
+  constexpr int PITCH = 68;
+  const int fr = lane & 31, fg = lane >> 5;
+  float* row = lds + (wave * 32 + fr) * PITCH;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+      *reinterpret_cast<f32x4*>(row + 32 * d + 8 * gq + 4 * fg) =
+          f32x4{vals[d][4 * gq], vals[d][4 * gq + 1], vals[d][4 * gq + 2], vals[d][4 * gq + 3]};
+  __syncthreads();
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 32; r += 2) {
+    s0 += lds[(slice * 32 + r) * PITCH + col];
+    s1 += lds[(slice * 32 + r + 1) * PITCH + col];
+  }
+  float* red = lds + 128 * PITCH;
+  red[slice * 64 + col] = s0 + s1;
+  __syncthreads();
+  if (threadIdx.x < 64) dst[threadIdx.x] = red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x];
+  __syncthreads();
 }
 
 // =====================================================================================================
@@ -470,7 +502,8 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     st = (st == 2) ? 0 : st + 1;
   }
   wait_vmcnt<0>();
-  if (qvalid) {
+  float rq[2][16];
+  {
     T* DQ = reinterpret_cast<T*>(p.dq) + b * p.dq_bs + (long long)myq * p.dq_rs + head * HD;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -479,8 +512,16 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
         u32x2 w;
         w[0] = pack2<T>(dqacc[d][4 * gq] * p.scale, dqacc[d][4 * gq + 1] * p.scale);
         w[1] = pack2<T>(dqacc[d][4 * gq + 2] * p.scale, dqacc[d][4 * gq + 3] * p.scale);
-        *reinterpret_cast<u32x2*>(DQ + d * 32 + 8 * gq + 4 * fg) = w;
+        if (qvalid) *reinterpret_cast<u32x2*>(DQ + d * 32 + 8 * gq + 4 * fg) = w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          rq[d][4 * gq + i] = qvalid ? bits_to_f<T>((uint16_t)(w[i >> 1] >> (16 * (i & 1)))) : 0.f;
       }
+  }
+  if (p.colsum_ws) {     // bias gradient of the QKV projection, q section
+    __syncthreads();     // every wave is done with the ring
+    float* dst = p.colsum_ws + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)(3 * p.H * HD) + head * HD;
+    tile_colsum(rq, reinterpret_cast<float*>(smem), dst, lane, wave);
   }
 }
 
@@ -639,21 +680,33 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
     st = (st == 2) ? 0 : st + 1;
   }
   wait_vmcnt<0>();
-  if (kvalid) {
+  float rk[2][16], rv[2][16];
+  {
     T* DK = reinterpret_cast<T*>(p.dk) + b * p.dk_bs + (long long)mykey * p.dk_rs + head * HD;
     T* DVp = reinterpret_cast<T*>(p.dv) + b * p.dv_bs + (long long)mykey * p.dv_rs + head * HD;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        u32x2 w;
+        u32x2 w, w2;
         w[0] = pack2<T>(dkacc[d][4 * gq] * p.scale, dkacc[d][4 * gq + 1] * p.scale);
         w[1] = pack2<T>(dkacc[d][4 * gq + 2] * p.scale, dkacc[d][4 * gq + 3] * p.scale);
-        *reinterpret_cast<u32x2*>(DK + d * 32 + 8 * gq + 4 * fg) = w;
-        w[0] = pack2<T>(dvacc[d][4 * gq], dvacc[d][4 * gq + 1]);
-        w[1] = pack2<T>(dvacc[d][4 * gq + 2], dvacc[d][4 * gq + 3]);
-        *reinterpret_cast<u32x2*>(DVp + d * 32 + 8 * gq + 4 * fg) = w;
+        if (kvalid) *reinterpret_cast<u32x2*>(DK + d * 32 + 8 * gq + 4 * fg) = w;
+        w2[0] = pack2<T>(dvacc[d][4 * gq], dvacc[d][4 * gq + 1]);
+        w2[1] = pack2<T>(dvacc[d][4 * gq + 2], dvacc[d][4 * gq + 3]);
+        if (kvalid) *reinterpret_cast<u32x2*>(DVp + d * 32 + 8 * gq + 4 * fg) = w2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          rk[d][4 * gq + i] = kvalid ? bits_to_f<T>((uint16_t)(w[i >> 1] >> (16 * (i & 1)))) : 0.f;
+          rv[d][4 * gq + i] = kvalid ? bits_to_f<T>((uint16_t)(w2[i >> 1] >> (16 * (i & 1)))) : 0.f;
+        }
       }
+  }
+  if (p.colsum_ws) {     // bias gradient of the QKV projection, k and v sections
+    __syncthreads();
+    float* dst = p.colsum_ws + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)(3 * p.H * HD) + (size_t)p.H * HD + head * HD;
+    tile_colsum(rk, reinterpret_cast<float*>(smem), dst, lane, wave);
+    tile_colsum(rv, reinterpret_cast<float*>(smem), dst + (size_t)p.H * HD, lane, wave);
   }
 }
 
@@ -666,7 +719,7 @@ int fill_args(const cogv_attn_desc* d, AttnArgs& a) {
   if (d->B <= 0 || d->H <= 0 || d->s_q <= 0 || d->s_k <= 0 || d->s_k < d->s_q) return COGV_ERR_ARG;
   if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return COGV_ERR_ARG;
   a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o; a.dout = d->dout; a.dq = d->dq; a.dk = d->dk; a.dv = d->dv;
-  a.lse = d->lse; a.dvec = d->dvec;
+  a.lse = d->lse; a.dvec = d->dvec; a.colsum_ws = nullptr;
   a.q_bs = d->q_bs; a.k_bs = d->k_bs; a.v_bs = d->v_bs; a.o_bs = d->o_bs; a.do_bs = d->do_bs;
   a.dq_bs = d->dq_bs; a.dk_bs = d->dk_bs; a.dv_bs = d->dv_bs;
   a.q_rs = d->q_rs; a.k_rs = d->k_rs; a.v_rs = d->v_rs; a.o_rs = d->o_rs; a.do_rs = d->do_rs;
@@ -709,6 +762,10 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   int rc = fill_args(d, a);
   if (rc) return rc;
   if (!a.q || !a.k || !a.v || !a.o || !a.dout || !a.dq || !a.dk || !a.dv || !a.lse || !a.dvec) return COGV_ERR_ARG;
+  if (d->colsum_partial) {
+    if (d->s_q != d->s_k || ((uintptr_t)d->colsum_partial & 15)) return COGV_ERR_ARG;
+    a.colsum_ws = d->colsum_partial;
+  }
   if (!aligned16(a.q) || !aligned16(a.k) || !aligned16(a.v) || !aligned16(a.o) || !aligned16(a.dout) ||
       !aligned16(a.dq) || !aligned16(a.dk) || !aligned16(a.dv)) return COGV_ERR_ARG;
   if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.do_rs | a.dq_rs | a.dk_rs | a.dv_rs) & 7) return COGV_ERR_ARG;

@@ -214,15 +214,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* dy, int
     if (gc < N) partial[(size_t)blockIdx.y * N + gc] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
   }
 }
+// out[c] (+)= sum_b partial[b][c]: 64 columns x 4 row slices per workgroup (a thread-per-column loop over
+// hundreds of partial rows took 75 us at N = 10240: only 40 workgroups, each a serial chain of dependent loads)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nslab, int N, void* out, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= N) return;
-  float s = 0.f;
-  for (int b = 0; b < nslab; ++b) s += partial[(size_t)b * N + c];
-  T* o = reinterpret_cast<T*>(out);
-  if (accumulate) s += HT<T>::to_f(o[c]);
-  o[c] = HT<T>::from_f(s);
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < N) {
+    int b = part;
+    for (; b + 4 < nslab; b += 8) { s0 += partial[(size_t)b * N + c]; s1 += partial[(size_t)(b + 4) * N + c]; }
+    if (b < nslab) s0 += partial[(size_t)b * N + c];
+  }
+  red[part][cl] = s0 + s1;
+  __syncthreads();
+  if (part == 0 && c < N) {
+    float s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    T* o = reinterpret_cast<T*>(out);
+    if (accumulate) s += HT<T>::to_f(o[c]);
+    o[c] = HT<T>::from_f(s);
+  }
 }
 
 template <typename T, int OP>
@@ -329,8 +341,8 @@ extern "C" int cogv_colsum_finalize(int dtype, const float* partial, int rows, i
   if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
   if (!partial || !out || rows <= 0 || N <= 0) return COGV_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == COGV_F16) hipLaunchKernelGGL((colsum_final_kernel<f16_t>), dim3((N + 255) / 256), dim3(256), 0, st, partial, rows, N, out, accumulate);
-  else hipLaunchKernelGGL((colsum_final_kernel<bf16_t>), dim3((N + 255) / 256), dim3(256), 0, st, partial, rows, N, out, accumulate);
+  if (dtype == COGV_F16) hipLaunchKernelGGL((colsum_final_kernel<f16_t>), dim3((N + 63) / 64), dim3(256), 0, st, partial, rows, N, out, accumulate);
+  else hipLaunchKernelGGL((colsum_final_kernel<bf16_t>), dim3((N + 63) / 64), dim3(256), 0, st, partial, rows, N, out, accumulate);
   return cogv_check_launch();
 }
 
@@ -352,10 +364,10 @@ extern "C" int cogv_colsum(int dtype, const void* dy, int M, int N, int ld, void
   float* part = reinterpret_cast<float*>(workspace);
   if (dtype == COGV_F16) {
     hipLaunchKernelGGL((colsum_partial_kernel<f16_t>), g1, dim3(256), 0, st, dy, M, N, ld, rows_per, part);
-    hipLaunchKernelGGL((colsum_final_kernel<f16_t>), dim3((N + 255) / 256), dim3(256), 0, st, part, nslab, N, out, accumulate);
+    hipLaunchKernelGGL((colsum_final_kernel<f16_t>), dim3((N + 63) / 64), dim3(256), 0, st, part, nslab, N, out, accumulate);
   } else {
     hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), g1, dim3(256), 0, st, dy, M, N, ld, rows_per, part);
-    hipLaunchKernelGGL((colsum_final_kernel<bf16_t>), dim3((N + 255) / 256), dim3(256), 0, st, part, nslab, N, out, accumulate);
+    hipLaunchKernelGGL((colsum_final_kernel<bf16_t>), dim3((N + 63) / 64), dim3(256), 0, st, part, nslab, N, out, accumulate);
   }
   return cogv_check_launch();
 }

@@ -430,11 +430,10 @@ def _layer_backward(layer, kp, dout, sep):
     dqkv = torch.empty_like(qkv)
     ops.attention_bwd(d_att, q, k, v, kp.att, kp.lse, sep=sep, dropout=kp.d_attn,
                       dq=dqkv[:, :, 0:hp].view(b, s, npp, 64), dk=dqkv[:, :, hp:2 * hp].view(b, s, npp, 64),
-                      dv=dqkv[:, :, 2 * hp:].view(b, s, npp, 64))
+                      dv=dqkv[:, :, 2 * hp:].view(b, s, npp, 64), colsum_out=G(bq))
     dqkv2 = dqkv.view(rows, 3 * hp)
     da = _mp_allreduce(ops.gemm(dqkv2, Wq, trans_b=True))
     wgrads.append((dqkv2, kp.a.view(rows, h), G(Wq)))
-    ops.colsum(dqkv2, out=G(bq), accumulate=True)
     dx = ops.sandwich_ln_bwd(da.view(b, s, h), kp.x, ln1.weight, *kp.st1, add_in=dy, dgamma=G(ln1.weight),
                              dbeta=G(ln1.bias), accumulate=True)
     ops.gemm_grouped(wgrads, trans_a=True, trans_b=True, accumulate=True)

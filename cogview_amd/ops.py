@@ -335,7 +335,10 @@ def attention_fwd(q, k, v, sep=0, dropout=None):
     return o, lse
 
 
-def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, dv=None):
+def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, dv=None, colsum_out=None,
+                  colsum_accumulate=True):
+    """colsum_out [3*H*64]: (+)= column sums of (dq | dk | dv) over all tokens -- the bias gradient of the fused
+    QKV projection -- taken from the kernels' accumulators instead of re-reading the three outputs."""
     _need_gpu(dout, q, k, v, o)
     b, s_q, H, _ = q.shape
     if dq is None:
@@ -352,7 +355,18 @@ def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, 
     d.dq_bs, d.dq_rs = _attn_strides(dq)
     d.dk_bs, d.dk_rs = _attn_strides(dk)
     d.dv_bs, d.dv_rs = _attn_strides(dv)
+    fuse = colsum_out is not None and k.shape[1] == s_q
+    if fuse:
+        rows = b * ((s_q + 127) // 128)
+        ws = workspace("attn_colsum", rows * 3 * H * 64 * 4, q.device)
+        d.colsum_partial = ws.data_ptr()
     L.check(L.lib().cogv_attention_bwd(C.byref(d), _stream()), "cogv_attention_bwd")
+    if fuse:
+        L.check(L.lib().cogv_colsum_finalize(dt_code(q), d.colsum_partial, rows, 3 * H * 64, _p(colsum_out),
+                                             int(colsum_accumulate), _stream()), "cogv_colsum_finalize")
+    elif colsum_out is not None:
+        for i, t in enumerate((dq, dk, dv)):
+            colsum(t.reshape(-1, H * 64), out=colsum_out[i * H * 64:(i + 1) * H * 64], accumulate=colsum_accumulate)
     return dq, dk, dv
 
 

@@ -124,6 +124,10 @@ typedef struct cogv_attn_desc {
   float* lse; float* dvec;
   long long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs;
   int q_rs, k_rs, v_rs, o_rs, do_rs, dq_rs, dk_rs, dv_rs;
+  /* backward only, optional: per-workgroup column sums of the stored dq | dk | dv (the bias gradient of the fused
+   * QKV projection, mpu/sparse_transformer.py:101-110) -> colsum_partial[B * ceil(s/128)][3 * H * 64] fp32, columns
+   * ordered [q heads | k heads | v heads]; requires s_q == s_k; finish with cogv_colsum_finalize. */
+  float* colsum_partial;
 } cogv_attn_desc;
 int cogv_attention_fwd(const cogv_attn_desc* d, void* stream);
 int cogv_attention_bwd(const cogv_attn_desc* d, void* stream);

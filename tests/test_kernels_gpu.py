@@ -414,3 +414,21 @@ def test_grad_stats_and_adamw(ops, dtype):
     ops.adamw_step(pd, dev(gbad), md, ed, vd, cs_t, cl_t, cg_t, [lr, lr], [wd, 0.0], 0.9, 0.999, 1e-8, 3,
                    inv_loss_scale=1.0 / scale, max_grad_norm=max_norm, stats=stats)
     assert torch.equal(before, md)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_bwd_fused_qkv_bias_grad(ops, dtype):
+    """colsum_out of cogv_attention_bwd == column sums of the stored dq | dk | dv (bias gradient of the QKV linear)."""
+    g = torch.Generator().manual_seed(5)
+    b, s, H = 2, 300, 3
+    qkv = dev(rnd((b, s, 3 * H * 64), dtype, g))
+    q, k, v = [qkv[:, :, i * H * 64:(i + 1) * H * 64].view(b, s, H, 64) for i in range(3)]
+    do = dev(rnd((b, s, H, 64), dtype, g))
+    o, lse = ops.attention_fwd(q, k, v, dropout=(0.1, 3, 4))
+    prev = rnd((3 * H * 64,), dtype, g)
+    fused = dev(prev.clone())
+    dq, dk, dv = ops.attention_bwd(do, q, k, v, o, lse, dropout=(0.1, 3, 4), colsum_out=fused)
+    dq2, dk2, dv2 = ops.attention_bwd(do, q, k, v, o, lse, dropout=(0.1, 3, 4))
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+    expect = torch.cat([t.float().reshape(-1, H * 64).sum(0) for t in (dq, dk, dv)]).cpu() + prev.float()
+    assert rel(fused, expect) < TOL[dtype]
