@@ -57,6 +57,7 @@ struct GroupArgs {
   GemmArgs g[MAX_GROUP];
   int item_start[MAX_GROUP + 1];     // prefix sums of tiles_m * tiles_n * splitk
   int count;
+  int* sched;                        // [0..7] per-XCD item counters, [8] finished workgroups: 0 at launch, re-armed by the last workgroup
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
@@ -1021,8 +1022,14 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     const char* g = reinterpret_cast<const char*>(p.B) + (size_t)(it.kt0 + kt) * kstride;
     char* l = smem + buf * BUF + B_OFF;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      if (COGV_EXP & 256) {        // probe: the same request stream into VGPRs (discarded) instead of LDS
+        u32x4 t; const char* a = g + it.offB[i];
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(a) : "memory");
+        continue;
+      }
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(g + it.offB[i]), (lds_void_t*)(l + (i * NW + wave) * 1024), 16, 0, 0);
+    }
   };
   auto issue_A = [&](const Item& it, int gi, int kt, int buf) {
     if (COGV_EXP & 1) return;
@@ -1032,8 +1039,14 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     const char* g = reinterpret_cast<const char*>(p.A) + (size_t)(it.kt0 + kt) * kstride;
     char* l = smem + buf * BUF + (gi ? A23_OFF : A01_OFF);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      if (COGV_EXP & 256) {
+        u32x4 t; const char* a = g + it.offA[gi][i];
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(a) : "memory");
+        continue;
+      }
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(g + it.offA[gi][i]), (lds_void_t*)(l + (i * NW + wave) * 1024), 16, 0, 0);
+    }
   };
   // tile 0 complete + B, A01 of tile 1: 14 DMA instructions per wave, in the order the k-loop certifies them
   auto prologue = [&](const Item& it) {
@@ -1055,10 +1068,18 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     adA[i] = AT ? tr_addr16<ROWB_A>(smem, wr * 64 + 16 * i, lane)
                 : (uint32_t)(uintptr_t)smem + (uint32_t)((wr * 64 + 16 * i + l15) * 128 + ((kb ^ swz(wr * 64 + 16 * i + l15)) << 4));
 
+  // Work distribution: the first item of a workgroup is its block index, every further one comes from an atomic
+  // counter.  A static stride would make the launch as slow as its unluckiest workgroup: this kernel needs a whole
+  // CU (512 threads x 256 registers), so when other kernels hold CUs -- RCCL's all-reduce channels during the
+  // data-parallel backward -- some workgroups start late, and with the queue they simply take fewer items.
+  // One queue per XCD (workgroup b runs on XCD b & 7): item i stays on XCD i & 7, which is what the tile order
+  // inside setup() assumes for L2 reuse (one shared queue measured 10-15 % slower).
+  __shared__ int s_next;
   Item cur;
-  if ((int)blockIdx.x < nitems) { setup(blockIdx.x, cur); prologue(cur); }
+  int item = blockIdx.x;
+  if (item < nitems) { setup(item, cur); prologue(cur); }
 #pragma unroll 1
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  while (item < nitems) {
     const GemmArgs& p = ga.g[cur.pi];
     const int nk = cur.nk;
     f32x4 acc[8][4];                   // 16x16 blocks of this wave's 128x64: acc[row block][column block]
@@ -1072,6 +1093,8 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     wait_vmcnt<8>();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();             // the stagger
+    int grabbed = 0;                                       // the item after this one: asked for now, used after the k-loop
+    if (threadIdx.x == 0) grabbed = atomicAdd(ga.sched + (blockIdx.x & 7), 1);
 
     TrRaw tb[KS][4], ta[KS][4];          // KS = 2 k-steps of 32 per k-tile
     u32x4 nb[KS][4], na[KS][4];
@@ -1179,8 +1202,14 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- next item's prologue goes out BEFORE this item's epilogue
+    if (threadIdx.x == 0) {      // j-th item of this XCD's list {x, x + 8, ...}: the first (gridDim.x - x + 7) / 8 were taken statically
+      const int x = blockIdx.x & 7;
+      s_next = x + 8 * (((int)gridDim.x - x + 7) / 8 + grabbed);
+    }
+    __syncthreads();
+    const int next = s_next;
     const Item done = cur;
-    if (item + (int)gridDim.x < nitems) { setup(item + gridDim.x, cur); prologue(cur); }
+    if (next < nitems) { setup(next, cur); prologue(cur); }
 
     // ---- epilogue.  The accumulators hold, per lane, 4 consecutive columns of row (l & 15) of each 16x16 block.
     //      Each wave transposes its own 128x64 sub-tile through a PRIVATE 2-KiB strip of LDS (8 rows x 64 fp32
@@ -1213,6 +1242,16 @@ void gemm_pp64_kernel(const GroupArgs ga) {
       // shader clock in MHz over this workgroup's lifetime so far (s_memrealtime ticks at 100 MHz)
       const uint64_t dt = __builtin_readcyclecounter() - exp_t0, dr = __builtin_amdgcn_s_memrealtime() - exp_r0;
       reinterpret_cast<float*>(p.C)[(size_t)done.m0 * p.ldc + done.n0] = 100.f * (float)dt / (float)dr;
+    }
+    item = next;
+  }
+  // the last workgroup to leave re-arms the queue for the next launch (every workgroup has made its last grab by then)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(ga.sched + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) ga.sched[t] = 0;
+      __threadfence();
     }
   }
 }
@@ -1275,9 +1314,29 @@ int num_cus() {
   return n;
 }
 
+// Work-queue counters of the persistent kernel: 64 zero-initialised slots of 16 ints per device (8 per-XCD item
+// counters + the finished-workgroup count), used round robin (a launch re-arms its slot when it finishes; launches
+// on one stream are ordered anyway).  The only device memory this library allocates itself: 4 KiB per GPU, on first use.
+int* sched_slot() {
+  constexpr int MAX_DEV = 16, SLOTS = 64;
+  static int* pool[MAX_DEV] = {};
+  static unsigned turn[MAX_DEV] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= MAX_DEV) return nullptr;
+  if (!pool[dev]) {
+    if (hipMalloc(reinterpret_cast<void**>(&pool[dev]), SLOTS * 16 * sizeof(int)) != hipSuccess) return nullptr;
+    (void)hipMemset(pool[dev], 0, SLOTS * 16 * sizeof(int));
+    (void)hipDeviceSynchronize();
+  }
+  return pool[dev] + 16 * (turn[dev]++ % SLOTS);
+}
+
 template <typename T, bool AT, bool BT>
-void launch_pp64(GroupArgs& ga, hipStream_t st) {
+int launch_pp64(GroupArgs& ga, hipStream_t st) {
   constexpr int shmem = 2 * 65536;
+  ga.sched = sched_slot();
+  if (!ga.sched) return COGV_ERR_LAUNCH;
   ga.item_start[0] = 0;
   for (int i = 0; i < ga.count; ++i) {
     GemmArgs& a = ga.g[i];
@@ -1294,13 +1353,14 @@ void launch_pp64(GroupArgs& ga, hipStream_t st) {
   const int num_cu = num_cus();
   const int items = ga.item_start[ga.count];
   hipLaunchKernelGGL((gemm_pp64_kernel<T, AT, BT>), dim3(items < num_cu ? items : num_cu), dim3(512), shmem, st, ga);
+  return COGV_OK;
 }
 template <typename T>
-void launch_pp64_layout(int trans_a, int trans_b, GroupArgs& ga, hipStream_t st) {
-  if (!trans_a && !trans_b) launch_pp64<T, false, false>(ga, st);
-  else if (!trans_a && trans_b) launch_pp64<T, false, true>(ga, st);
-  else if (trans_a && trans_b) launch_pp64<T, true, true>(ga, st);
-  else launch_pp64<T, true, false>(ga, st);
+int launch_pp64_layout(int trans_a, int trans_b, GroupArgs& ga, hipStream_t st) {
+  if (!trans_a && !trans_b) return launch_pp64<T, false, false>(ga, st);
+  if (!trans_a && trans_b) return launch_pp64<T, false, true>(ga, st);
+  if (trans_a && trans_b) return launch_pp64<T, true, true>(ga, st);
+  return launch_pp64<T, true, false>(ga, st);
 }
 template <typename T>
 void launch_splitk_reduce(GemmArgs& a, hipStream_t st) {
@@ -1346,7 +1406,8 @@ int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
     else if (variant == 8) launch_glds_layout<T, 2, 4, 4, 1, 64, 3, true>(d, a, st);   // 256x128x64 ping-pong (128-B rows)
     else if (variant == 9) {                                                            // generation 3 (operands < 4 GiB)
       GroupArgs ga; ga.count = 1; ga.g[0] = a;
-      launch_pp64_layout<T>(d->trans_a, d->trans_b, ga, st);
+      const int rc = launch_pp64_layout<T>(d->trans_a, d->trans_b, ga, st);
+      if (rc != COGV_OK) return rc;
       a.tiles_m = ga.g[0].tiles_m; a.tiles_n = ga.g[0].tiles_n;
     }
     else launch_glds_layout<T, 4, 2, 2, 2, 64>(d, a, st);
@@ -1484,8 +1545,9 @@ extern "C" int cogv_gemm_grouped(const cogv_gemm_desc* descs, int count, void* s
     if (d->trans_b && (a.N & 7)) return COGV_ERR_UNSUPPORTED;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (descs[0].dtype == COGV_F16) launch_pp64_layout<f16_t>(descs[0].trans_a, descs[0].trans_b, ga, st);
-  else launch_pp64_layout<bf16_t>(descs[0].trans_a, descs[0].trans_b, ga, st);
+  const int lrc = descs[0].dtype == COGV_F16 ? launch_pp64_layout<f16_t>(descs[0].trans_a, descs[0].trans_b, ga, st)
+                                             : launch_pp64_layout<bf16_t>(descs[0].trans_a, descs[0].trans_b, ga, st);
+  if (lrc != COGV_OK) return lrc;
   for (int i = 0; i < count; ++i)
     if (ga.g[i].splitk > 1) {
       if (descs[0].dtype == COGV_F16) launch_splitk_reduce<f16_t>(ga.g[i], st);

@@ -89,6 +89,8 @@ int cogv_colsum_finalize(int dtype, const float* partial, int rows, int N, void*
  * each alone would leave a partial last round.  COGV_ERR_UNSUPPORTED when a problem does not fit the 256x256x64
  * kernel (M, N >= 256, K % 64 == 0): issue them one by one then.  Split-K as in cogv_gemm, per problem. */
 int cogv_gemm_grouped(const cogv_gemm_desc* descs, int count, void* stream);
+/* Note: the persistent GEMM kernel distributes tiles through per-XCD atomic work queues; the library keeps their
+ * counters in 4 KiB of device memory per GPU that it allocates itself on the first GEMM call (its only allocation). */
 int cogv_gemm_pick_splitk_tiles(int tiles_256x256, int K);
 
 /* ------------------------------------------------------------------ Sandwich-LN
