@@ -40,7 +40,8 @@ def rnd(shape, dtype, gen, scale=1.0):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (510, 768, 256), (300, 136, 72), (1088, 1024, 1024), (64, 2560, 2560)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (510, 768, 256), (300, 136, 72), (1088, 1024, 1024), (64, 2560, 2560),
+                                   (700, 520, 192), (2000, 264, 64)])
 def test_gemm_nt_bias(ops, dtype, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N)
     a, b, bias = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 0.1), rnd((N,), dtype, g)
@@ -62,7 +63,7 @@ def test_gemm_asymmetric_identity(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(510, 256, 768), (1088, 1024, 3072), (136, 72, 304)])
+@pytest.mark.parametrize("M,N,K", [(510, 256, 768), (1088, 1024, 3072), (136, 72, 304), (700, 520, 192)])
 def test_gemm_dgrad_nn(ops, dtype, M, N, K):
     """dX[M,N] = dY[M,K] W[K,N]  (trans_b: B stored [K][N])."""
     g = torch.Generator().manual_seed(K)
@@ -72,7 +73,8 @@ def test_gemm_dgrad_nn(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,splitk", [(768, 256, 510, 1), (1024, 1024, 4352, None), (72, 136, 300, 3), (3072, 1024, 2176, 4)])
+@pytest.mark.parametrize("M,N,K,splitk", [(768, 256, 510, 1), (1024, 1024, 4352, None), (72, 136, 300, 3), (3072, 1024, 2176, 4),
+                                          (520, 264, 1088, 2), (2560, 2560, 8704, None)])
 def test_gemm_wgrad_tn(ops, dtype, M, N, K, splitk):
     """dW[M,N] = dY[K,M]^T X[K,N]  (both operands stored contraction-major)."""
     g = torch.Generator().manual_seed(K + 1)
