@@ -1137,7 +1137,7 @@ void gemm_pp64_kernel(const GroupArgs ga) {
         }
     };
     auto mma = [&](int half) {
-      __builtin_amdgcn_s_setprio(1);
+      if (!(COGV_EXP & 512)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         typename HT<T>::v8 fa[4], fb[4];
@@ -1163,7 +1163,7 @@ void gemm_pp64_kernel(const GroupArgs ga) {
           for (int j = 0; j < 4; ++j)
             acc[4 * half + i][j] = HT<T>::mfma16(fb[j], fa[i], acc[4 * half + i][j]);
       }
-      __builtin_amdgcn_s_setprio(0);
+      if (!(COGV_EXP & 512)) __builtin_amdgcn_s_setprio(0);
     };
 
     for (int kt = 0; kt < nk; ++kt) {
