@@ -373,28 +373,6 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
 }
 
 // =====================================================================================================
-// D[b][h][q] = sum_d dO[q][d] * O[q][d]     (8 lanes per row)
-// =====================================================================================================
-template <typename T>
-__global__ __launch_bounds__(256) void attn_dvec_kernel(const AttnArgs p) {
-  const long long nrow = (long long)p.B * p.H * p.s_q;
-  const long long rid = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3;
-  const int sub = threadIdx.x & 7;
-  float s = 0.f;
-  if (rid < nrow) {
-    const int q = (int)(rid % p.s_q); const long long bh = rid / p.s_q;
-    const int head = (int)(bh % p.H); const int b = (int)(bh / p.H);
-    float a[8], c[8];
-    unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.dout) + b * p.do_bs + (long long)q * p.do_rs + head * HD + sub * 8), a);
-    unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.o) + b * p.o_bs + (long long)q * p.o_rs + head * HD + sub * 8), c);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += a[i] * c[i];
-  }
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-  if (rid < nrow && sub == 0) p.dvec[rid] = s;
-}
-
-// =====================================================================================================
 // dQ: grid (ceil(s_q/128), H, B); lane = query.   dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
 // Ring stage = K tile | V tile (K serves both S^T (natural read) and dQ^T (transposing read)).
 // =====================================================================================================
@@ -424,7 +402,20 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   }
   const long long arow = ((long long)b * p.H + head) * p.s_q + myq;
   const float lse2 = qvalid ? p.lse[arow] * 1.4426950408889634f : 0.f;
-  const float dv = qvalid ? p.dvec[arow] : 0.f;
+  // D[q] = sum_d dO[q][d] O[q][d] (the softmax-backward row term): computed here from the dO fragments this lane
+  // already holds (+ the matching O fragments), published for the dK/dV kernel that runs next -- no separate pass
+  float dv = 0.f;
+  {
+    const T* Op = reinterpret_cast<const T*>(p.o) + b * p.o_bs + head * HD;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const typename HT<T>::v8 of = load_frag_global<T>(Op + (long long)myq * p.o_rs + 16 * t + 8 * fg, qvalid);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dv = fmaf((float)dof[t][e], (float)of[e], dv);
+    }
+    dv += __shfl_xor(dv, 32, 64);
+    if (qvalid && fg == 0) p.dvec[arow] = dv;
+  }
   const int ngrp = (p.s_k + 3) >> 2;
   const float sl2 = p.scale * 1.4426950408889634f;
   const float masked_raw = MASKED / p.scale;
@@ -771,8 +762,6 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.do_rs | a.dq_rs | a.dk_rs | a.dv_rs) & 7) return COGV_ERR_ARG;
   if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs | a.do_bs | a.dq_bs | a.dk_bs | a.dv_bs) & 7) return COGV_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const long long nrow = (long long)a.B * a.H * a.s_q;
-  const int gD = (int)((nrow * 8 + 255) / 256);
   dim3 gq((a.s_q + 127) / 128, a.H, a.B), gk((a.s_k + 127) / 128, a.H, a.B);
   const int sh_q = 3 * 2 * TILE, sh_k = 3 * (2 * TILE + 512);
   static bool attr = false;
@@ -782,11 +771,9 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
     attr = true;
   }
   if (d->dtype == COGV_F16) {
-    hipLaunchKernelGGL((attn_dvec_kernel<f16_t>), dim3(gD), dim3(256), 0, st, a);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t>), gq, dim3(NT), sh_q, st, a);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t>), gk, dim3(NT), sh_k, st, a);
   } else {
-    hipLaunchKernelGGL((attn_dvec_kernel<bf16_t>), dim3(gD), dim3(256), 0, st, a);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t>), gq, dim3(NT), sh_q, st, a);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t>), gk, dim3(NT), sh_k, st, a);
   }
