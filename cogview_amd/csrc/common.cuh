@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define COGV_OK 0
 #define COGV_ERR_ARG 1      // bad argument (shape/alignment/dtype)
@@ -84,6 +85,24 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+// Wave-wide sum through DPP only (no LDS crossbar): quad butterflies, half-row and row mirrors, then the two
+// cross-row broadcasts; the total lands in lane 63 and is returned as a wave-uniform value.
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+  auto dpp_add = [](float x, auto ctrl, auto row_mask) {
+    constexpr int C = decltype(ctrl)::value, RM = decltype(row_mask)::value;
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C, RM, 0xf, false);
+    return x + __builtin_bit_cast(float, y);
+  };
+  using IC = std::integral_constant<int, 0>;
+  (void)sizeof(IC);
+  v = dpp_add(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+  v = dpp_add(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+  v = dpp_add(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});   // row_half_mirror
+  v = dpp_add(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});   // row_mirror
+  v = dpp_add(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast15 -> rows 1, 3
+  v = dpp_add(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -150,31 +150,30 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const LnBwdArgs p) {
   };
   fetch(blockIdx.x * R);
   for (int row0 = blockIdx.x * R; row0 < p.rows; row0 += gridDim.x * R) {
-    u32x4 dyv[R], xv[R], adv[R];
-    float mean[R], rstd[R], s1[R], s2[R];
+    u32x4 adv[R];
+    float rstd[R], s1[R], s2[R];
+    float xhk[R][8], gyk[R][8];        // normalised input and gamma * dy of the rows in flight (kept for phase 2)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      dyv[r] = dyn[r]; xv[r] = xn_[r]; adv[r] = adn[r]; mean[r] = meann[r]; rstd[r] = rstdn[r];
-    }
-    fetch(row0 + gridDim.x * R);       // rows past the end load nothing
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float dy[8], xh[8];
-      unpack8<T>(dyv[r], dy); unpack8<T>(xv[r], xh);
+      float dy[8];
+      unpack8<T>(dyn[r], dy); unpack8<T>(xn_[r], xhk[r]);
+      adv[r] = adn[r]; rstd[r] = rstdn[r];
+      const float mr = meann[r] * rstdn[r];
       float a1 = 0.f, a2 = 0.f;
       if (act && row0 + r < p.rows) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          xh[i] = (xh[i] - mean[r]) * rstd[r];
-          const float gy = dy[i] * g[i];
-          a1 += gy;
-          a2 += gy * xh[i];
-          dg[i] += dy[i] * xh[i];
+          xhk[r][i] = fmaf(xhk[r][i], rstd[r], -mr);
+          gyk[r][i] = dy[i] * g[i];
+          a1 += gyk[r][i];
+          a2 = fmaf(gyk[r][i], xhk[r][i], a2);
+          dg[i] = fmaf(dy[i], xhk[r][i], dg[i]);
           db[i] += dy[i];
         }
       }
-      s1[r] = wave_sum(a1); s2[r] = wave_sum(a2);
+      s1[r] = wave_sum_uniform(a1); s2[r] = wave_sum_uniform(a2);
     }
+    fetch(row0 + gridDim.x * R);       // next iteration's rows (rows past the end load nothing)
     if (lane == 0) {
 #pragma unroll
       for (int r = 0; r < R; ++r) { red[buf][r][wave][0] = s1[r]; red[buf][r][wave][1] = s2[r]; }
@@ -187,13 +186,9 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const LnBwdArgs p) {
       for (int w = 0; w < nw; ++w) { m1 += red[buf][r][w][0]; m2 += red[buf][r][w][1]; }
       m1 *= inv_h; m2 *= inv_h;
       if (act && row < p.rows) {
-        float dy[8], xh[8], o[8];
-        unpack8<T>(dyv[r], dy); unpack8<T>(xv[r], xh);
+        float o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float xn = (xh[i] - mean[r]) * rstd[r];
-          o[i] = rstd[r] * (dy[i] * g[i] - m1 - xn * m2);
-        }
+        for (int i = 0; i < 8; ++i) o[i] = rstd[r] * (gyk[r][i] - m1 - xhk[r][i] * m2);
         if (p.thr16) {
           const uint64_t e = (uint64_t)row * (uint64_t)p.h + (uint64_t)col;
           const u32x4 rn = Philox::gen(p.seed, p.stream_id, e >> 3);
