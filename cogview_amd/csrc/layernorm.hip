@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
         for (int i = 0; i < 8; ++i) x[v][i] = 0.f;
       }
     }
-    const float mean = wave_sum(s) * inv_h;
+    const float mean = wave_sum_uniform(s) * inv_h;
     float q = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
         for (int i = 0; i < 8; ++i) { const float d = x[v][i] - mean; q += d * d; }
       }
     }
-    const float var = wave_sum(q) * inv_h;
+    const float var = wave_sum_uniform(q) * inv_h;
     const float rstd = 1.0f / sqrtf(var + eps);
     if (lane == 0) { if (p.mean) p.mean[row] = mean; if (p.rstd) p.rstd[row] = rstd; }
 #pragma unroll
