@@ -1068,15 +1068,18 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     adA[i] = AT ? tr_addr16<ROWB_A>(smem, wr * 64 + 16 * i, lane)
                 : (uint32_t)(uintptr_t)smem + (uint32_t)((wr * 64 + 16 * i + l15) * 128 + ((kb ^ swz(wr * 64 + 16 * i + l15)) << 4));
 
-  // Work distribution: the first item of a workgroup is its block index, every further one comes from an atomic
-  // counter.  A static stride would make the launch as slow as its unluckiest workgroup: this kernel needs a whole
-  // CU (512 threads x 256 registers), so when other kernels hold CUs -- RCCL's all-reduce channels during the
-  // data-parallel backward -- some workgroups start late, and with the queue they simply take fewer items.
+  // Work distribution: every item, the first one included, comes from an atomic counter.  A static assignment
+  // would make the launch as slow as its unluckiest workgroup: this kernel needs a whole CU (512 threads x 256
+  // registers), so when other kernels hold CUs -- RCCL's all-reduce channels during the data-parallel backward --
+  // some workgroups start late; with the queue they take fewer items, or none and exit at once.
   // One queue per XCD (workgroup b runs on XCD b & 7): item i stays on XCD i & 7, which is what the tile order
   // inside setup() assumes for L2 reuse (one shared queue measured 10-15 % slower).
   __shared__ int s_next;
+  const int xq = blockIdx.x & 7;
+  if (threadIdx.x == 0) s_next = xq + 8 * atomicAdd(ga.sched + xq, 1);
+  __syncthreads();
   Item cur;
-  int item = blockIdx.x;
+  int item = s_next;
   if (item < nitems) { setup(item, cur); prologue(cur); }
 #pragma unroll 1
   while (item < nitems) {
@@ -1094,7 +1097,7 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();             // the stagger
     int grabbed = 0;                                       // the item after this one: asked for now, used after the k-loop
-    if (threadIdx.x == 0) grabbed = atomicAdd(ga.sched + (blockIdx.x & 7), 1);
+    if (threadIdx.x == 0) grabbed = atomicAdd(ga.sched + xq, 1);
 
     TrRaw tb[KS][4], ta[KS][4];          // KS = 2 k-steps of 32 per k-tile
     u32x4 nb[KS][4], na[KS][4];
@@ -1202,10 +1205,7 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- next item's prologue goes out BEFORE this item's epilogue
-    if (threadIdx.x == 0) {      // j-th item of this XCD's list {x, x + 8, ...}: the first (gridDim.x - x + 7) / 8 were taken statically
-      const int x = blockIdx.x & 7;
-      s_next = x + 8 * (((int)gridDim.x - x + 7) / 8 + grabbed);
-    }
+    if (threadIdx.x == 0) s_next = xq + 8 * grabbed;       // the grabbed-th item of this XCD's list {x, x + 8, ...}
     __syncthreads();
     const int next = s_next;
     const Item done = cur;
