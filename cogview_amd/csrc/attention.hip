@@ -155,6 +155,26 @@ __device__ __forceinline__ u32x2 attn_bits(uint32_t key, long long arow, int ngr
   return Philox::gen64_k(key, (uint64_t)(arow * ngrp + (key0 >> 2)));
 }
 __device__ __forceinline__ uint32_t bits_of(const u32x2& r, int i) { return (r[i >> 1] >> (16 * (i & 1))) & 0xffffu; }
+// The same draw with the 64-bit group counter kept as (lo, hi * C): ctr = base + g with g < 2^32.  Bit-identical to
+// attn_bits(key, arow, ngrp, key0) for base = arow * ngrp, g = key0 >> 2, without the per-draw 64-bit add and the
+// quarter-rate multiply of the high word (it only changes on a carry).
+struct CtrBase { uint32_t lo, hic; };
+__device__ __forceinline__ CtrBase ctr_base(unsigned long long base) {
+  return CtrBase{(uint32_t)base, (uint32_t)(base >> 32) * 0x85EBCA6Bu};
+}
+__device__ __forceinline__ u32x2 attn_bits_at(uint32_t key, const CtrBase& cb, uint32_t g) {
+  const uint32_t lo = cb.lo + g;
+  const uint32_t hic = cb.hic + (lo < cb.lo ? 0x85EBCA6Bu : 0u);
+  u32x2 o;
+  o[0] = pcg32((lo ^ key) + hic);
+  o[1] = xorshift32(o[0] ^ 0x68E31DA4u);
+  return o;
+}
+// keep test on element i of a draw without extracting the 16-bit field: high halves compare the whole word against
+// thr << 16 (the low half only adds less than one unit), low halves compare the low 16 bits
+__device__ __forceinline__ bool keep_of(const u32x2& r, int i, uint32_t thr16) {
+  return (i & 1) ? (r[i >> 1] >= (thr16 << 16)) : ((r[i >> 1] & 0xffffu) >= thr16);
+}
 
 // 4 transposed fragments (2 d-blocks x k-steps t = 0,1 of a 32-row sub-block SB) of one tile
 template <typename T, int SB>
@@ -260,6 +280,10 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   const float masked_raw = MASKED / p.scale;         // raw value whose scaled score is exactly -10000
   const long long arow = ((long long)b * p.H + head) * p.s_q + myq;
   const int ngrp = (p.s_k + 3) >> 2;
+  const CtrBase cb = ctr_base((unsigned long long)arow * (unsigned long long)ngrp);
+  // dropout scale 1 / (1 - p) folded into the exponent: the probabilities (and their running sum) carry it, the
+  // final normalisation takes it back out -- no multiply per kept element
+  const float kofs = p.thr16 ? __builtin_amdgcn_logf(p.keep_scale) : 0.f;     // v_log_f32 = log2
   const uint32_t loff[2] = {tr_lane_off(0, lane) ^ tr_lane_fix(lane), tr_lane_off(1, lane) ^ tr_lane_fix(lane)};
   const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
 
@@ -315,17 +339,17 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { const float pv = fast_exp2(fmaf(sacc[sb][e], sl2, -m_run)); sacc[sb][e] = pv; ls += pv; }
+        for (int e = 0; e < 16; ++e) { const float pv = fast_exp2(fmaf(sacc[sb][e], sl2, kofs - m_run)); sacc[sb][e] = pv; ls += pv; }
       l_run += ls;
       if (p.thr16) {
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
-            const u32x2 r = attn_bits(p.rng_key, arow, ngrp, kb * 64 + sb * 32 + 8 * gq + 4 * fg);
+            const u32x2 r = attn_bits_at(p.rng_key, cb, (uint32_t)((kb * 64 + sb * 32 + 8 * gq + 4 * fg) >> 2));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              sacc[sb][4 * gq + i] = (bits_of(r, i) >= p.thr16) ? sacc[sb][4 * gq + i] * p.keep_scale : 0.f;
+              sacc[sb][4 * gq + i] = keep_of(r, i, p.thr16) ? sacc[sb][4 * gq + i] : 0.f;
           }
       }
       // O^T[d][query] += V^T[d][key] . P^T[key][query]
@@ -356,9 +380,9 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   }
   wait_vmcnt<0>();
   if (wave_active && myq < p.s_q) {
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (fg == 0 && p.lse) p.lse[((long long)b * p.H + head) * p.s_q + myq] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);       // = keep_scale * sum of probabilities
+    const float inv = (p.thr16 ? p.keep_scale : 1.0f) / l_tot;
+    if (fg == 0 && p.lse) p.lse[((long long)b * p.H + head) * p.s_q + myq] = (m_run + __builtin_amdgcn_logf(l_tot) - kofs) * 0.6931471805599453f;
     T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + (long long)myq * p.o_rs + head * HD;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -401,6 +425,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     dof[t] = load_frag_global<T>(DO + (long long)myq * p.do_rs + 16 * t + 8 * fg, qvalid);
   }
   const long long arow = ((long long)b * p.H + head) * p.s_q + myq;
+  const CtrBase cb = ctr_base((unsigned long long)arow * (unsigned long long)((p.s_k + 3) >> 2));
   const float lse2 = qvalid ? p.lse[arow] * 1.4426950408889634f : 0.f;
   // D[q] = sum_d dO[q][d] O[q][d] (the softmax-backward row term): computed here from the dO fragments this lane
   // already holds (+ the matching O fragments), published for the dK/dV kernel that runs next -- no separate pass
@@ -469,13 +494,13 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           u32x2 r = {0u, 0u};
-          if (p.thr16) r = attn_bits(p.rng_key, arow, ngrp, kfirst + 8 * gq + 4 * fg);
+          if (p.thr16) r = attn_bits_at(p.rng_key, cb, (uint32_t)((kfirst + 8 * gq + 4 * fg) >> 2));
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int e = 4 * gq + i;
             const float pr = fast_exp2(fmaf(sacc[e], sl2, -lse2));
             float dp = pacc[e];
-            if (p.thr16) dp = (bits_of(r, i) >= p.thr16) ? dp * p.keep_scale : 0.f;
+            if (p.thr16) dp = keep_of(r, i, p.thr16) ? dp * p.keep_scale : 0.f;
             ds[e] = pr * (dp - dv);
           }
         }
@@ -557,6 +582,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   const float masked_raw = MASKED / p.scale;
   const int ngrp = (p.s_k + 3) >> 2;
   const long long arow0 = ((long long)b * p.H + head) * p.s_q;
+  const unsigned long long ctr_lane = (unsigned long long)(arow0 + 4 * fg + (lane & 3)) * (unsigned long long)ngrp + (unsigned long long)(mykey >> 2);
 
   f32x16 dkacc[2], dvacc[2];
 #pragma unroll
@@ -606,11 +632,13 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
           const int c = lane & 3;
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
-            const int q = qb * 64 + sb * 32 + 8 * gq + 4 * fg + c;
-            const u32x2 r = attn_bits(p.rng_key, arow0 + q, ngrp, mykey & ~3);
+            // ctr = (arow0 + q) * ngrp + (key >> 2), q = qb * 64 + sb * 32 + 8 gq + 4 fg + c: the lane's part
+            // (arow0 + 4 fg + c) * ngrp + (key >> 2) is hoisted (ctr_lane), the rest is a small multiple of ngrp
+            const unsigned long long ctr = ctr_lane + (unsigned long long)(uint32_t)(qb * 64 + sb * 32 + 8 * gq) * (uint32_t)ngrp;
+            const u32x2 r = attn_bits_at(p.rng_key, ctr_base(ctr), 0u);
             uint32_t m4 = 0;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) m4 |= (bits_of(r, f) >= p.thr16 ? 1u : 0u) << f;
+            for (int f = 0; f < 4; ++f) m4 |= (keep_of(r, f, p.thr16) ? 1u : 0u) << f;
             kmask[gq] = m4;
           }
         }
