@@ -426,6 +426,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   }
   const long long arow = ((long long)b * p.H + head) * p.s_q + myq;
   const CtrBase cb = ctr_base((unsigned long long)arow * (unsigned long long)((p.s_k + 3) >> 2));
+  const float kscale = p.thr16 ? p.keep_scale : 1.0f;
   const float lse2 = qvalid ? p.lse[arow] * 1.4426950408889634f : 0.f;
   // D[q] = sum_d dO[q][d] O[q][d] (the softmax-backward row term): computed here from the dO fragments this lane
   // already holds (+ the matching O fragments), published for the dK/dV kernel that runs next -- no separate pass
@@ -500,8 +501,8 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
             const int e = 4 * gq + i;
             const float pr = fast_exp2(fmaf(sacc[e], sl2, -lse2));
             float dp = pacc[e];
-            if (p.thr16) dp = keep_of(r, i, p.thr16) ? dp * p.keep_scale : 0.f;
-            ds[e] = pr * (dp - dv);
+            if (p.thr16) dp = keep_of(r, i, p.thr16) ? dp : 0.f;
+            ds[e] = pr * fmaf(dp, kscale, -dv);                  // kscale = 1 / (1 - p) (1 without dropout)
           }
         }
         tr_wait(kr[0][0], kr[0][1]); tr_wait(kr[1][0], kr[1][1]);
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   const float masked_raw = MASKED / p.scale;
   const int ngrp = (p.s_k + 3) >> 2;
   const long long arow0 = ((long long)b * p.H + head) * p.s_q;
+  const float kscale = p.thr16 ? p.keep_scale : 1.0f;
   const unsigned long long ctr_lane = (unsigned long long)(arow0 + 4 * fg + (lane & 3)) * (unsigned long long)ngrp + (unsigned long long)(mykey >> 2);
 
   f32x16 dkacc[2], dvacc[2];
@@ -663,10 +665,12 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
             if (!all_visible) { const int q = qb * 64 + ql + i; if (!visible(q, mykey, off, p.sep_k)) a = masked_raw; }
             float pr = fast_exp2(fmaf(a, sl2, -l4[i] * l2e));
             if (tail) { if (qb * 64 + ql + i >= p.s_q) pr = 0.f; }
-            float keep = 1.f;
-            if (p.thr16) keep = ((km[i] >> kbit) & 1u) ? p.keep_scale : 0.f;
-            pd[e] = pr * keep;
-            ds[e] = pr * (pacc[e] * keep - d4[i]);
+            // dropped probability Pd = keep ? P / (1 - p) : 0 and dS = P (keep ? dPd / (1 - p) : 0  -  D)
+            const float prs = pr * kscale;
+            const bool kept = !p.thr16 || ((km[i] >> kbit) & 1u);
+            pd[e] = kept ? prs : 0.f;
+            const float t = pr * d4[i];
+            ds[e] = kept ? fmaf(prs, pacc[e], -t) : -t;
           }
         }
         if (!kvalid) {
