@@ -63,8 +63,19 @@ template <> __device__ __forceinline__ float bits_to_f<bf16_t>(uint16_t b) {
 template <typename T> __device__ __forceinline__ uint16_t f_to_bits(float x) {
   T h = (T)x; uint16_t b; __builtin_memcpy(&b, &h, 2); return b;
 }
-template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)f_to_bits<T>(lo) | ((uint32_t)f_to_bits<T>(hi) << 16);
+// two floats -> one packed 16-bit pair, round-to-nearest-even.  Through a 2-vector conversion: gfx950 has
+// v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, but two scalar casts compile to two converts + shift + or (4 instructions).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) {
+  const bf16x2_t h = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+  uint32_t u; __builtin_memcpy(&u, &h, 4); return u;
+}
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) {
+  const f16x2_t h = __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t);
+  uint32_t u; __builtin_memcpy(&u, &h, 4); return u;
 }
 template <typename T> __device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
 #pragma unroll
