@@ -629,6 +629,18 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
         // keys of one group, so lane c of the quad hashes only the queries with (e & 3) == c, reduces each 64-bit
         // draw to a 4-bit keep mask (bit f <-> key 4m+f) and the quad shares it by a broadcast DPP move:
         // 4 hashes per lane per 32x32 tile instead of 16.
+        // masking only in blocks that touch the diagonal / the sequence end (wave-uniform branch): masked scores become
+        // the raw value whose scaled score is -10000, queries past the end -inf (probability exactly 0)
+        if (!all_visible || tail) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int q = qfirst + 4 * fg + (e & 3) + 8 * (e >> 2);
+            float a = sacc[e];
+            if (!visible(q, mykey, off, p.sep_k)) a = masked_raw;
+            if (q >= p.s_q) a = -INFINITY;
+            sacc[e] = a;
+          }
+        }
         uint32_t kmask[4] = {0u, 0u, 0u, 0u};
         if (p.thr16) {
           const int c = lane & 3;
@@ -661,10 +673,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int e = 4 * gq + i;
-            float a = sacc[e];
-            if (!all_visible) { const int q = qb * 64 + ql + i; if (!visible(q, mykey, off, p.sep_k)) a = masked_raw; }
-            float pr = fast_exp2(fmaf(a, sl2, -l4[i] * l2e));
-            if (tail) { if (qb * 64 + ql + i >= p.s_q) pr = 0.f; }
+            const float pr = fast_exp2(fmaf(sacc[e], sl2, -l4[i] * l2e));
             // dropped probability Pd = keep ? P / (1 - p) : 0 and dS = P (keep ? dPd / (1 - p) : 0  -  D)
             const float prs = pr * kscale;
             const bool kept = !p.thr16 || ((km[i] >> kbit) & 1u);
