@@ -142,6 +142,36 @@ __device__ __forceinline__ float block_max(float v, float* smem) {
   return r;
 }
 
+// Abs-max of 16-bit floats on their BIT PATTERNS: with the sign cleared, integer order is magnitude order for fp16 and
+// bf16 alike, and every NaN pattern sorts above infinity -- so one v_pk_max_u16 per pair replaces unpack + fabs +
+// max + NaN test, and NaN propagates by itself (the reference's x.abs().max() semantics).
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t absmax_pk(uint32_t m, uint32_t packed) {
+  const uint32_t x = packed & 0x7fff7fffu;
+  u16x2_t a, b;
+  __builtin_memcpy(&a, &m, 4); __builtin_memcpy(&b, &x, 4);
+  a = __builtin_elementwise_max(a, b);
+  __builtin_memcpy(&m, &a, 4);
+  return m;
+}
+__device__ __forceinline__ uint32_t absmax_pk8(uint32_t m, const u32x4& v) {
+  return absmax_pk(absmax_pk(absmax_pk(absmax_pk(m, v[0]), v[1]), v[2]), v[3]);
+}
+// block-wide max of the running pair, returned as the fp32 value of the largest pattern (NaN stays NaN)
+template <typename T>
+__device__ __forceinline__ float absmax_pk_block(uint32_t m, uint32_t* smem) {
+  uint32_t v = max(m & 0xffffu, m >> 16);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  uint32_t r = smem[0];
+  for (int i = 1; i < nw; ++i) r = max(r, smem[i]);
+  return bits_to_f<T>((uint16_t)r);
+}
+
 // non-negative float atomic max through the integer ordering of IEEE-754.
 // Same-address atomics serialise at L2 (~90 per microsecond on MI355X), and a launch has thousands of
 // workgroups, so the current value is read first (relaxed, agent scope -> served by L2) and the atomic is

@@ -132,7 +132,7 @@ __device__ __forceinline__ typename HT<T>::v8 read_frag(const char* lds, int row
 template <typename T, int F = -1>
 //      bias_pre / aux_pre / c_pre: values the caller already loaded (the generation-3 epilogue issues all of a
 //      sub-tile's dGeLU / accumulate reads up front instead of one exposed global-load latency per pass).
-__device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, float (&v)[8], const u32x4* bias_pre = nullptr,
+__device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, float (&v)[8], const u32x4* bias_pre = nullptr,
                                            const u32x4* aux_pre = nullptr, const u32x4* c_pre = nullptr, float* rounded = nullptr) {
   const int flags = F >= 0 ? F : p.flags;
   const bool out_f32 = F >= 0 ? false : (p.out_f32 != 0);
@@ -175,26 +175,24 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& p, int m, int n, floa
       for (int i = 0; i < 8; ++i) v[i] += c[i];
     }
   }
-  float amax = 0.f;
+  // returns the pair-wise max of the outputs' |value| bit patterns (see absmax_pk); 0 unless COGV_EPI_ABSMAX
+  uint32_t amax_pk = 0u;
   if (out_f32) {
     float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
     *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    if (rounded) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+      for (int i = 0; i < 8; ++i) rounded[i] = v[i];
+    }
+    if (flags & COGV_EPI_ABSMAX) amax_pk = absmax_pk8(0u, pack8<T>(v));      // fp32 output: max taken on the 16-bit rounding
   } else {
     u32x4 o = pack8<T>(v);
     *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = o;
     if (rounded) unpack8<T>(o, rounded);
-    if (flags & COGV_EPI_ABSMAX) {
-      float r[8]; unpack8<T>(o, r);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(r[i]));   // NaN-ignoring max; NaNs handled below
-#pragma unroll
-      for (int i = 0; i < 8; ++i) if (r[i] != r[i]) amax = r[i];
-    }
+    if (flags & COGV_EPI_ABSMAX) amax_pk = absmax_pk8(0u, o);
   }
-  return amax;
+  return amax_pk;
 }
 
 template <typename T, bool AT, bool BT>
@@ -288,8 +286,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
       }
   __syncthreads();
 
-  float amax = 0.f;
-  bool nan = false;
+  uint32_t amax_pk = 0u;
   const int cchunk = (threadIdx.x & 15) * 8;
 #pragma unroll 1
   for (int pass = 0; pass < 8; ++pass) {
@@ -306,17 +303,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
         *reinterpret_cast<f32x4*>(w) = x0;
         *reinterpret_cast<f32x4*>(w + 4) = x1;
       } else {
-        const float a = epilogue8<T>(p, m, n, v);
-        if (a != a) nan = true; else amax = fmaxf(amax, a);
+        amax_pk = absmax_pk(amax_pk, epilogue8<T>(p, m, n, v));
       }
     }
   }
   if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
     // fmaxf drops NaNs, so a NaN anywhere in the tile is carried by a flag and published as a quiet-NaN
     // bit pattern (larger than every finite value under the unsigned ordering used by the atomic)
-    float bm = block_max(amax, reinterpret_cast<float*>(smem));
-    const bool any_nan = __syncthreads_or(nan);
-    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, any_nan ? __uint_as_float(0x7fc00000u) : bm);
+    const float bm = absmax_pk_block<T>(amax_pk, reinterpret_cast<uint32_t*>(smem));
+    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, bm);
   }
 }
 
@@ -432,7 +427,7 @@ __device__ __forceinline__ void store_c_tile_impl(const GemmArgs& p, ACC (&acc)[
   constexpr int SLAB = TBM / NH;
   static_assert(SLAB * TBN * 4 <= RING && SLAB % 32 == 0 && MI * BLK * NW * NJ * BLK == TBM * TBN, "C slab does not fit the ring");
   float* ct = reinterpret_cast<float*>(smem);
-  float amax = 0.f; bool nan = false;
+  uint32_t amax_pk = 0u;
   constexpr int CPR = TBN / 8;                       // 8-column chunks per row
   constexpr int RPP = NW * 64 / CPR;                 // rows per pass
   const int cchunk = (threadIdx.x % CPR) * 8;
@@ -471,17 +466,15 @@ __device__ __forceinline__ void store_c_tile_impl(const GemmArgs& p, ACC (&acc)[
           float v[8];
           v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
           v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
-          const float a = epilogue8<T>(p, m, n, v);
-          if (a != a) nan = true; else amax = fmaxf(amax, a);
+          amax_pk = absmax_pk(amax_pk, epilogue8<T>(p, m, n, v));
         }
       }
     }
   }
   if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
     __syncthreads();
-    float bm = block_max(amax, reinterpret_cast<float*>(smem));
-    const bool any_nan = __syncthreads_or(nan);
-    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, any_nan ? __uint_as_float(0x7fc00000u) : bm);
+    const float bm = absmax_pk_block<T>(amax_pk, reinterpret_cast<uint32_t*>(smem));
+    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, bm);
   }
 }
 
@@ -819,7 +812,7 @@ void gemm_glds_kernel(const GemmArgs p) {
 //      (-1: runtime flags / fp32 output, -2: split-K partial slab).
 template <typename T, int F>
 __device__ __forceinline__ void pp64_epilogue(const GemmArgs& p, f32x4 (&acc)[8][4], float* strip, int m_base, int n_base,
-                                              int ksplit, int lane, float& amax, bool& nan, int colsum_row) {
+                                              int ksplit, int lane, uint32_t& amax_pk, int colsum_row) {
   const int l15 = lane & 15, kb = lane >> 4;
   const bool want_cs = (F == -1) ? ((p.flags & COGV_EPI_COLSUM) != 0 && !p.out_f32) : (F >= 0 && (F & COGV_EPI_COLSUM));
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -867,10 +860,9 @@ __device__ __forceinline__ void pp64_epilogue(const GemmArgs& p, f32x4 (&acc)[8]
         } else {
           float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
           float rv[8];
-          const float a = epilogue8<T, (F < 0 ? -1 : F)>(p, m, n, v, PRE_BIAS ? &bias_v : nullptr,
-                                                         PRE_AUX ? &aux_v[2 * i + hh] : nullptr, PRE_C ? &c_v[2 * i + hh] : nullptr,
-                                                         want_cs ? rv : nullptr);
-          if (a != a) nan = true; else amax = fmaxf(amax, a);
+          amax_pk = absmax_pk(amax_pk, epilogue8<T, (F < 0 ? -1 : F)>(p, m, n, v, PRE_BIAS ? &bias_v : nullptr,
+                                                                       PRE_AUX ? &aux_v[2 * i + hh] : nullptr,
+                                                                       PRE_C ? &c_v[2 * i + hh] : nullptr, want_cs ? rv : nullptr));
           if (want_cs) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) cs[e] += rv[e];
@@ -1217,26 +1209,27 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     //      "8 lanes x 16 bytes = one 128-byte line per row" order for the fused epilogue8: no workgroup barrier,
     //      full-line stores.  (Storing straight from the MFMA layout -- 8 bytes per lane, 32-byte row segments --
     //      measured 4x slower than this: 16 us per tile.)  16-byte chunk c of strip row r sits at chunk c ^ r.
-    float amax = 0.f; bool nan = false;
+    uint32_t amax_pk = 0u;
     float* strip = reinterpret_cast<float*>(smem + BUF + A23_OFF + wave * 2048);
     // One instance per hot flag combination (compile-time mask): the passes below are fully unrolled (the
     // accumulators need static register indices), so a single runtime-flag body is ~100 KB of code per kernel
     // and every item would stream it through the instruction cache.
     constexpr int F_FWD_DROP = COGV_EPI_BIAS | COGV_EPI_DROPOUT | COGV_EPI_ABSMAX, F_FWD_GELU = COGV_EPI_BIAS | COGV_EPI_GELU;
-    if (p.splitk > 1) pp64_epilogue<T, -2>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
-    else if (p.out_f32) pp64_epilogue<T, -1>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
-    else if (p.flags == 0) pp64_epilogue<T, 0>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
-    else if (p.flags == COGV_EPI_BIAS) pp64_epilogue<T, COGV_EPI_BIAS>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
-    else if (p.flags == COGV_EPI_ACCUM) pp64_epilogue<T, COGV_EPI_ACCUM>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
-    else if (p.flags == F_FWD_DROP) pp64_epilogue<T, F_FWD_DROP>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
-    else if (p.flags == F_FWD_GELU) pp64_epilogue<T, F_FWD_GELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
-    else if (p.flags == (COGV_EPI_DGELU | COGV_EPI_COLSUM)) pp64_epilogue<T, COGV_EPI_DGELU | COGV_EPI_COLSUM>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
-    else if (p.flags == COGV_EPI_DGELU) pp64_epilogue<T, COGV_EPI_DGELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
-    else pp64_epilogue<T, -1>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax, nan, (done.m0 >> 7) + wr);
+    if (p.splitk > 1) pp64_epilogue<T, -2>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
+    else if (p.out_f32) pp64_epilogue<T, -1>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
+    else if (p.flags == 0) pp64_epilogue<T, 0>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
+    else if (p.flags == COGV_EPI_BIAS) pp64_epilogue<T, COGV_EPI_BIAS>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
+    else if (p.flags == COGV_EPI_ACCUM) pp64_epilogue<T, COGV_EPI_ACCUM>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
+    else if (p.flags == F_FWD_DROP) pp64_epilogue<T, F_FWD_DROP>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
+    else if (p.flags == F_FWD_GELU) pp64_epilogue<T, F_FWD_GELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
+    else if (p.flags == (COGV_EPI_DGELU | COGV_EPI_COLSUM)) pp64_epilogue<T, COGV_EPI_DGELU | COGV_EPI_COLSUM>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
+    else if (p.flags == COGV_EPI_DGELU) pp64_epilogue<T, COGV_EPI_DGELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
+    else pp64_epilogue<T, -1>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
     if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
-      float wmx = wave_max(amax);
-      const bool wnan = __any(nan);
-      if (lane == 0) atomic_max_nonneg(p.absmax, wnan ? __uint_as_float(0x7fc00000u) : wmx);
+      uint32_t wv = max(amax_pk & 0xffffu, amax_pk >> 16);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) wv = max(wv, (uint32_t)__shfl_xor((int)wv, o, 64));
+      if (lane == 0) atomic_max_nonneg(p.absmax, bits_to_f<T>((uint16_t)wv));
     }
     if ((COGV_EXP & 16) && p.out_f32 && threadIdx.x == 0) {
       // shader clock in MHz over this workgroup's lifetime so far (s_memrealtime ticks at 100 MHz)
@@ -1260,7 +1253,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   __shared__ float red[16];
   const size_t nvec = (size_t)p.M * (p.N / 8);
-  float amax = 0.f; bool nan = false;
+  uint32_t amax_pk = 0u;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
     const int m = (int)(i / (p.N / 8));
     const int n = (int)(i % (p.N / 8)) * 8;
@@ -1272,13 +1265,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
       v[0] += x0[0]; v[1] += x0[1]; v[2] += x0[2]; v[3] += x0[3];
       v[4] += x1[0]; v[5] += x1[1]; v[6] += x1[2]; v[7] += x1[3];
     }
-    const float a = epilogue8<T>(p, m, n, v);
-    if (a != a) nan = true; else amax = fmaxf(amax, a);
+    amax_pk = absmax_pk(amax_pk, epilogue8<T>(p, m, n, v));
   }
   if (p.flags & COGV_EPI_ABSMAX) {
-    float bm = block_max(amax, red);
-    const bool any_nan = __syncthreads_or(nan);
-    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, any_nan ? __uint_as_float(0x7fc00000u) : bm);
+    const float bm = absmax_pk_block<T>(amax_pk, reinterpret_cast<uint32_t*>(red));
+    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax, bm);
   }
 }
 

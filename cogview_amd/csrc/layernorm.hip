@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
       unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.beta) + col), b[v]);
     }
   }
-  float amax = 0.f; bool nan = false;
+  uint32_t amax_pk = 0u;               // running max of |output| bit patterns (absmax_pk)
   for (int row = wave_global; row < p.rows; row += nwaves) {
     float x[NV][8];
     float s = 0.f;
@@ -86,19 +86,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
         }
         const u32x4 ov = pack8<T>(o);
         *reinterpret_cast<u32x4*>(Y + (size_t)row * p.h + col) = ov;
-        if (p.absmax_out) {
-          float rr[8]; unpack8<T>(ov, rr);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { if (rr[i] != rr[i]) nan = true; else amax = fmaxf(amax, fabsf(rr[i])); }
-        }
+        amax_pk = absmax_pk8(amax_pk, ov);
       }
     }
   }
   if (p.absmax_out) {
-    __shared__ float red[16];
-    const float bm = block_max(amax, red);
-    const bool any_nan = __syncthreads_or(nan);
-    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax_out, any_nan ? __uint_as_float(0x7fc00000u) : bm);
+    __shared__ uint32_t red[16];
+    const float bm = absmax_pk_block<T>(amax_pk, red);
+    if (threadIdx.x == 0) atomic_max_nonneg(p.absmax_out, bm);
   }
 }
 
