@@ -184,6 +184,48 @@ def test_train_steps_vs_oracle(golden_dir, dtype):
         assert torch.equal(before, opt._master_flat)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_full_width_layer_vs_oracle(dtype):
+    """One layer at the 4B configuration's real width and length (h = 2560, 40 heads, 1088 positions; small vocabulary to
+    keep the head cheap): the shapes the generation-3 GEMM, the grouped weight gradients, the fused bias-gradient
+    epilogues, Sandwich-LN at 5 waves per row and attention at 17 key blocks actually run at in bench.py, against
+    the fp32 CPU oracle on the same (rounded) weights -- logits, loss and every parameter gradient."""
+    from cogview_amd import training
+    from cogview_amd.fp16 import FP16_Module
+    from cogview_amd.model import GPT2Model
+    L_, V_, H_, NH_, S_, B_ = 1, 2048, 2560, 40, 1088, 1
+    torch.manual_seed(7)
+    m = GPT2Model(L_, V_, H_, NH_, 0.0, 0.0, 0.0, S_ + 1, 0, False)
+    for n, p in m.named_parameters():                      # non-trivial LN affine / biases
+        if p.dim() == 1:
+            with torch.no_grad():
+                p.add_(0.05 * torch.randn_like(p))
+    model = FP16_Module(m.cuda(), dtype=dtype, keep_half_outputs=True)
+    g = torch.Generator().manual_seed(3)
+    tokens = torch.randint(0, V_, (B_, S_), generator=g)
+    labels = torch.randint(0, V_, (B_, S_), generator=g)
+    lmask = torch.ones(B_, S_)
+    pos = torch.arange(S_).unsqueeze(0).expand(B_, -1)
+    pr = {n: p.detach().float().cpu().clone().requires_grad_(True) for n, p in model.module.named_parameters()}
+    batch = (tokens.cuda(), labels.cuda(), lmask.cuda(), 0, pos.cuda())
+    logits, = model(tokens.cuda(), pos.cuda(), 0, None, None, 0)
+    lo = O.gpt2_forward(tokens, pos, O.build_mask(S_, S_), pr, L_, NH_)
+    e_log = rel(logits, lo.detach())
+    loss, _, _, _ = training.forward_step(batch, model, log=False)
+    l_ref = O.lm_loss(lo, labels, lmask)
+    assert abs(loss.item() - l_ref.item()) < 5e-3 * abs(l_ref.item())
+    loss.backward()
+    l_ref.backward()
+    worst, worst_n = 0.0, ""
+    for n, p in model.module.named_parameters():
+        e = rel(p.grad, pr[n].grad)
+        if e > worst:
+            worst, worst_n = e, n
+        assert e < GRAD_TOL[dtype], f"{n}: {e}"
+    print(f"[{dtype}] full-width layer: logits rel-L2 {e_log:.2e}, worst grad rel-L2 {worst:.2e} ({worst_n})")
+    assert e_log < LOGIT_TOL[dtype]
+
+
 def test_standalone_modules_autograd():
     """mpu.ColumnParallelLinear / RowParallelLinear / LayerNorm used on their own (model-parallel size 1)."""
     from cogview_amd import mpu
