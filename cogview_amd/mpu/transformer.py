@@ -200,6 +200,8 @@ class GPT2ParallelTransformer(torch.nn.Module):
                                          output_layer_init_method=output_layer_init_method, query_window=query_window,
                                          key_window_times=key_window_times, scale_normalization=True)
             for _ in range(num_layers)])
+        for i, layer in enumerate(self.layers):
+            layer._cogv_index = i              # backward defers weight gradients to groups of layers (functional.py)
         self.final_layernorm = LayerNorm(hidden_size, eps=layernorm_epsilon)
         self.rmask = None
         self.on_layer_backward_done = None      # set by the data-parallel wrapper to overlap the all-reduce

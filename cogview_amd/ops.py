@@ -201,10 +201,10 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
 
 
 def gemm_grouped(problems, trans_a=True, trans_b=True, accumulate=True):
-    """Up to four GEMMs of one layout in ONE persistent launch (cogv_gemm_grouped): `problems` is a list of
-    (a, b, out).  Used for the four weight gradients of a transformer layer, which fill the 256 CUs together.
+    """Up to 16 GEMMs of one layout in ONE persistent launch (cogv_gemm_grouped): `problems` is a list of
+    (a, b, out).  Used for the weight gradients of one or several transformer layers, which fill the 256 CUs together.
     Falls back to one cogv_gemm per problem when the library reports a shape the grouped kernel does not take."""
-    assert 1 <= len(problems) <= 4
+    assert 1 <= len(problems) <= 16
     lib = L.lib()
     descs = (L.GemmDesc * len(problems))()
     tiles, kmin, flops, nbytes = 0, None, 0.0, 0.0

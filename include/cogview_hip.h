@@ -84,9 +84,9 @@ int cogv_gemm_pick_splitk(int M, int N, int K);
 int cogv_gemm_colsum_rows(int M);            /* slabs of COGV_EPI_COLSUM partial sums: 2 * ceil(M / 256) */
 /* out[n] (+)= sum over `rows` partial rows; the second half of cogv_colsum, also used after COGV_EPI_COLSUM */
 int cogv_colsum_finalize(int dtype, const float* partial, int rows, int N, void* out, int accumulate, void* stream);
-/* Up to 4 GEMMs of one dtype and layout (same trans_a / trans_b) in ONE persistent launch: the weight gradients
- * dW = dY^T X of the four linears of a layer (autograd of mpu/layers.py:243,319) fill the 256 CUs together where
- * each alone would leave a partial last round.  COGV_ERR_UNSUPPORTED when a problem does not fit the 256x256x64
+/* Up to 16 GEMMs of one dtype and layout (same trans_a / trans_b) in ONE persistent launch: the weight gradients
+ * dW = dY^T X of the four linears of a layer -- or of several layers -- (autograd of mpu/layers.py:243,319) fill the
+ * 256 CUs together where each alone would leave a partial last round.  COGV_ERR_UNSUPPORTED when a problem does not fit the 256x256x64
  * kernel (M, N >= 256, K % 64 == 0): issue them one by one then.  Split-K as in cogv_gemm, per problem. */
 int cogv_gemm_grouped(const cogv_gemm_desc* descs, int count, void* stream);
 /* Note: the persistent GEMM kernel distributes tiles through per-XCD atomic work queues; the library keeps their
