@@ -288,3 +288,97 @@ def test_data_parallel_wrapper_on_one_gpu(golden_dir):
     assert torch.equal(arena.grad[n_word:], want[n_word:])
     assert rel(arena.grad[:n_word], want[:n_word]) < 2e-3
     assert not ddp.needs_reduction and ddp._pending == []
+
+
+# ------------------------------------------------------------------------------------------------ two ranks, one GPU
+def _dp2_worker(rank, world, port, golden_dir, ret):
+    """One data-parallel rank: half of the golden batch, the bucketed / overlapped gradient exchange over gloo on
+    CUDA tensors (two processes share cuda:0), one full optimizer step."""
+    import sys
+    import traceback
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+        torch.cuda.set_device(0)
+        from cogview_amd import mpu, training
+        from cogview_amd.fp16 import FP16_Optimizer
+        from cogview_amd.model import PyTorchDistributedDataParallel, gpt2_get_params_for_weight_decay_optimization
+        from cogview_amd.optim import FusedAdam
+        mpu.initialize_model_parallel(1)
+        g = _golden(golden_dir)
+        S_, B_ = int(g["cfg"][5]), int(g["cfg"][6])
+        half = B_ // world
+        sl = slice(rank * half, (rank + 1) * half)
+        model = _build(g, torch.float16)
+        ddp = PyTorchDistributedDataParallel(model, process_group=mpu.get_data_parallel_group(), bucket_layers=1)
+        assert ddp.overlap and len(ddp._buckets) == 2
+        groups = gpt2_get_params_for_weight_decay_optimization(model.module)
+        for grp in groups:
+            for p in grp["params"]:
+                if not hasattr(p, "model_parallel"):
+                    p.model_parallel = False
+        opt = FP16_Optimizer(FusedAdam(groups, lr=1e-3, weight_decay=0.01), dynamic_loss_scale=True,
+                             dynamic_loss_args={"init_scale": 2 ** 10, "scale_window": 100, "min_scale": 1, "delayed_shift": 1})
+        pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(half, -1)
+        ones = torch.ones_like(g["loss_mask"][sl]).cuda()          # equal mask sums: mean of rank means == global mean
+        batch = (g["tokens"][sl].cuda(), g["labels"][sl].cuda(), ones, 0, pos)
+        loss, _, _, _ = training.forward_step(batch, ddp, log=False, world_size=world)
+        training.backward_step(opt, ddp, loss, 1.0)
+        torch.cuda.synchronize()
+        grads = (model.module._cogv_arena.grad.detach().float() / opt.loss_scale).cpu()   # averaged over the ranks
+        opt.step()
+        torch.cuda.synchronize()
+        assert not opt.overflow
+        flat = model.module._cogv_arena.data.detach().float().cpu()
+        parts = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(parts, flat)
+        assert torch.equal(parts[0], parts[1]), "replicas diverged after one data-parallel step"
+        ret[rank] = ("ok", grads if rank == 0 else None)
+        dist.destroy_process_group()
+    except Exception:
+        ret[rank] = (traceback.format_exc(), None)
+
+
+def test_two_rank_data_parallel_step_on_one_gpu(golden_dir):
+    """Two data-parallel processes sharing the GPU (gloo moves the CUDA gradient slices): bucketed all-reduce
+    overlapped with backward, overflow sync, clip and fused AdamW.  Both replicas must end bit-identical, and the
+    averaged gradients must equal (to fp16 round-off) those of ONE process on the whole batch."""
+    import socket
+    import torch.multiprocessing as mp
+    from cogview_amd import mpu, training
+    from cogview_amd.fp16 import FP16_Optimizer
+    from cogview_amd.model import gpt2_get_params_for_weight_decay_optimization
+    from cogview_amd.optim import FusedAdam
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_dp2_worker, args=(r, 2, port, golden_dir, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+        for r in range(2):
+            assert ret.get(r) is not None and ret[r][0] == "ok", f"rank {r}: {ret.get(r)}"
+        dp_grads = ret[0][1]
+    # single process, whole batch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29593")
+        dist.init_process_group("nccl", init_method="env://", world_size=1, rank=0)
+    if not mpu.model_parallel_is_initialized():
+        mpu.initialize_model_parallel(1)
+    g = _golden(golden_dir)
+    S_, B_ = int(g["cfg"][5]), int(g["cfg"][6])
+    model = _build(g, torch.float16)
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    batch = (g["tokens"].cuda(), g["labels"].cuda(), torch.ones_like(g["loss_mask"]).cuda(), 0, pos)
+    loss, _, _, _ = training.forward_step(batch, model, log=False)
+    (loss * 1024.0).backward()
+    one = (model.module._cogv_arena.grad.detach().float() / 1024.0).cpu()
+    e = rel(dp_grads, one)
+    print(f"two-rank averaged gradients vs one-rank whole batch, rel-L2: {e:.2e}")
+    assert e < 1e-2
