@@ -122,11 +122,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
+    # COGV_BENCH_ONE_DEVICE=1 (development only): all ranks share cuda:0 and talk over gloo -- exercises the N > 1
+    # control flow of this script on a one-GPU box; RCCL refuses two ranks on one device.  Never set by the driver.
+    one_dev = os.environ.get("COGV_BENCH_ONE_DEVICE") == "1"
+    torch.cuda.set_device(0 if one_dev else local_rank)
     import torch.distributed as dist
     if not dist.is_initialized():
         if world > 1:
-            dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+            dist.init_process_group("gloo" if one_dev else "nccl", init_method="env://", world_size=world, rank=rank)
         else:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29577")
