@@ -8,13 +8,18 @@
 //   dgrad    dX = dY W             autograd of the above                            -> transA=0, transB=1
 //   wgrad    dW = dY^T X           autograd of the above                            -> transA=1, transB=1
 //
-// "trans" means the operand is stored with the contraction index as the SLOW dimension
-// (A stored [K][M], B stored [K][N]); such tiles are transposed in registers while being staged to LDS
-// so that every MFMA fragment read is one conflict-free ds_read_b128.
+// "trans" means the operand is stored with the contraction index as the SLOW dimension (A stored [K][M], B stored
+// [K][N]): dgrad's W and both weight-gradient operands.  No transposed copies exist in HBM.
 //
-// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16.
-// LDS: 2 stages x (A 16 KiB + B 16 KiB) = 64 KiB (2 blocks / CU); the fp32 C tile reuses the same 64 KiB
-// for a coalesced, fused epilogue (bias, GeLU, dGeLU, dropout, accumulate, abs-max for Sandwich-LN).
+// Three kernels, newest first (dispatch: launch_gemm):
+//   generation 3  gemm_pp64_kernel   256x256x64 tiles, 8 waves ping-pong, v_mfma_f32_16x16x32, LDS-DMA granule ring,
+//                                    persistent with per-XCD work queues, up to 16 problems per launch.  Default.
+//   generation 2  gemm_glds_kernel   256x128x32 tiles, 4 waves, 3-stage LDS-DMA ring, 2 workgroups per CU.
+//                                    For M or N < 256 and operands >= 4 GiB.
+//   generation 1  gemm_kernel        128x128x64 tiles, register-staged with register transposes.  For K % 64 != 0 and
+//                                    other unaligned shapes.
+// All share the fused epilogue (epilogue8): bias, GeLU (+ stored pre-activation), dGeLU, dropout, += C, abs-max for
+// Sandwich-LN, and (generation 3) the bias-gradient column sums of the output.
 #include "common.cuh"
 #include "cogview_hip.h"
 
@@ -499,22 +504,10 @@ constexpr int glds_min_waves(int nw, int ring_bytes) {
 }
 
 // per-wave tile = (32*MI) x (32*NJ); workgroup tile = (WM*32*MI) x (WN*32*NJ); WM*WN waves
-//
-// PP = true ("ping-pong", 8 waves, one workgroup per CU, NST-stage ring): the two halves of the workgroup run
-// one barrier apart.  A workgroup's waves w and w + 4 share a SIMD, so on every SIMD one wave is in its READ
-// phase (all fragment reads of a k-tile + the DMA issue of tile kt + NST - 1) while the other is in its MFMA phase
-// (16 back-to-back MFMAs at raised priority); two barriers per k-tile swap the roles.  Ordering argument (global
-// barrier index g; group 0 passes B1(kt) = 2kt, B2(kt) = 2kt + 1, group 1 one later):
-//   RAW  every wave certifies ITS pieces of tile kt+1 (counted vmcnt) before its B2(kt) <= 2kt + 2, and nobody
-//        reads tile kt+1 before passing 2kt + 2;
-//   WAR  tile kt + NST - 1 overwrites the stage of tile kt - 1, is issued after B1(kt) >= 2kt, and every read of
-//        tile kt - 1 was retired (lgkmcnt(0)) before that wave's B2(kt-1) <= 2kt.
-template <typename T, bool AT, bool BT, int WM, int WN, int MI, int NJ, int BKT, int NST = 3, bool PP = false>
-__global__ __launch_bounds__(WM * WN * 64, glds_min_waves(WM * WN, NST * (WM * 32 * MI + WN * 32 * NJ) * 2 * BKT))
+template <typename T, bool AT, bool BT, int WM, int WN, int MI, int NJ, int BKT>
+__global__ __launch_bounds__(WM * WN * 64, glds_min_waves(WM * WN, 3 * (WM * 32 * MI + WN * 32 * NJ) * 2 * BKT))
 void gemm_glds_kernel(const GemmArgs p) {
-  constexpr int NW = WM * WN, TBM = WM * 32 * MI, TBN = WN * 32 * NJ;
-  static_assert(!PP || (NW == 8 && NST >= 3), "ping-pong schedule: 8 waves, >= 3 stages");
-  static_assert(PP || NST == 3, "the single-barrier schedule uses a 3-stage ring");
+  constexpr int NW = WM * WN, TBM = WM * 32 * MI, TBN = WN * 32 * NJ, NST = 3;
   constexpr int A_BYTES = TBM * 2 * BKT, B_BYTES = TBN * 2 * BKT, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PER = A_BYTES / 1024 / NW, B_PER = B_BYTES / 1024 / NW;      // 1-KiB DMA pieces per wave per k-tile
   constexpr int LPT = A_PER + B_PER;
@@ -618,93 +611,6 @@ void gemm_glds_kernel(const GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) trB[j] = BT ? tr_addr<TBN * 2>(smem + A_BYTES, wn + 32 * j, lane) : 0u;
 
-  if constexpr (PP) {
-    constexpr int D = NST - 1;                 // prefetch distance in k-tiles
-#pragma unroll
-    for (int t = 0; t < D; ++t) issue(min(t, nk - 1), t);
-    wait_vmcnt<(D - 1) * LPT>();               // this wave's pieces of tile 0 have landed
-    __builtin_amdgcn_s_barrier();              // ... and everybody's
-    const int grp = wave / (NW / 2);
-    if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger
-    int st = 0;
-    uint32_t nA[MI], nB[NJ];                   // natural-region read addresses (stage 0, k-step 0)
-#pragma unroll
-    for (int i = 0; i < MI; ++i) nA[i] = (uint32_t)(uintptr_t)smem + nat_off<BKT>(wm + 32 * i + fr, fg);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) nB[j] = (uint32_t)(uintptr_t)(smem + A_BYTES) + nat_off<BKT>(wn + 32 * j + fr, fg);
-    for (int kt = 0; kt < nk; ++kt) {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();            // B1: READ phase
-      __builtin_amdgcn_sched_barrier(0);
-      const uint32_t soff = (uint32_t)(st * STAGE);
-      TrRaw ta[KS][MI], tb[KS][NJ];
-      u32x4 na[KS][MI], nb[KS][NJ];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (COGV_EXP & 2) break;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (BT) tr_issue<TBN * 2>(trB[j] + soff, ks, tb[ks][j]);
-          else nat_issue((nB[j] + soff) ^ (uint32_t)(ks << 5), nb[ks][j]);
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          if (AT) tr_issue<TBM * 2>(trA[i] + soff, ks, ta[ks][i]);
-          else nat_issue((nA[i] + soff) ^ (uint32_t)(ks << 5), na[ks][i]);
-        }
-      }
-      {
-        const int kpf = min(kt + D, nk - 1);
-        const int pst = st == 0 ? NST - 1 : st - 1;        // == (st + D) % NST
-        if (!(COGV_EXP & 1)) issue(kpf, pst);
-      }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          if (AT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[ks][i].lo), "+v"(ta[ks][i].hi) : : "memory");
-          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na[ks][i]) : : "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (BT) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[ks][j].lo), "+v"(tb[ks][j].hi) : : "memory");
-          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nb[ks][j]) : : "memory");
-        }
-      }
-      wait_vmcnt<(D - 1) * LPT>();             // this wave's pieces of tile kt+1 have landed
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();            // B2: MFMA phase
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        typename HT<T>::v8 fa[MI], fb[NJ];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          if (AT) fa[i] = tr_pack<T>(ta[ks][i]); else __builtin_memcpy(&fa[i], &na[ks][i], 16);
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (BT) fb[j] = tr_pack<T>(tb[ks][j]); else __builtin_memcpy(&fb[j], &nb[ks][j], 16);
-        }
-        if (COGV_EXP & 4) {
-#pragma unroll
-          for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(fa[i]));
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(fb[j]));
-          continue;
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = HT<T>::mfma32(fa[i], fb[j], acc[i][j]);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      st = (st == NST - 1) ? 0 : st + 1;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (grp == 0) __builtin_amdgcn_s_barrier();            // even out the barrier count
-  } else {
   issue(0, 0);
   issue(nk > 1 ? 1 : 0, 1);
   int st = 0;
@@ -794,7 +700,6 @@ void gemm_glds_kernel(const GemmArgs p) {
       if (ks < KS - 1 && (AT || BT)) { __builtin_amdgcn_sched_barrier(0); land(nxt); }
     }
     st = (st == 2) ? 0 : st + 1;
-  }
   }
   wait_vmcnt<0>();   // drain the (redundant) tail prefetches before the ring is reused
   __syncthreads();   // every wave is done reading the ring: reuse it for the fp32 C tile
@@ -1274,26 +1179,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
-template <typename T, bool AT, bool BT, int WM, int WN, int MI, int NJ, int BKT, int NST = 3, bool PP = false>
+template <typename T, bool AT, bool BT, int WM, int WN, int MI, int NJ, int BKT>
 void launch_glds(GemmArgs& a, hipStream_t st) {
   constexpr int TBM = WM * 32 * MI, TBN = WN * 32 * NJ;
-  constexpr int shmem = NST * (TBM + TBN) * 2 * BKT;
+  constexpr int shmem = 3 * (TBM + TBN) * 2 * BKT;
   a.tiles_m = (a.M + TBM - 1) / TBM; a.tiles_n = (a.N + TBN - 1) / TBN;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, AT, BT, WM, WN, MI, NJ, BKT, NST, PP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, AT, BT, WM, WN, MI, NJ, BKT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<T, AT, BT, WM, WN, MI, NJ, BKT, NST, PP>), dim3(a.tiles_m * a.tiles_n, a.splitk),
+  hipLaunchKernelGGL((gemm_glds_kernel<T, AT, BT, WM, WN, MI, NJ, BKT>), dim3(a.tiles_m * a.tiles_n, a.splitk),
                      dim3(WM * WN * 64), shmem, st, a);
 }
-template <typename T, int WM, int WN, int MI, int NJ, int BKT, int NST = 3, bool PP = false>
+template <typename T, int WM, int WN, int MI, int NJ, int BKT>
 void launch_glds_layout(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
-  if (!d->trans_a && !d->trans_b) launch_glds<T, false, false, WM, WN, MI, NJ, BKT, NST, PP>(a, st);
-  else if (!d->trans_a && d->trans_b) launch_glds<T, false, true, WM, WN, MI, NJ, BKT, NST, PP>(a, st);
-  else if (d->trans_a && d->trans_b) launch_glds<T, true, true, WM, WN, MI, NJ, BKT, NST, PP>(a, st);
-  else launch_glds<T, true, false, WM, WN, MI, NJ, BKT, NST, PP>(a, st);
+  if (!d->trans_a && !d->trans_b) launch_glds<T, false, false, WM, WN, MI, NJ, BKT>(a, st);
+  else if (!d->trans_a && d->trans_b) launch_glds<T, false, true, WM, WN, MI, NJ, BKT>(a, st);
+  else if (d->trans_a && d->trans_b) launch_glds<T, true, true, WM, WN, MI, NJ, BKT>(a, st);
+  else launch_glds<T, true, false, WM, WN, MI, NJ, BKT>(a, st);
 }
 
 int num_cus() {
@@ -1367,16 +1272,15 @@ int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
                        (!d->trans_b || (a.N & 7) == 0) && d->kernel_variant != 1;
   if ((d->flags & COGV_EPI_COLSUM) && !glds_ok) return COGV_ERR_UNSUPPORTED;
   if (glds_ok) {
-    // variant 2: 256x128x64, 8 waves (64x64 each), one workgroup per CU   -- best for long-K NT (measured)
-    // variant 3: 256x128x32, 4 waves (128x64 each), two workgroups per CU -- default: the two workgroups' barrier
-    //            phases interleave on each SIMD, and a fat wave reads 6 fragments per 8 MFMAs instead of 4 per 4
-    // variant 4: 128x128x32, 4 waves (64x64 each), three workgroups per CU
-    // variant 5: 256x256x32, 8 waves (128x64 each), one workgroup per CU -- least L2->LDS traffic per flop: long-K NT
-    // variant 9: generation 3 (256x256x64 ping-pong, persistent, 16x16x32 MFMAs) -- default whenever its 256 tile
+    // variant 3: generation 2 -- 256x128x32, 4 waves (128x64 each), two workgroups per CU (M or N < 256, huge operands)
+    // variant 9: generation 3 -- 256x256x64 ping-pong, persistent, 16x16x32 MFMAs: default whenever its 256 tile
     //            slots per round are filled about as well as variant 3's 512
+    // (the intermediate designs -- 256x128x64 / 128x128x32 / 256x256x32 rings, ping-pong on 32-deep tiles -- measured
+    //  within +-5 % of variant 3 and were removed; DESIGN.md section 4 keeps the numbers)
     int variant = d->kernel_variant;
     const size_t a_span = (size_t)(d->trans_a ? a.K : a.M) * a.lda * 2, b_span = (size_t)(d->trans_b ? a.K : a.N) * a.ldb * 2;
     const bool v9_ok = a.M >= 256 && a.N >= 256 && a_span < (1ull << 32) && b_span < (1ull << 32);   // 32-bit DMA offsets
+    if (variant != 0 && variant != 3 && variant != 9) variant = 0;
     if ((d->flags & COGV_EPI_COLSUM) && (!v9_ok || (variant != 0 && variant != 9))) return COGV_ERR_UNSUPPORTED;
     if (d->flags & COGV_EPI_COLSUM) variant = 9;
     if (variant == 9 && !v9_ok) variant = 0;
@@ -1391,11 +1295,6 @@ int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
       }
     }
     if (variant == 3) launch_glds_layout<T, 2, 2, 4, 2, 32>(d, a, st);
-    else if (variant == 5) launch_glds_layout<T, 2, 4, 4, 2, 32>(d, a, st);   // 256x256x32, 8 fat waves, one WG per CU
-    else if (variant == 4) launch_glds_layout<T, 2, 2, 2, 2, 32>(d, a, st);
-    else if (variant == 6) launch_glds_layout<T, 2, 4, 4, 2, 32, 4, true>(d, a, st);   // 256x256x32 ping-pong, 4-stage ring
-    else if (variant == 7) launch_glds_layout<T, 2, 4, 4, 2, 32, 3, true>(d, a, st);   // same, 3-stage ring
-    else if (variant == 8) launch_glds_layout<T, 2, 4, 4, 1, 64, 3, true>(d, a, st);   // 256x128x64 ping-pong (128-B rows)
     else if (variant == 9) {                                                            // generation 3 (operands < 4 GiB)
       GroupArgs ga; ga.count = 1; ga.g[0] = a;
       const int rc = launch_pp64_layout<T>(d->trans_a, d->trans_b, ga, st);

@@ -73,7 +73,7 @@ typedef struct cogv_gemm_desc {
   float* absmax;        /* device scalar, caller zeroes it */
   float dropout_p; uint64_t seed; uint64_t stream_id;
   int splitk;           /* >1: contraction split over this many workgroups + reduce pass */
-  int kernel_variant;   /* 0 = auto; 1 = generation-1 (register-staged) kernel; 2/3/4 = DMA kernel 256x128x64 (8 waves) / 256x128x32 (4 fat waves, 2 WG/CU) / 128x128x32 (3 WG/CU) */
+  int kernel_variant;   /* 0 = auto; 1 = generation 1 (register-staged 128x128x64); 3 = generation 2 (256x128x32 LDS-DMA ring); 9 = generation 3 (256x256x64 ping-pong, persistent) */
   void* workspace; size_t workspace_bytes;   /* >= cogv_gemm_workspace_bytes() when splitk > 1 */
   float* colsum_partial;                     /* COGV_EPI_COLSUM: [cogv_gemm_colsum_rows(M)][N] fp32, fully written */
 } cogv_gemm_desc;
