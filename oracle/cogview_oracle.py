@@ -57,6 +57,60 @@ def standard_attention(q, k, v, mask, drop_mask=None):
     return torch.matmul(probs, v)
 
 
+def sparse_rmask(s, w, times):
+    """Mask used to pick the visible pivots in sparse training (mpu/sparse_transformer.py:491-496): position q may
+    use key j as a PIVOT iff j lies before the window of q's block, i.e. j < (q // w - times + 1) * w
+    (keys inside the window are reached through the window branch instead)."""
+    qi = torch.arange(s).unsqueeze(1)
+    kj = torch.arange(s).unsqueeze(0)
+    return (kj < (qi // w - times + 1) * w).to(torch.float32)
+
+
+def sparse_attention(q, k, v, pivot_idx, pivot_attention_mask, w=128, times=6):
+    """CogView sparse attention, training form (mpu/sparse_transformer.py:675-725), restated per query:
+        keys of query i  =  the n_piv pivot keys (gathered; masked; every pivot score gets + log(s // n_piv))
+                          U the w*times window slots ending with i's block: slot c of block g is key
+                            (g - times + 1) * w + c (zero padding in front of the sequence).
+        window slot c of the query with in-block offset r is visible iff c <= r + w*(times-1); masked slots score
+        -10000; for the first times-1 blocks the padding slots take ANOTHER -10000 (:710-711 subtracts it from the
+        already masked value, so those slots score -20000).
+      joint softmax over the n_piv + w*times scores, context = probs @ [pivot values ; window values].
+    q, k, v [b, nh, s, hn] with s % w == 0; pivot_idx [b, n_piv]; pivot_attention_mask [b, s, n_piv]."""
+    b, nh, s, hn = q.shape
+    n_piv = pivot_idx.shape[1]
+    scale = 1.0 / math.sqrt(hn)
+    idx = pivot_idx.view(b, 1, n_piv, 1).expand(b, nh, n_piv, hn)
+    pk, pv = torch.gather(k, 2, idx), torch.gather(v, 2, idx)
+    pm = pivot_attention_mask.unsqueeze(1)
+    sp = torch.einsum("bhqd,bhpd->bhqp", q, pk) * (pm * scale) - 10000.0 * (1.0 - pm) + math.log(s // n_piv)
+    # window: slot c of query i is key (i // w - times + 1) * w + c; negative keys are padding (zero vectors)
+    qi = torch.arange(s)
+    c = torch.arange(w * times)
+    key = ((qi // w - times + 1) * w).unsqueeze(1) + c.unsqueeze(0)             # [s, w*times]
+    pad = key < 0
+    kw = k[:, :, key.clamp(min=0)] * (~pad).view(1, 1, s, w * times, 1)         # [b, nh, s, w*times, hn]
+    vw = v[:, :, key.clamp(min=0)] * (~pad).view(1, 1, s, w * times, 1)
+    vis = (c.unsqueeze(0) <= (qi % w).unsqueeze(1) + w * (times - 1)).to(q.dtype)
+    sw = torch.einsum("bhqd,bhqcd->bhqc", q, kw) * (vis * scale) - 10000.0 * (1.0 - vis)
+    sw = sw - 10000.0 * pad.to(q.dtype)
+    probs = torch.softmax(torch.cat((sp, sw), dim=-1), dim=-1)
+    return torch.einsum("bhqp,bhpd->bhqd", probs[..., :n_piv], pv) + torch.einsum("bhqc,bhqcd->bhqd", probs[..., n_piv:], vw)
+
+
+def sparse_attention_inference(q, k, v, pivot_and_window_idx):
+    """mpu/sparse_transformer.py:727-750: the sq queries are the last sq keys; they attend the gathered
+    (pivot + window) keys, causally among themselves (the last sq gathered keys are the queries' own positions)."""
+    b, nh, sq, hn = q.shape
+    n = pivot_and_window_idx.shape[1]
+    idx = pivot_and_window_idx.view(b, 1, n, 1).expand(b, nh, n, hn)
+    gk, gv = torch.gather(k, 2, idx), torch.gather(v, 2, idx)
+    sc = torch.einsum("bhqd,bhpd->bhqp", q / math.sqrt(hn), gk)
+    if sq > 1:
+        causal = torch.triu(torch.full((sq, sq), -10000.0, dtype=q.dtype), diagonal=1)
+        sc = torch.cat((sc[..., :-sq], sc[..., -sq:] + causal), dim=-1)
+    return torch.einsum("bhqp,bhpd->bhqd", torch.softmax(sc, dim=-1), gv)
+
+
 def self_attention(x, ltor_mask, p, prefix, n_heads, attn_drop_mask=None, out_drop_mask=None, mem=None):
     """GPT2ParallelSelfAttention.forward, mpu/sparse_transformer.py:123-169 (model-parallel size 1)."""
     b, s, h = x.shape
