@@ -223,8 +223,18 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* partia
   T* out = reinterpret_cast<T*>(set == 0 ? dgamma : set == 1 ? dbeta : colsum);
   __shared__ float red[16][64];
   float s = 0.f;
-  if (c < h && out)
-    for (int b = part; b < nblk; b += 16) s += partial[((size_t)b * 3 + set) * h + c];
+  if (c < h && out) {
+    // independent partial sums: the loads of one thread are all in flight together (a rolled loop of dependent
+    // adds made this a chain of ~32 memory latencies)
+    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = part;
+    for (; b + 7 * 16 < nblk; b += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] += partial[((size_t)(b + 16 * u) * 3 + set) * h + c];
+    }
+    for (; b < nblk; b += 16) t[0] += partial[((size_t)b * 3 + set) * h + c];
+    s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  }
   red[part][threadIdx.x & 63] = s;
   __syncthreads();
   if (part == 0 && c < h && out) {
