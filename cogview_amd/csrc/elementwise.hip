@@ -221,13 +221,16 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial,
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  float s0 = 0.f, s1 = 0.f;
+  float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // independent sums: all loads of a thread in flight together
   if (c < N) {
     int b = part;
-    for (; b + 4 < nslab; b += 8) { s0 += partial[(size_t)b * N + c]; s1 += partial[(size_t)(b + 4) * N + c]; }
-    if (b < nslab) s0 += partial[(size_t)b * N + c];
+    for (; b + 7 * 4 < nslab; b += 8 * 4) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] += partial[(size_t)(b + 4 * u) * N + c];
+    }
+    for (; b < nslab; b += 4) t[0] += partial[(size_t)b * N + c];
   }
-  red[part][cl] = s0 + s1;
+  red[part][cl] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
   __syncthreads();
   if (part == 0 && c < N) {
     float s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
