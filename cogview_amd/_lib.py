@@ -50,6 +50,7 @@ class AttnDesc(C.Structure):
         ("q_rs", C.c_int), ("k_rs", C.c_int), ("v_rs", C.c_int), ("o_rs", C.c_int),
         ("do_rs", C.c_int), ("dq_rs", C.c_int), ("dk_rs", C.c_int), ("dv_rs", C.c_int),
         ("colsum_partial", C.c_void_p),
+        ("kv_index", C.c_void_p), ("kv_index_bs", C.c_longlong),
     ]
 
 

@@ -43,6 +43,7 @@ struct AttnArgs {
   const void* dout; void* dq; void* dk; void* dv;              // backward
   float* lse; float* dvec;                                     // [b][H][s_q]
   float* colsum_ws;                                            // optional [B * nblk][3 * H * 64]: sums of dq | dk | dv
+  const int* kv_index; long long kv_index_bs;                  // forward only, optional: key slot j reads K/V row kv_index[b][j]
   long long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs; // batch strides (elements)
   int q_rs, k_rs, v_rs, o_rs, do_rs, dq_rs, dk_rs, dv_rs;       // row strides (elements)
   int B, H, s_q, s_k, sep_k;   // sep_k: keys [0, sep_k) visible to every query
@@ -62,13 +63,18 @@ __device__ __forceinline__ int aswz(int row) { return (((row >> 1) & 1) << 2) | 
 // DMA of one tile: 8 pieces of 1 KiB (8 rows each); wave w issues pieces w and w+4.  Rows beyond `nrows` are
 // clamped to the last valid row (finite data; every use of such a row is masked out by the kernels).
 template <typename T>
-__device__ __forceinline__ void dma_tile(const T* base, long long rs, int row0, int nrows, char* lds, int wave, int lane) {
+__device__ __forceinline__ void dma_tile(const T* base, long long rs, int row0, int nrows, char* lds, int wave, int lane,
+                                         const int* lds_index = nullptr) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int piece = wave + 4 * i;
     const int row = piece * 8 + (lane >> 3);
     const int c = (lane & 7) ^ aswz(row);
-    const int gr = min(row0 + row, nrows - 1);
+    int gr = min(row0 + row, nrows - 1);
+    if (lds_index) {      // gathered keys: slot -> row through the index table staged in LDS (asm read: no vmcnt drain)
+      const uint32_t a = (uint32_t)(uintptr_t)(lds_index + gr);
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(gr) : "v"(a) : "memory");
+    }
     __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + (long long)gr * rs + c * 8), (lds_void_t*)(lds + piece * 1024), 16, 0, 0);
   }
 }
@@ -287,9 +293,18 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   const uint32_t loff[2] = {tr_lane_off(0, lane) ^ tr_lane_fix(lane), tr_lane_off(1, lane) ^ tr_lane_fix(lane)};
   const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
 
+  // gathered form (sparse_attention_inference, mpu/sparse_transformer.py:727-750): key slot j is row kv_index[b][j] of
+  // K and V; the table (<= 4096 slots) is staged once behind the ring
+  int* lidx = nullptr;
+  if (p.kv_index) {
+    lidx = reinterpret_cast<int*>(smem + 3 * STAGE);
+    const int* gi = p.kv_index + (long long)b * p.kv_index_bs;
+    for (int i = threadIdx.x; i < p.s_k; i += NT) lidx[i] = gi[i];
+    __syncthreads();
+  }
   auto issue = [&](int kb, int st) {
-    dma_tile<T>(K, p.k_rs, kb * 64, p.s_k, smem + st * STAGE, wave, lane);
-    dma_tile<T>(V, p.v_rs, kb * 64, p.s_k, smem + st * STAGE + TILE, wave, lane);
+    dma_tile<T>(K, p.k_rs, kb * 64, p.s_k, smem + st * STAGE, wave, lane, lidx);
+    dma_tile<T>(V, p.v_rs, kb * 64, p.s_k, smem + st * STAGE + TILE, wave, lane, lidx);
   };
   if (nkb > 0) { issue(0, 0); issue(nkb > 1 ? 1 : 0, 1); }
   int st = 0;
@@ -751,7 +766,7 @@ int fill_args(const cogv_attn_desc* d, AttnArgs& a) {
   if (d->B <= 0 || d->H <= 0 || d->s_q <= 0 || d->s_k <= 0 || d->s_k < d->s_q) return COGV_ERR_ARG;
   if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return COGV_ERR_ARG;
   a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o; a.dout = d->dout; a.dq = d->dq; a.dk = d->dk; a.dv = d->dv;
-  a.lse = d->lse; a.dvec = d->dvec; a.colsum_ws = nullptr;
+  a.lse = d->lse; a.dvec = d->dvec; a.colsum_ws = nullptr; a.kv_index = nullptr; a.kv_index_bs = 0;
   a.q_bs = d->q_bs; a.k_bs = d->k_bs; a.v_bs = d->v_bs; a.o_bs = d->o_bs; a.do_bs = d->do_bs;
   a.dq_bs = d->dq_bs; a.dk_bs = d->dk_bs; a.dv_bs = d->dv_bs;
   a.q_rs = d->q_rs; a.k_rs = d->k_rs; a.v_rs = d->v_rs; a.o_rs = d->o_rs; a.do_rs = d->do_rs;
@@ -783,7 +798,12 @@ extern "C" int cogv_attention_fwd(const cogv_attn_desc* d, void* stream) {
   if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs) & 7) return COGV_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((a.s_q + 127) / 128, a.H, a.B);
-  const int sh = 3 * 2 * TILE;
+  int sh = 3 * 2 * TILE;
+  if (d->kv_index) {
+    if (a.s_k > 4096) return COGV_ERR_UNSUPPORTED;
+    a.kv_index = d->kv_index; a.kv_index_bs = d->kv_index_bs;
+    sh += ((a.s_k * 4 + 15) / 16) * 16;
+  }
   if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), grid, dim3(NT), sh, st, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, dim3(NT), sh, st, a);
   return cogv_check_launch();
@@ -794,6 +814,7 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   int rc = fill_args(d, a);
   if (rc) return rc;
   if (!a.q || !a.k || !a.v || !a.o || !a.dout || !a.dq || !a.dk || !a.dv || !a.lse || !a.dvec) return COGV_ERR_ARG;
+  if (d->kv_index) return COGV_ERR_UNSUPPORTED;          // the gathered form is inference only
   if (d->colsum_partial) {
     if (d->s_q != d->s_k || ((uintptr_t)d->colsum_partial & 15)) return COGV_ERR_ARG;
     a.colsum_ws = d->colsum_partial;

@@ -45,6 +45,7 @@ def gelu(x):
 
 
 standard_attention = F_.standard_attention
+sparse_attention_inference = F_.sparse_attention_inference      # mpu/sparse_transformer.py:727-750 (forward only)
 
 
 class _Dropout(torch.nn.Module):
@@ -85,16 +86,21 @@ class GPT2ParallelSelfAttention(torch.nn.Module):
         return tensor.view(*shape).permute(0, 2, 1, 3)
 
     def forward(self, hidden_states, ltor_mask, pivot_idx=None, is_sparse=0, mem=None):
-        if is_sparse:
-            raise NotImplementedError("sparse attention is not implemented yet (SURVEY.md section 8f, item 1)")
+        if int(is_sparse) == 1:
+            raise NotImplementedError("sparse attention TRAINING is not implemented yet (SURVEY.md section 8f, item 1); "
+                                      "the inference form (is_sparse=2) and dense attention are")
         query_length = hidden_states.size(1)
         src = hidden_states if mem is None else torch.cat((mem, hidden_states), 1)
         mixed = self.query_key_value(src)
         q, k, v = split_tensor_along_last_dim(mixed, 3)
         if mem is not None:
             q = q[:, -query_length:]
-        ctx = standard_attention(self._transpose_for_scores(q), self._transpose_for_scores(k),
-                                 self._transpose_for_scores(v), ltor_mask, self.attention_dropout)
+        if int(is_sparse) == 2:          # mpu/sparse_transformer.py:149-150: pivot_idx carries pivots + trailing window
+            ctx = sparse_attention_inference(self._transpose_for_scores(q), self._transpose_for_scores(k),
+                                             self._transpose_for_scores(v), pivot_idx)
+        else:
+            ctx = standard_attention(self._transpose_for_scores(q), self._transpose_for_scores(k),
+                                     self._transpose_for_scores(v), ltor_mask, self.attention_dropout)
         ctx = ctx.permute(0, 2, 1, 3).contiguous()
         ctx = ctx.view(*ctx.size()[:-2], self.hidden_size_per_partition)
         return self.output_dropout(self.dense(ctx))
@@ -141,9 +147,10 @@ class GPT2ParallelTransformerLayer(torch.nn.Module):
 
     def forward(self, hidden_states, ltor_mask, pivot_idx=None, is_sparse=0, mem=None, recompute=False,
                 on_backward_done=None):
-        if is_sparse:
-            raise NotImplementedError("sparse attention is not implemented yet (SURVEY.md section 8f, item 1)")
-        if mem is None and self.scale_normalization:
+        is_sparse = int(is_sparse)
+        if is_sparse == 1:
+            raise NotImplementedError("sparse attention TRAINING is not implemented yet (SURVEY.md section 8f, item 1)")
+        if mem is None and self.scale_normalization and is_sparse == 0:
             s = hidden_states.size(1)
             sep = F_.mask_to_sep(ltor_mask, s, s)
             return F_.transformer_layer(self, hidden_states, getattr(hidden_states, "_cogv_absmax", None), sep,
@@ -215,8 +222,9 @@ class GPT2ParallelTransformer(torch.nn.Module):
 
     def forward(self, hidden_states, position_ids, attention_mask, txt_indices_bool, img_indices_bool, is_sparse=0,
                 *mems, embedded=False):
-        if is_sparse:
-            raise NotImplementedError("sparse attention is not implemented yet (SURVEY.md section 8f, item 1)")
+        is_sparse = int(is_sparse)
+        if is_sparse == 1:
+            raise NotImplementedError("sparse attention TRAINING is not implemented yet (SURVEY.md section 8f, item 1)")
         batch_size, query_length = hidden_states.size()[:2]
         memory_length = mems[0].size(1) if mems else 0
         key_length = query_length + memory_length
@@ -231,8 +239,30 @@ class GPT2ParallelTransformer(torch.nn.Module):
             hidden_states = F_.dropout(hidden_states, self.embedding_dropout.p, self.training)
         mem_layers = [hidden_states.detach()] if self.max_memory_length > 0 else []
         recompute = bool(self.checkpoint_activations) and torch.is_grad_enabled()
+        if is_sparse == 2:
+            # sparse inference (mpu/sparse_transformer.py:497-499, 511-518, 586-600): every layer draws its own pivots --
+            # all text positions plus a random sample of the image positions left of the trailing window
+            import random
+            left = max(0, key_length - self.key_window_times * self.query_window)
+            window_idx = torch.arange(left, key_length, device=hidden_states.device, dtype=torch.long).expand(batch_size, -1)
+            img_indices = [img_indices_bool[i][:left].nonzero(as_tuple=False).view(-1) for i in range(batch_size)]
+            txt_indices = [txt_indices_bool[i][:left].nonzero(as_tuple=False).view(-1) for i in range(batch_size)]
+            ratio = self.num_pivot / self.max_sequence_length
+            max_text_num = max(len(t) for t in txt_indices)
+            num_pivot = max_text_num + int((left - max_text_num) * ratio)
         for i, layer in enumerate(self.layers):
             mem_i = mems[i] if mems else None
+            if is_sparse == 2:
+                pivot_idx = torch.stack([
+                    torch.cat((text_idx, img_indices[j][torch.tensor(
+                        random.sample(range(len(img_indices[j])), k=num_pivot - len(text_idx)), dtype=torch.long,
+                        device=text_idx.device)]), dim=0)
+                    for j, text_idx in enumerate(txt_indices)])
+                pw_idx = torch.cat((pivot_idx, window_idx), dim=-1)
+                hidden_states = layer(hidden_states, sep, pw_idx, is_sparse, mem=mem_i)
+                if self.max_memory_length > 0:
+                    mem_layers.append(hidden_states.detach())
+                continue
             hidden_states = layer(hidden_states, sep, mem=mem_i, recompute=recompute,
                                   on_backward_done=self.on_layer_backward_done)
             if self.max_memory_length > 0:

@@ -323,13 +323,20 @@ def _attn_desc(q, k, v, o, sep, dropout):
     return d
 
 
-def attention_fwd(q, k, v, sep=0, dropout=None):
-    """q [b,s_q,H,64], k/v [b,s_k,H,64] (strided views are fine).  Returns (o [b,s_q,H,64] contiguous, lse)."""
+def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None):
+    """q [b,s_q,H,64], k/v [b,s_k,H,64] (strided views are fine).  Returns (o [b,s_q,H,64] contiguous, lse).
+    kv_index [b, n] int32 (forward only): key slot j is row kv_index[b, j] of k / v -- the gathered form of
+    sparse_attention_inference; the left-to-right rule then applies to slots (the last s_q slots are the queries)."""
     _need_gpu(q, k, v)
     b, s_q, H, _ = q.shape
     o = torch.empty((b, s_q, H, 64), dtype=q.dtype, device=q.device)
     lse = torch.empty((b, H, s_q), dtype=torch.float32, device=q.device)
     d = _attn_desc(q, k, v, o, sep, dropout)
+    if kv_index is not None:
+        assert kv_index.dtype == torch.int32 and kv_index.dim() == 2 and kv_index.shape[0] == b and kv_index.is_contiguous()
+        assert kv_index.shape[1] >= s_q
+        d.s_k = kv_index.shape[1]
+        d.kv_index, d.kv_index_bs = kv_index.data_ptr(), kv_index.stride(0)
     d.lse = lse.data_ptr()
     L.check(L.lib().cogv_attention_fwd(C.byref(d), _stream()), "cogv_attention_fwd")
     return o, lse

@@ -130,6 +130,10 @@ typedef struct cogv_attn_desc {
    * QKV projection, mpu/sparse_transformer.py:101-110) -> colsum_partial[B * ceil(s/128)][3 * H * 64] fp32, columns
    * ordered [q heads | k heads | v heads]; requires s_q == s_k; finish with cogv_colsum_finalize. */
   float* colsum_partial;
+  /* forward only, optional: gathered keys (sparse_attention_inference, mpu/sparse_transformer.py:727-750): key slot j of
+   * batch b is row kv_index[b * kv_index_bs + j] of k and v; s_k is the number of slots (<= 4096).  The left-to-right
+   * rule applies to SLOTS: the last s_q slots are the queries' own positions. */
+  const int* kv_index; long long kv_index_bs;
 } cogv_attn_desc;
 int cogv_attention_fwd(const cogv_attn_desc* d, void* stream);
 int cogv_attention_bwd(const cogv_attn_desc* d, void* stream);

@@ -5,6 +5,7 @@ storage type): fp16 3e-3, bf16 2e-2 for single kernels whose output is rounded o
 (bf16 has 8 significant bits: 2^-9 = 2e-3 per element before any accumulation effects).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -434,3 +435,31 @@ def test_attention_bwd_fused_qkv_bias_grad(ops, dtype):
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
     expect = torch.cat([t.float().reshape(-1, H * 64).sum(0) for t in (dq, dk, dv)]).cpu() + prev.float()
     assert rel(fused, expect) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sparse_attention_inference_vs_reference_golden(ops, dtype, golden_dir):
+    """Gathered-key forward (sparse_attention_inference, mpu/sparse_transformer.py:727-750) against the REFERENCE's
+    own output (tests/golden/sparse_attention.npz) and, at a longer gathered length with several queries, the oracle."""
+    import numpy as np
+    from cogview_amd import mpu
+    F_ = mpu.transformer
+    z = np.load(os.path.join(golden_dir, "sparse_attention.npz"))
+    t = {k: torch.from_numpy(z[k]) for k in z.files}
+    sq, sk = [int(x) for x in t["inf_cfg"]]
+    q = t["q"][:, :, sk - sq:sk].to(dtype)
+    k, v = t["k"][:, :, :sk].to(dtype), t["v"][:, :, :sk].to(dtype)
+    with torch.no_grad():
+        out = F_.sparse_attention_inference(dev(q), dev(k), dev(v), dev(t["pw_idx"]))
+    ref = O.sparse_attention_inference(q.float(), k.float(), v.float(), t["pw_idx"])
+    assert rel(out, t["inf_ctx"]) < 3 * TOL[dtype]           # golden was computed from unrounded inputs
+    assert rel(out, ref) < TOL[dtype]
+    g = torch.Generator().manual_seed(9)
+    b, nh, s, n, sq = 2, 3, 700, 333, 5
+    q, k, v = [rnd((b, nh, s, 64), dtype, g) for _ in range(3)]
+    idx = torch.stack([torch.cat((torch.randperm(s - sq, generator=g)[:n - sq].sort().values, torch.arange(s - sq, s)))
+                       for _ in range(b)])
+    with torch.no_grad():
+        out = F_.sparse_attention_inference(dev(q[:, :, -sq:]), dev(k), dev(v), dev(idx))
+    ref = O.sparse_attention_inference(q[:, :, -sq:].float(), k.float(), v.float(), idx)
+    assert rel(out, ref) < TOL[dtype]

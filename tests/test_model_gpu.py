@@ -485,3 +485,49 @@ def test_two_way_tensor_parallel_on_one_gpu():
             worst = max(worst, e)
             assert e < 1.5e-2, f"{n} rank {r}: {e}"
     print(f"tensor parallel x2: logits rel-L2 {e_log:.2e}, worst shard-gradient rel-L2 {worst:.2e}")
+
+
+def test_sparse_inference_mode_equals_dense_when_every_key_is_reachable(golden_dir):
+    """is_sparse = 2 (generation with sparse attention, mpu/sparse_transformer.py:497-518, 586-600, 727-750) through the
+    whole model: (a) the trailing window covers the sequence -> no pivots, (b) a short window but every earlier
+    position is text -> all of them are pivots.  In both cases every key is reachable, so the gathered attention must
+    reproduce dense attention; (b) goes through the pivot sampling and the in-kernel gather."""
+    from cogview_amd.fp16 import FP16_Module
+    from cogview_amd.model import GPT2Model
+    g = _golden(golden_dir)
+    L_, V_, H_, NH_, P_, S_, B_ = [int(v) for v in g["cfg"]]
+    tokens = g["tokens"].cuda()
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    for qw, times in ((128, 6), (8, 2)):
+        torch.manual_seed(0)
+        m = GPT2Model(L_, V_, H_, NH_, 0.0, 0.0, 0.0, P_, 0, False, query_window=qw, key_window_times=times, num_pivot=16)
+        m.load_state_dict({k[6:]: v for k, v in g.items() if k.startswith("param.")})
+        model = FP16_Module(m.cuda(), dtype=torch.float16, keep_half_outputs=True).eval()
+        left = max(0, S_ - qw * times)
+        txt = torch.zeros(B_, S_, dtype=torch.bool, device="cuda")
+        txt[:, :left] = True
+        with torch.no_grad():
+            dense, = model(tokens, pos, 0, None, None, 0)
+            sparse, = model(tokens, pos, 0, txt, ~txt, 2)
+        e = rel(sparse, dense)
+        print(f"is_sparse=2 vs dense (window {qw}x{times}, {left} pivots): logits rel-L2 {e:.2e}")
+        assert e < 3e-3
+    # generation-style use: a dense prefix fills the memories, the last 4 tokens attend pivots + trailing window.
+    torch.manual_seed(0)
+    m = GPT2Model(L_, V_, H_, NH_, 0.0, 0.0, 0.0, P_, S_, False, query_window=8, key_window_times=2, num_pivot=16)
+    m.load_state_dict({k[6:]: v for k, v in g.items() if k.startswith("param.")})
+    model = FP16_Module(m.cuda(), dtype=torch.float16, keep_half_outputs=True).eval()
+    pre, left = S_ - 4, S_ - 16
+    all_txt = torch.zeros(B_, S_, dtype=torch.bool, device="cuda")
+    all_txt[:, :left] = True
+    few_txt = torch.zeros_like(all_txt)
+    few_txt[:, :2] = True
+    with torch.no_grad():
+        _, *mems = model(tokens[:, :pre], pos[:, :pre], 0, None, None, 0)
+        dense_tail, *_ = model(tokens[:, pre:], pos[:, pre:], 0, None, None, 0, *mems)
+        full_tail, *_ = model(tokens[:, pre:], pos[:, pre:], 0, all_txt, ~all_txt, 2, *mems)
+        few_tail, *_ = model(tokens[:, pre:], pos[:, pre:], 0, few_txt, ~few_txt, 2, *mems)
+    e_full, e_few = rel(full_tail, dense_tail), rel(few_tail, dense_tail)
+    print(f"last 4 tokens on memories: all keys as pivots {e_full:.2e}, 2 text + sampled pivots {e_few:.2e} vs dense")
+    assert e_full < 3e-3
+    assert torch.isfinite(few_tail).all() and e_few > 1e-3          # fewer reachable keys: a different (finite) result
