@@ -51,6 +51,7 @@ class AttnDesc(C.Structure):
         ("do_rs", C.c_int), ("dq_rs", C.c_int), ("dk_rs", C.c_int), ("dv_rs", C.c_int),
         ("colsum_partial", C.c_void_p),
         ("kv_index", C.c_void_p), ("kv_index_bs", C.c_longlong),
+        ("kv_index_gs", C.c_longlong), ("sparse_window", C.c_int), ("sparse_pivots", C.c_int), ("sparse_pivot_bias", C.c_float),
     ]
 
 

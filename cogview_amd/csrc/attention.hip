@@ -43,7 +43,11 @@ struct AttnArgs {
   const void* dout; void* dq; void* dk; void* dv;              // backward
   float* lse; float* dvec;                                     // [b][H][s_q]
   float* colsum_ws;                                            // optional [B * nblk][3 * H * 64]: sums of dq | dk | dv
-  const int* kv_index; long long kv_index_bs;                  // forward only, optional: key slot j reads K/V row kv_index[b][j]
+  const int* kv_index; long long kv_index_bs;                  // optional: key slot j reads K/V row kv_index[b][j] & 0x7fffffff
+  // sparse TRAINING form in slot space (sp_w > 0): one index row per query block g = q / sp_w (kv_index_gs apart);
+  // bit 31 of an entry = slot masked (-10000); the first sp_npiv slots are pivots and take sp_bias (added to the
+  // scaled score); the left-to-right rule runs on slots, the block's own sp_w queries being the last sp_w slots
+  long long kv_index_gs; int sp_w, sp_npiv; float sp_bias;
   long long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs; // batch strides (elements)
   int q_rs, k_rs, v_rs, o_rs, do_rs, dq_rs, dk_rs, dv_rs;       // row strides (elements)
   int B, H, s_q, s_k, sep_k;   // sep_k: keys [0, sep_k) visible to every query
@@ -74,6 +78,7 @@ __device__ __forceinline__ void dma_tile(const T* base, long long rs, int row0, 
     if (lds_index) {      // gathered keys: slot -> row through the index table staged in LDS (asm read: no vmcnt drain)
       const uint32_t a = (uint32_t)(uintptr_t)(lds_index + gr);
       asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(gr) : "v"(a) : "memory");
+      gr &= 0x7fffffff;
     }
     __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + (long long)gr * rs + c * 8), (lds_void_t*)(lds + piece * 1024), 16, 0, 0);
   }
@@ -259,7 +264,9 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   const int fr = lane & 31, fg = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
   const int q0 = blockIdx.x * 128, q0w = q0 + wave * 32;
-  const int off = p.s_k - p.s_q;
+  const bool spw = p.sp_w > 0;                      // sparse training form (slot space)
+  const int gblk = spw ? q0 / p.sp_w : 0;
+  const int off = spw ? (p.s_k - p.sp_w - gblk * p.sp_w) : (p.s_k - p.s_q);
   const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + head * HD;
   const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + head * HD;
   const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + head * HD;
@@ -298,10 +305,11 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   int* lidx = nullptr;
   if (p.kv_index) {
     lidx = reinterpret_cast<int*>(smem + 3 * STAGE);
-    const int* gi = p.kv_index + (long long)b * p.kv_index_bs;
+    const int* gi = p.kv_index + (long long)b * p.kv_index_bs + (long long)gblk * p.kv_index_gs;
     for (int i = threadIdx.x; i < p.s_k; i += NT) lidx[i] = gi[i];
     __syncthreads();
   }
+  const float sp_bias_raw = spw ? p.sp_bias / p.scale : 0.f;      // added to RAW scores of pivot slots
   auto issue = [&](int kb, int st) {
     dma_tile<T>(K, p.k_rs, kb * 64, p.s_k, smem + st * STAGE, wave, lane, lidx);
     dma_tile<T>(V, p.v_rs, kb * 64, p.s_k, smem + st * STAGE + TILE, wave, lane, lidx);
@@ -327,6 +335,25 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
       // V^T fragments of the first 32 keys: issued now, consumed after the softmax
       TrRaw vr[2][2];
       tr_frags_issue<T, 0>(lv, loff, vr);
+      if (spw) {
+        // slot attributes of this block, one slot per lane: masked flag (bit 31 of the index entry) and "is a pivot"
+        int raw;
+        const uint32_t ia = (uint32_t)(uintptr_t)(lidx + min(kb * 64 + lane, p.s_k - 1));
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(ia) : "memory");
+        const unsigned long long mflag = __ballot(raw < 0), mpiv = __ballot(kb * 64 + lane < p.sp_npiv);
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+          const uint32_t fm = (uint32_t)(mflag >> (32 * sb)) >> (4 * fg), pm = (uint32_t)(mpiv >> (32 * sb)) >> (4 * fg);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int bit = (e & 3) + 8 * (e >> 2);
+            float v = sacc[sb][e];
+            v = ((fm >> bit) & 1u) ? masked_raw : v;
+            v += ((pm >> bit) & 1u) ? sp_bias_raw : 0.f;
+            sacc[sb][e] = v;
+          }
+        }
+      }
       const int kfirst = kb * 64;
       const bool all_visible = (kfirst + 63 <= q0w + off) || (kfirst + 63 < p.sep_k);
       if (!all_visible || kfirst + 64 > p.s_k) {
@@ -763,10 +790,12 @@ int fill_args(const cogv_attn_desc* d, AttnArgs& a) {
   if (!d) return COGV_ERR_ARG;
   if (d->dtype != COGV_F16 && d->dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
   if (d->head_dim != HD) return COGV_ERR_UNSUPPORTED;
-  if (d->B <= 0 || d->H <= 0 || d->s_q <= 0 || d->s_k <= 0 || d->s_k < d->s_q) return COGV_ERR_ARG;
+  if (d->B <= 0 || d->H <= 0 || d->s_q <= 0 || d->s_k <= 0) return COGV_ERR_ARG;
+  if (d->s_k < d->s_q && !(d->kv_index && d->sparse_window > 0)) return COGV_ERR_ARG;   // slot space: s_k = slots per block
   if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return COGV_ERR_ARG;
   a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o; a.dout = d->dout; a.dq = d->dq; a.dk = d->dk; a.dv = d->dv;
   a.lse = d->lse; a.dvec = d->dvec; a.colsum_ws = nullptr; a.kv_index = nullptr; a.kv_index_bs = 0;
+  a.kv_index_gs = 0; a.sp_w = 0; a.sp_npiv = 0; a.sp_bias = 0.f;
   a.q_bs = d->q_bs; a.k_bs = d->k_bs; a.v_bs = d->v_bs; a.o_bs = d->o_bs; a.do_bs = d->do_bs;
   a.dq_bs = d->dq_bs; a.dk_bs = d->dk_bs; a.dv_bs = d->dv_bs;
   a.q_rs = d->q_rs; a.k_rs = d->k_rs; a.v_rs = d->v_rs; a.o_rs = d->o_rs; a.do_rs = d->do_rs;
@@ -803,6 +832,13 @@ extern "C" int cogv_attention_fwd(const cogv_attn_desc* d, void* stream) {
     if (a.s_k > 4096) return COGV_ERR_UNSUPPORTED;
     a.kv_index = d->kv_index; a.kv_index_bs = d->kv_index_bs;
     sh += ((a.s_k * 4 + 15) / 16) * 16;
+    if (d->sparse_window > 0) {          // training form: s_k = slots per query block, queries in blocks of sparse_window
+      if ((d->sparse_window % 128) || (a.s_q % d->sparse_window) || d->sparse_pivots < 0 || d->sparse_pivots > a.s_k ||
+          a.s_k < d->sparse_window || a.sep_k != 0) return COGV_ERR_ARG;
+      a.kv_index_gs = d->kv_index_gs; a.sp_w = d->sparse_window; a.sp_npiv = d->sparse_pivots; a.sp_bias = d->sparse_pivot_bias;
+    }
+  } else if (d->sparse_window > 0) {
+    return COGV_ERR_ARG;
   }
   if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), grid, dim3(NT), sh, st, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, dim3(NT), sh, st, a);

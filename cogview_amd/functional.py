@@ -172,6 +172,24 @@ def standard_attention(query_layer, key_layer, value_layer, attention_mask, atte
     return o.permute(0, 2, 1, 3)
 
 
+def sparse_slot_table(pivot_idx, s, w, times):
+    """Index table of the sparse TRAINING form in slot space: [b, s // w, n_piv + times * w] int32.  Query block g
+    attends its n_piv pivots (masked -- bit 31 -- unless the pivot lies before the block's window: the rmask rule of
+    mpu/sparse_transformer.py:491-496) followed by the window keys (g - times + 1) * w ... (g + 1) * w - 1 (front
+    padding masked)."""
+    b, n_piv = pivot_idx.shape
+    G = s // w
+    dev = pivot_idx.device
+    ks = (torch.arange(G, device=dev) - times + 1) * w                                   # first window key per block
+    piv = pivot_idx.to(torch.int64).unsqueeze(1).expand(b, G, n_piv)
+    piv = piv + (piv >= ks.view(1, G, 1)).to(torch.int64) * (1 << 31)
+    win = ks.view(G, 1) + torch.arange(times * w, device=dev).view(1, -1)
+    win = win.clamp(min=0) + (win < 0).to(torch.int64) * (1 << 31)
+    tab = torch.cat((piv, win.unsqueeze(0).expand(b, G, times * w)), dim=-1)
+    tab = torch.where(tab >= (1 << 31), tab - (1 << 32), tab)                            # as signed 32-bit patterns
+    return tab.to(torch.int32).contiguous()
+
+
 def sparse_attention_inference(q, k, v, pivot_and_window_idx, **kwargs):
     """Drop-in for mpu/sparse_transformer.py:727-750 (generation with sparse attention): the sq queries -- the last
     sq keys -- attend the gathered pivot + window keys, causally among themselves.  [b, np, s, hn] tensors, index

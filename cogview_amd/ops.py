@@ -323,7 +323,7 @@ def _attn_desc(q, k, v, o, sep, dropout):
     return d
 
 
-def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None):
+def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None):
     """q [b,s_q,H,64], k/v [b,s_k,H,64] (strided views are fine).  Returns (o [b,s_q,H,64] contiguous, lse).
     kv_index [b, n] int32 (forward only): key slot j is row kv_index[b, j] of k / v -- the gathered form of
     sparse_attention_inference; the left-to-right rule then applies to slots (the last s_q slots are the queries)."""
@@ -332,14 +332,27 @@ def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None):
     o = torch.empty((b, s_q, H, 64), dtype=q.dtype, device=q.device)
     lse = torch.empty((b, H, s_q), dtype=torch.float32, device=q.device)
     d = _attn_desc(q, k, v, o, sep, dropout)
-    if kv_index is not None:
+    if kv_index is not None and sparse is None:
         assert kv_index.dtype == torch.int32 and kv_index.dim() == 2 and kv_index.shape[0] == b and kv_index.is_contiguous()
         assert kv_index.shape[1] >= s_q
         d.s_k = kv_index.shape[1]
         d.kv_index, d.kv_index_bs = kv_index.data_ptr(), kv_index.stride(0)
+    elif sparse is not None:
+        _sparse_desc(d, kv_index, sparse, b, s_q)
     d.lse = lse.data_ptr()
     L.check(L.lib().cogv_attention_fwd(C.byref(d), _stream()), "cogv_attention_fwd")
     return o, lse
+
+
+def _sparse_desc(d, kv_index, sparse, b, s_q):
+    """Sparse training form in slot space: kv_index [b, s_q // w, n_slots] int32 (bit 31 = masked slot),
+    sparse = (w, n_pivots, pivot_bias)."""
+    w, n_piv, bias = sparse
+    assert kv_index.dtype == torch.int32 and kv_index.dim() == 3 and kv_index.is_contiguous()
+    assert kv_index.shape[0] == b and kv_index.shape[1] == s_q // w and s_q % w == 0 and w % 128 == 0
+    d.s_k = kv_index.shape[2]
+    d.kv_index, d.kv_index_bs, d.kv_index_gs = kv_index.data_ptr(), kv_index.stride(0), kv_index.stride(1)
+    d.sparse_window, d.sparse_pivots, d.sparse_pivot_bias = int(w), int(n_piv), float(bias)
 
 
 def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, dv=None, colsum_out=None,

@@ -134,6 +134,13 @@ typedef struct cogv_attn_desc {
    * batch b is row kv_index[b * kv_index_bs + j] of k and v; s_k is the number of slots (<= 4096).  The left-to-right
    * rule applies to SLOTS: the last s_q slots are the queries' own positions. */
   const int* kv_index; long long kv_index_bs;
+  /* sparse TRAINING form (sparse_attention, mpu/sparse_transformer.py:675-725) in "slot space": sparse_window > 0 (the
+   * reference's query_window, a multiple of 128 dividing s_q).  Each block of sparse_window queries has its own index
+   * row (kv_index_gs entries apart) of s_k slots: first sparse_pivots pivot slots, then the key_window_times *
+   * sparse_window window slots ending with the block's own positions.  Bit 31 of an entry marks a masked slot (an
+   * invisible pivot, front padding): score -10000.  Pivot slots add sparse_pivot_bias = log(s // n_pivots) to the
+   * scaled score; the left-to-right rule applies to the last sparse_window slots. */
+  long long kv_index_gs; int sparse_window, sparse_pivots; float sparse_pivot_bias;
 } cogv_attn_desc;
 int cogv_attention_fwd(const cogv_attn_desc* d, void* stream);
 int cogv_attention_bwd(const cogv_attn_desc* d, void* stream);

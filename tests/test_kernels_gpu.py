@@ -463,3 +463,23 @@ def test_sparse_attention_inference_vs_reference_golden(ops, dtype, golden_dir):
         out = F_.sparse_attention_inference(dev(q[:, :, -sq:]), dev(k), dev(v), dev(idx))
     ref = O.sparse_attention_inference(q[:, :, -sq:].float(), k.float(), v.float(), idx)
     assert rel(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sparse_attention_training_form_forward(ops, dtype):
+    """Forward of the sparse TRAINING form (pivots + window, joint softmax; mpu/sparse_transformer.py:675-725) computed
+    in slot space by the gathered attention kernel, against the oracle restatement (itself pinned to the reference)."""
+    from cogview_amd import mpu                      # (importing the package first avoids the functional <-> mpu cycle)
+    from cogview_amd import functional as F_
+    g = torch.Generator().manual_seed(21)
+    b, nh, w, times, n_piv = 2, 3, 128, 2, 40
+    s = 4 * w
+    q, k, v = [rnd((b, nh, s, 64), dtype, g) for _ in range(3)]
+    pivot_idx = torch.stack([torch.cat((torch.arange(7), 7 + torch.randperm(s - 7, generator=g)[:n_piv - 7])) for _ in range(b)])
+    rmask = O.sparse_rmask(s, w, times)
+    pam = rmask.expand(b, s, s).gather(-1, pivot_idx.unsqueeze(1).expand(b, s, n_piv))
+    ref = O.sparse_attention(q.float(), k.float(), v.float(), pivot_idx, pam, w, times)
+    tab = F_.sparse_slot_table(dev(pivot_idx), s, w, times)
+    qd, kd, vd = [dev(t).permute(0, 2, 1, 3).contiguous() for t in (q, k, v)]          # [b, s, H, 64]
+    out, _ = ops.attention_fwd(qd, kd, vd, kv_index=tab, sparse=(w, n_piv, math.log(s // n_piv)))
+    assert rel(out.permute(0, 2, 1, 3), ref) < TOL[dtype]
