@@ -100,6 +100,7 @@ SIGNATURES = {
     "cogv_ln_bwd_num_blocks": (_i, [_i]),
     "cogv_attention_fwd": (_i, [C.POINTER(AttnDesc), _vp]),
     "cogv_attention_bwd": (_i, [C.POINTER(AttnDesc), _vp]),
+    "cogv_sparse_slot_reduce": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cogv_embedding_fwd": (_i, [_i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _f, _u64, _u64, _vp]),
     "cogv_embedding_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _i, _f, _u64, _u64, _vp]),
     "cogv_gelu_fwd": (_i, [_i, _vp, _vp, _sz, _vp]),

@@ -451,7 +451,9 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const int fr = lane & 31, fg = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
   const int q0 = blockIdx.x * 128, q0w = q0 + wave * 32;
-  const int off = p.s_k - p.s_q;
+  const bool spw = p.sp_w > 0;                      // sparse training form (slot space), see attn_fwd_kernel
+  const int gblk = spw ? q0 / p.sp_w : 0;
+  const int off = spw ? (p.s_k - p.sp_w - gblk * p.sp_w) : (p.s_k - p.s_q);
   const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + head * HD;
   const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + head * HD;
   const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + head * HD;
@@ -502,9 +504,17 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const uint32_t loff[2] = {tr_lane_off(0, lane) ^ tr_lane_fix(lane), tr_lane_off(1, lane) ^ tr_lane_fix(lane)};
   const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
 
+  int* lidx = nullptr;
+  if (p.kv_index) {
+    lidx = reinterpret_cast<int*>(smem + 3 * STAGE);
+    const int* gi = p.kv_index + (long long)b * p.kv_index_bs + (long long)gblk * p.kv_index_gs;
+    for (int i = threadIdx.x; i < p.s_k; i += NT) lidx[i] = gi[i];
+    __syncthreads();
+  }
+  const float sp_bias_raw = spw ? p.sp_bias / p.scale : 0.f;
   auto issue = [&](int kb, int st) {
-    dma_tile<T>(K, p.k_rs, kb * 64, p.s_k, smem + st * STAGE, wave, lane);
-    dma_tile<T>(V, p.v_rs, kb * 64, p.s_k, smem + st * STAGE + TILE, wave, lane);
+    dma_tile<T>(K, p.k_rs, kb * 64, p.s_k, smem + st * STAGE, wave, lane, lidx);
+    dma_tile<T>(V, p.v_rs, kb * 64, p.s_k, smem + st * STAGE + TILE, wave, lane, lidx);
   };
   if (nkb > 0) { issue(0, 0); issue(nkb > 1 ? 1 : 0, 1); }
   int st = 0;
@@ -515,6 +525,13 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     if (kb * 64 < kend_w) {
       const char* lk = smem + st * STAGE; const char* lv = lk + TILE;
       const uint32_t lkt = smem_addr + st * STAGE;
+      unsigned long long mflag = 0ull, mpiv = 0ull;         // slot attributes of this block (sparse training form)
+      if (spw) {
+        int raw;
+        const uint32_t ia = (uint32_t)(uintptr_t)(lidx + min(kb * 64 + lane, p.s_k - 1));
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(ia) : "memory");
+        mflag = __ballot(raw < 0); mpiv = __ballot(kb * 64 + lane < p.sp_npiv);
+      }
       auto half = [&](auto SBc) {
         constexpr int sb = decltype(SBc)::value;
         f32x16 sacc, pacc;
@@ -527,6 +544,17 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
         }
         TrRaw kr[2][2];
         tr_frags_issue<T, sb>(lkt, loff, kr);
+        if (spw) {
+          const uint32_t fm = (uint32_t)(mflag >> (32 * sb)) >> (4 * fg), pm = (uint32_t)(mpiv >> (32 * sb)) >> (4 * fg);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int bit = (e & 3) + 8 * (e >> 2);
+            float v = sacc[e];
+            v = ((fm >> bit) & 1u) ? masked_raw : v;
+            v += ((pm >> bit) & 1u) ? sp_bias_raw : 0.f;
+            sacc[e] = v;
+          }
+        }
         const int kfirst = kb * 64 + sb * 32;
         const bool all_visible = (kfirst + 31 <= q0w + off) || (kfirst + 31 < p.sep_k);
         if (!all_visible || kfirst + 32 > p.s_k) {
@@ -597,9 +625,15 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 31, fg = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
+  // sparse training form (sp_w > 0): grid z = (b, query block g); keys are the block's slots, queries its sp_w rows,
+  // dK / dV go to slot-space buffers [z][slot] which cogv_sparse_slot_reduce folds back onto the keys
+  const bool spw = p.sp_w > 0;
+  const int nblk = spw ? p.s_q / p.sp_w : 1;
+  const int zb = blockIdx.z, head = blockIdx.y;
+  const int b = spw ? zb / nblk : zb, gblk = spw ? zb - b * nblk : 0;
   const int k0 = blockIdx.x * 128, k0w = k0 + wave * 32;
-  const int off = p.s_k - p.s_q;
+  const int off = spw ? (p.s_k - p.sp_w - gblk * p.sp_w) : (p.s_k - p.s_q);
+  const int qlo = gblk * p.sp_w, qhi = spw ? qlo + p.sp_w : p.s_q;
   const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + head * HD;
   const T* K = reinterpret_cast<const T*>(p.k) + b * p.k_bs + head * HD;
   const T* V = reinterpret_cast<const T*>(p.v) + b * p.v_bs + head * HD;
@@ -610,16 +644,23 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   const bool kvalid = mykey < p.s_k;
   const bool wave_active = k0w < p.s_k;
 
+  int krow = mykey;
+  bool kflag = false;
+  if (p.kv_index) {
+    const int raw = kvalid ? p.kv_index[(long long)b * p.kv_index_bs + (long long)gblk * p.kv_index_gs + mykey] : 0;
+    kflag = raw < 0; krow = raw & 0x7fffffff;
+  }
   typename HT<T>::v8 kf[4], vf[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    kf[t] = load_frag_global<T>(K + (long long)mykey * p.k_rs + 16 * t + 8 * fg, kvalid);
-    vf[t] = load_frag_global<T>(V + (long long)mykey * p.v_rs + 16 * t + 8 * fg, kvalid);
+    kf[t] = load_frag_global<T>(K + (long long)krow * p.k_rs + 16 * t + 8 * fg, kvalid);
+    vf[t] = load_frag_global<T>(V + (long long)krow * p.v_rs + 16 * t + 8 * fg, kvalid);
   }
-  const int qbeg_blk = (k0 < p.sep_k) ? 0 : max(0, k0 - off);
-  const int qbeg_w = (k0w < p.sep_k) ? 0 : max(0, k0w - off);
+  const int qbeg_blk = (k0 < p.sep_k) ? qlo : max(qlo, k0 - off);
+  const int qbeg_w = (k0w < p.sep_k) ? qlo : max(qlo, k0w - off);
   const int qb0 = qbeg_blk >> 6;
-  const int nqb = (p.s_q + 63) >> 6;
+  const int nqb = (qhi + 63) >> 6;
+  const float sp_add = (spw && mykey < p.sp_npiv) ? p.sp_bias / p.scale : 0.f;
   const float sl2 = p.scale * 1.4426950408889634f;
   const float l2e = 1.4426950408889634f;
   const float masked_raw = MASKED / p.scale;
@@ -682,6 +723,10 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
             if (q >= p.s_q) a = -INFINITY;
             sacc[e] = a;
           }
+        }
+        if (spw) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sacc[e] = (kflag ? masked_raw : sacc[e]) + sp_add;
         }
         uint32_t kmask[4] = {0u, 0u, 0u, 0u};
         if (p.thr16) {
@@ -756,8 +801,8 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   wait_vmcnt<0>();
   float rk[2][16], rv[2][16];
   {
-    T* DK = reinterpret_cast<T*>(p.dk) + b * p.dk_bs + (long long)mykey * p.dk_rs + head * HD;
-    T* DVp = reinterpret_cast<T*>(p.dv) + b * p.dv_bs + (long long)mykey * p.dv_rs + head * HD;
+    T* DK = reinterpret_cast<T*>(p.dk) + zb * p.dk_bs + (long long)mykey * p.dk_rs + head * HD;
+    T* DVp = reinterpret_cast<T*>(p.dv) + zb * p.dv_bs + (long long)mykey * p.dv_rs + head * HD;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -778,9 +823,51 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   }
   if (p.colsum_ws) {     // bias gradient of the QKV projection, k and v sections
     __syncthreads();
-    float* dst = p.colsum_ws + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)(3 * p.H * HD) + (size_t)p.H * HD + head * HD;
+    float* dst = p.colsum_ws + ((size_t)zb * gridDim.x + blockIdx.x) * (size_t)(3 * p.H * HD) + (size_t)p.H * HD + head * HD;
     tile_colsum(rk, reinterpret_cast<float*>(smem), dst, lane, wave);
     tile_colsum(rv, reinterpret_cast<float*>(smem), dst + (size_t)p.H * HD, lane, wave);
+  }
+}
+
+// Sparse training form: fold the slot-space gradients [B][G][n_slots][H*64] back onto the keys.  Key r is a window
+// slot of the blocks g = r/w ... r/w + times - 1 (slot n_piv + r - (g - times + 1) w) and, when it is pivot j
+// (pivot_inv[b][r] = j, else -1), slot j of every block whose window starts after it (g >= r/w + times; the blocks
+// before that hold it as a masked slot, whose gradient is exactly 0).  fp32 sums in a fixed order: deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void sparse_slot_reduce_kernel(const T* __restrict__ dks, const T* __restrict__ dvs,
+                                                                 const int* __restrict__ pivot_inv, T* __restrict__ dk,
+                                                                 T* __restrict__ dv, long long dk_bs, int dk_rs,
+                                                                 long long dv_bs, int dv_rs, int B, int s, int C8,
+                                                                 int w, int times, int n_piv) {
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * s * C8;
+  if (tid >= total) return;
+  const int c = (int)(tid % C8);
+  const long long br = tid / C8;
+  const int r = (int)(br % s), b = (int)(br / s);
+  const int G = s / w, n_slots = n_piv + times * w, g0 = r / w;
+  const long long slot_row = (long long)C8 * 8;
+  const int pj = pivot_inv[(long long)b * s + r];
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const T* src = (which ? dvs : dks) + (long long)b * G * n_slots * slot_row + c * 8;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    auto add = [&](int g, int slot) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(src + ((long long)g * n_slots + slot) * slot_row);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += bits_to_f<T>((uint16_t)(raw[i >> 1] >> (16 * (i & 1))));
+    };
+    const int gend = min(G - 1, g0 + times - 1);
+    for (int g = g0; g <= gend; ++g) add(g, n_piv + r - (g - times + 1) * w);
+    if (pj >= 0)
+      for (int g = g0 + times; g < G; ++g) add(g, pj);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = pack2<T>(acc[2 * i], acc[2 * i + 1]);
+    T* dst = which ? dv + b * dv_bs + (long long)r * dv_rs + c * 8 : dk + b * dk_bs + (long long)r * dk_rs + c * 8;
+    *reinterpret_cast<u32x4*>(dst) = o;
   }
 }
 
@@ -810,6 +897,22 @@ int fill_args(const cogv_attn_desc* d, AttnArgs& a) {
   return COGV_OK;
 }
 
+// gathered keys (kv_index) and the sparse training form's slot attributes
+int index_args(const cogv_attn_desc* d, AttnArgs& a) {
+  if (d->kv_index) {
+    if (a.s_k > 4096) return COGV_ERR_UNSUPPORTED;
+    a.kv_index = d->kv_index; a.kv_index_bs = d->kv_index_bs;
+    if (d->sparse_window > 0) {          // training form: s_k = slots per query block, queries in blocks of sparse_window
+      if ((d->sparse_window % 128) || (a.s_q % d->sparse_window) || d->sparse_pivots < 0 || d->sparse_pivots > a.s_k ||
+          a.s_k < d->sparse_window || a.sep_k != 0) return COGV_ERR_ARG;
+      a.kv_index_gs = d->kv_index_gs; a.sp_w = d->sparse_window; a.sp_npiv = d->sparse_pivots; a.sp_bias = d->sparse_pivot_bias;
+    }
+  } else if (d->sparse_window > 0) {
+    return COGV_ERR_ARG;
+  }
+  return COGV_OK;
+}
+
 template <typename K>
 void set_smem(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -828,18 +931,8 @@ extern "C" int cogv_attention_fwd(const cogv_attn_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((a.s_q + 127) / 128, a.H, a.B);
   int sh = 3 * 2 * TILE;
-  if (d->kv_index) {
-    if (a.s_k > 4096) return COGV_ERR_UNSUPPORTED;
-    a.kv_index = d->kv_index; a.kv_index_bs = d->kv_index_bs;
-    sh += ((a.s_k * 4 + 15) / 16) * 16;
-    if (d->sparse_window > 0) {          // training form: s_k = slots per query block, queries in blocks of sparse_window
-      if ((d->sparse_window % 128) || (a.s_q % d->sparse_window) || d->sparse_pivots < 0 || d->sparse_pivots > a.s_k ||
-          a.s_k < d->sparse_window || a.sep_k != 0) return COGV_ERR_ARG;
-      a.kv_index_gs = d->kv_index_gs; a.sp_w = d->sparse_window; a.sp_npiv = d->sparse_pivots; a.sp_bias = d->sparse_pivot_bias;
-    }
-  } else if (d->sparse_window > 0) {
-    return COGV_ERR_ARG;
-  }
+  if ((rc = index_args(d, a))) return rc;
+  if (a.kv_index) sh += ((a.s_k * 4 + 15) / 16) * 16;
   if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), grid, dim3(NT), sh, st, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, dim3(NT), sh, st, a);
   return cogv_check_launch();
@@ -850,7 +943,9 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   int rc = fill_args(d, a);
   if (rc) return rc;
   if (!a.q || !a.k || !a.v || !a.o || !a.dout || !a.dq || !a.dk || !a.dv || !a.lse || !a.dvec) return COGV_ERR_ARG;
-  if (d->kv_index) return COGV_ERR_UNSUPPORTED;          // the gathered form is inference only
+  if (d->kv_index && d->sparse_window <= 0) return COGV_ERR_UNSUPPORTED;      // the plain gathered form is inference only
+  if ((rc = index_args(d, a))) return rc;
+  if (a.sp_w > 0 && d->colsum_partial) return COGV_ERR_UNSUPPORTED;
   if (d->colsum_partial) {
     if (d->s_q != d->s_k || ((uintptr_t)d->colsum_partial & 15)) return COGV_ERR_ARG;
     a.colsum_ws = d->colsum_partial;
@@ -860,13 +955,21 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.do_rs | a.dq_rs | a.dk_rs | a.dv_rs) & 7) return COGV_ERR_ARG;
   if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs | a.do_bs | a.dq_bs | a.dk_bs | a.dv_bs) & 7) return COGV_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  dim3 gq((a.s_q + 127) / 128, a.H, a.B), gk((a.s_k + 127) / 128, a.H, a.B);
-  const int sh_q = 3 * 2 * TILE, sh_k = 3 * (2 * TILE + 512);
+  // sparse training form: dK / dV are slot-space buffers, one [s_k] plane per (batch, query block): dk_bs / dv_bs is
+  // the plane stride and grid z runs over B * (s_q / sparse_window) planes
+  const int planes = a.sp_w > 0 ? a.B * (a.s_q / a.sp_w) : a.B;
+  dim3 gq((a.s_q + 127) / 128, a.H, a.B), gk((a.s_k + 127) / 128, a.H, planes);
+  const int sh_q = 3 * 2 * TILE + (a.kv_index ? ((a.s_k * 4 + 15) / 16) * 16 : 0), sh_k = 3 * (2 * TILE + 512);
+  if (sh_q > 160 * 1024) return COGV_ERR_UNSUPPORTED;
+  static int attr_q = 0;
   static bool attr = false;
   if (!attr) {
     set_smem(&attn_bwd_dkdv_kernel<f16_t>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t>, sh_k);
-    set_smem(&attn_bwd_dq_kernel<f16_t>, sh_q); set_smem(&attn_bwd_dq_kernel<bf16_t>, sh_q);
     attr = true;
+  }
+  if (sh_q > attr_q) {
+    set_smem(&attn_bwd_dq_kernel<f16_t>, sh_q); set_smem(&attn_bwd_dq_kernel<bf16_t>, sh_q);
+    attr_q = sh_q;
   }
   if (d->dtype == COGV_F16) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t>), gq, dim3(NT), sh_q, st, a);
@@ -875,5 +978,28 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t>), gq, dim3(NT), sh_q, st, a);
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t>), gk, dim3(NT), sh_k, st, a);
   }
+  return cogv_check_launch();
+}
+
+extern "C" int cogv_sparse_slot_reduce(int dtype, const void* dk_slots, const void* dv_slots, const int* pivot_inv,
+                                       void* dk, void* dv, long long dk_bs, int dk_rs, long long dv_bs, int dv_rs,
+                                       int B, int s, int H, int window, int times, int n_pivots, void* stream) {
+  if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
+  if (!dk_slots || !dv_slots || !pivot_inv || !dk || !dv) return COGV_ERR_ARG;
+  if (B <= 0 || s <= 0 || H <= 0 || window <= 0 || times <= 0 || n_pivots < 0 || (s % window)) return COGV_ERR_ARG;
+  if (!aligned16(dk_slots) || !aligned16(dv_slots) || !aligned16(dk) || !aligned16(dv)) return COGV_ERR_ARG;
+  if ((dk_bs | dv_bs | dk_rs | dv_rs) & 7) return COGV_ERR_ARG;
+  const int C8 = H * HD / 8;
+  const long long total = (long long)B * s * C8;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == COGV_F16)
+    hipLaunchKernelGGL((sparse_slot_reduce_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, (const f16_t*)dk_slots,
+                       (const f16_t*)dv_slots, pivot_inv, (f16_t*)dk, (f16_t*)dv, dk_bs, dk_rs, dv_bs, dv_rs, B, s, C8,
+                       window, times, n_pivots);
+  else
+    hipLaunchKernelGGL((sparse_slot_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)dk_slots,
+                       (const bf16_t*)dv_slots, pivot_inv, (bf16_t*)dk, (bf16_t*)dv, dk_bs, dk_rs, dv_bs, dv_rs, B, s, C8,
+                       window, times, n_pivots);
   return cogv_check_launch();
 }

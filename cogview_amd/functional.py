@@ -13,6 +13,8 @@ in one flat arena (cogview_amd/arena.py) `param.grad` is a view of one flat grad
 data-parallel all-reduce, the overflow check, the norm and the Adam step are each ONE kernel / collective over
 that buffer (the reference does each per tensor: 388 tensors for the 24-layer model, 772 for 48 layers).
 """
+import math
+
 import torch
 
 from . import ops
@@ -188,6 +190,56 @@ def sparse_slot_table(pivot_idx, s, w, times):
     tab = torch.cat((piv, win.unsqueeze(0).expand(b, G, times * w)), dim=-1)
     tab = torch.where(tab >= (1 << 31), tab - (1 << 32), tab)                            # as signed 32-bit patterns
     return tab.to(torch.int32).contiguous()
+
+
+class _SparseAttention(torch.autograd.Function):
+    """q, k, v [b,s,H,64]; tab = sparse_slot_table(...); inv [b,s] int32 pivot slot of each key or -1."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, tab, inv, sparse, times, dropout):
+        o, lse = ops.attention_fwd(q, k, v, sep=0, dropout=dropout, kv_index=tab, sparse=sparse)
+        ctx.save_for_backward(q, k, v, o, lse, tab, inv)
+        ctx.sparse, ctx.times, ctx.dropout = sparse, times, dropout
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, tab, inv = ctx.saved_tensors
+        doc = do if do.is_contiguous() else do.contiguous()
+        dq, dk, dv = ops.sparse_attention_bwd(doc, q, k, v, o, lse, tab, ctx.sparse, inv, ctx.times, dropout=ctx.dropout)
+        return dq, dk, dv, None, None, None, None, None
+
+
+def sparse_pivot_plan(pivot_idx, s, w, times):
+    """Everything the sparse training kernels derive from one pivot draw: (slot table, inverse pivot map).  A plan is
+    shared by the layers that share the draw (one per checkpoint chunk in the reference, mpu/sparse_transformer.py:
+    553-570)."""
+    b, n_piv = pivot_idx.shape
+    inv = torch.full((b, s), -1, dtype=torch.int32, device=pivot_idx.device)
+    inv.scatter_(1, pivot_idx.to(torch.int64), torch.arange(n_piv, dtype=torch.int32, device=pivot_idx.device).expand(b, n_piv))
+    return sparse_slot_table(pivot_idx, s, w, times), inv
+
+
+def sparse_attention(q, k, v, pivot_idx, pivot_attention_mask, query_window=128, key_window_times=6,
+                     attention_dropout=None):
+    """Drop-in for mpu/sparse_transformer.py:675-725 (sparse attention, training form); [b, np, s, hn] tensors with
+    hn = 64, s % query_window == 0, query_window % 128 == 0, distinct pivots per sample (the reference draws them with
+    random.sample).  pivot_attention_mask is accepted for signature compatibility: the kernels rebuild it from the
+    rule that defines it (rmask gathered at the pivots, :491-496 and :569 -- a pivot is visible to a query iff it lies
+    before the query block's window), or take a precomputed plan (pivot_idx = the tuple sparse_pivot_plan returned)."""
+    b, _np, s, _hn = q.shape
+    w, times = int(query_window), int(key_window_times)
+    if isinstance(pivot_idx, tuple):
+        tab, inv = pivot_idx
+    else:
+        tab, inv = sparse_pivot_plan(pivot_idx, s, w, times)
+    n_piv = tab.shape[2] - times * w
+    drop = None
+    if attention_dropout is not None:
+        drop = _drop(attention_dropout.p, attention_dropout.training, attention=True)
+    o = _SparseAttention.apply(_as_bshd(q), _as_bshd(k), _as_bshd(v), tab, inv,
+                               (w, n_piv, math.log(s // n_piv)), times, drop)
+    return o.permute(0, 2, 1, 3)
 
 
 def sparse_attention_inference(q, k, v, pivot_and_window_idx, **kwargs):

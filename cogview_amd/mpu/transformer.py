@@ -6,8 +6,9 @@ Forward paths:
     (cogview_amd.functional.transformer_layer);
   * incremental decoding with `mems` (generation/sampling.py:64-186 keeps LAYER INPUTS as memories): the same
     kernels composed op by op (no autograd needed there).
-Sparse attention (is_sparse = 1/2, mpu/sparse_transformer.py:675-750) is the next row of the scope table
- and raises NotImplementedError.
+  * sparse attention (mpu/sparse_transformer.py:675-750): is_sparse = 1 (training:
+    pivots + blocked window, forward and backward in "slot space", see csrc/attention.hip) and is_sparse = 2
+    (generation: gathered keys), composed op by op around the sparse attention kernels.
 """
 import math
 
@@ -45,6 +46,7 @@ def gelu(x):
 
 
 standard_attention = F_.standard_attention
+sparse_attention = F_.sparse_attention                          # mpu/sparse_transformer.py:675-725
 sparse_attention_inference = F_.sparse_attention_inference      # mpu/sparse_transformer.py:727-750 (forward only)
 
 
@@ -86,16 +88,18 @@ class GPT2ParallelSelfAttention(torch.nn.Module):
         return tensor.view(*shape).permute(0, 2, 1, 3)
 
     def forward(self, hidden_states, ltor_mask, pivot_idx=None, is_sparse=0, mem=None):
-        if int(is_sparse) == 1:
-            raise NotImplementedError("sparse attention TRAINING is not implemented yet (SURVEY.md section 8f, item 1); "
-                                      "the inference form (is_sparse=2) and dense attention are")
         query_length = hidden_states.size(1)
         src = hidden_states if mem is None else torch.cat((mem, hidden_states), 1)
         mixed = self.query_key_value(src)
         q, k, v = split_tensor_along_last_dim(mixed, 3)
         if mem is not None:
             q = q[:, -query_length:]
-        if int(is_sparse) == 2:          # mpu/sparse_transformer.py:149-150: pivot_idx carries pivots + trailing window
+        if int(is_sparse) == 1:          # mpu/sparse_transformer.py:147-148: ltor_mask carries the pivot attention mask
+            assert mem is None
+            ctx = sparse_attention(self._transpose_for_scores(q), self._transpose_for_scores(k),
+                                   self._transpose_for_scores(v), pivot_idx, ltor_mask, self.query_window,
+                                   self.key_window_times, self.attention_dropout)
+        elif int(is_sparse) == 2:        # mpu/sparse_transformer.py:149-150: pivot_idx carries pivots + trailing window
             ctx = sparse_attention_inference(self._transpose_for_scores(q), self._transpose_for_scores(k),
                                              self._transpose_for_scores(v), pivot_idx)
         else:
@@ -148,8 +152,6 @@ class GPT2ParallelTransformerLayer(torch.nn.Module):
     def forward(self, hidden_states, ltor_mask, pivot_idx=None, is_sparse=0, mem=None, recompute=False,
                 on_backward_done=None):
         is_sparse = int(is_sparse)
-        if is_sparse == 1:
-            raise NotImplementedError("sparse attention TRAINING is not implemented yet (SURVEY.md section 8f, item 1)")
         if mem is None and self.scale_normalization and is_sparse == 0:
             s = hidden_states.size(1)
             sep = F_.mask_to_sep(ltor_mask, s, s)
@@ -223,12 +225,12 @@ class GPT2ParallelTransformer(torch.nn.Module):
     def forward(self, hidden_states, position_ids, attention_mask, txt_indices_bool, img_indices_bool, is_sparse=0,
                 *mems, embedded=False):
         is_sparse = int(is_sparse)
-        if is_sparse == 1:
-            raise NotImplementedError("sparse attention TRAINING is not implemented yet (SURVEY.md section 8f, item 1)")
         batch_size, query_length = hidden_states.size()[:2]
         memory_length = mems[0].size(1) if mems else 0
         key_length = query_length + memory_length
-        if isinstance(attention_mask, torch.Tensor) and attention_mask.numel() > 1:
+        if is_sparse == 1:
+            sep = 0                              # the sparse training form has its own mask rule (rmask + window)
+        elif isinstance(attention_mask, torch.Tensor) and attention_mask.numel() > 1:
             sep = F_.mask_to_sep(attention_mask, query_length, key_length)
         else:
             sep = int(attention_mask) if not isinstance(attention_mask, torch.Tensor) else int(attention_mask.item())
@@ -239,6 +241,18 @@ class GPT2ParallelTransformer(torch.nn.Module):
             hidden_states = F_.dropout(hidden_states, self.embedding_dropout.p, self.training)
         mem_layers = [hidden_states.detach()] if self.max_memory_length > 0 else []
         recompute = bool(self.checkpoint_activations) and torch.is_grad_enabled()
+        if is_sparse == 1:
+            # sparse training (mpu/sparse_transformer.py:492-505, 553-570): one pivot draw -- all text positions plus a
+            # random sample of the image positions -- per chunk of checkpoint_num_layers layers.  The reference REQUIRES
+            # activation checkpointing here to fit its gathered copies; these layers keep their activations instead
+            # (no gathered copies exist on this path, and the dense fused layer is the one that recomputes).
+            import random
+            assert key_length == query_length and not mems
+            if query_length % self.query_window:
+                raise ValueError("sparse attention training needs the sequence length to be a multiple of query_window")
+            img_indices = [img_indices_bool[i].nonzero(as_tuple=False).view(-1) for i in range(batch_size)]
+            txt_indices = [txt_indices_bool[i].nonzero(as_tuple=False).view(-1) for i in range(batch_size)]
+            num_pivot = self.num_pivot
         if is_sparse == 2:
             # sparse inference (mpu/sparse_transformer.py:497-499, 511-518, 586-600): every layer draws its own pivots --
             # all text positions plus a random sample of the image positions left of the trailing window
@@ -252,6 +266,16 @@ class GPT2ParallelTransformer(torch.nn.Module):
             num_pivot = max_text_num + int((left - max_text_num) * ratio)
         for i, layer in enumerate(self.layers):
             mem_i = mems[i] if mems else None
+            if is_sparse == 1:
+                if i % max(1, int(self.checkpoint_num_layers)) == 0:
+                    pivot_idx = torch.stack([
+                        torch.cat((text_idx, img_indices[j][torch.tensor(
+                            random.sample(range(len(img_indices[j])), k=num_pivot - len(text_idx)), dtype=torch.long,
+                            device=text_idx.device)]), dim=0)
+                        for j, text_idx in enumerate(txt_indices)])
+                    plan = F_.sparse_pivot_plan(pivot_idx, query_length, self.query_window, self.key_window_times)
+                hidden_states = layer(hidden_states, None, plan, is_sparse)
+                continue
             if is_sparse == 2:
                 pivot_idx = torch.stack([
                     torch.cat((text_idx, img_indices[j][torch.tensor(

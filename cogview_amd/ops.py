@@ -355,6 +355,36 @@ def _sparse_desc(d, kv_index, sparse, b, s_q):
     d.sparse_window, d.sparse_pivots, d.sparse_pivot_bias = int(w), int(n_piv), float(bias)
 
 
+def sparse_attention_bwd(dout, q, k, v, o, lse, kv_index, sparse, pivot_inv, times, dropout=None):
+    """Backward of the sparse training form (attention_fwd with sparse=...).  The dK/dV kernel works per (batch, query
+    block) on the block's slots and leaves slot-space gradients; cogv_sparse_slot_reduce folds them onto the keys.
+    pivot_inv [b, s] int32: pivot slot of each key or -1."""
+    _need_gpu(dout, q, k, v, o)
+    b, s, H, _ = q.shape
+    w, n_piv, _bias = sparse
+    G, n_slots = s // w, kv_index.shape[2]
+    assert n_slots == n_piv + times * w and pivot_inv.dtype == torch.int32 and pivot_inv.shape == (b, s) and pivot_inv.is_contiguous()
+    dq = torch.empty((b, s, H, 64), dtype=q.dtype, device=q.device)
+    dks = torch.empty((b * G, n_slots, H, 64), dtype=q.dtype, device=q.device)
+    dvs = torch.empty_like(dks)
+    dvec = torch.empty((b, H, s), dtype=torch.float32, device=q.device)
+    d = _attn_desc(q, k, v, o, 0, dropout)
+    _sparse_desc(d, kv_index, sparse, b, s)
+    d.lse, d.dvec = lse.data_ptr(), dvec.data_ptr()
+    d.dout, d.dq, d.dk, d.dv = dout.data_ptr(), dq.data_ptr(), dks.data_ptr(), dvs.data_ptr()
+    d.do_bs, d.do_rs = _attn_strides(dout)
+    d.dq_bs, d.dq_rs = _attn_strides(dq)
+    d.dk_bs, d.dk_rs = _attn_strides(dks)
+    d.dv_bs, d.dv_rs = _attn_strides(dvs)
+    L.check(L.lib().cogv_attention_bwd(C.byref(d), _stream()), "cogv_attention_bwd")
+    dk = torch.empty((b, s, H, 64), dtype=q.dtype, device=q.device)
+    dv = torch.empty_like(dk)
+    L.check(L.lib().cogv_sparse_slot_reduce(dt_code(q), _p(dks), _p(dvs), _p(pivot_inv), _p(dk), _p(dv),
+                                            dk.stride(0), dk.stride(1), dv.stride(0), dv.stride(1), b, s, H, int(w),
+                                            int(times), int(n_piv), _stream()), "cogv_sparse_slot_reduce")
+    return dq, dk, dv
+
+
 def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, dv=None, colsum_out=None,
                   colsum_accumulate=True):
     """colsum_out [3*H*64]: (+)= column sums of (dq | dk | dv) over all tokens -- the bias gradient of the fused

@@ -130,7 +130,7 @@ typedef struct cogv_attn_desc {
    * QKV projection, mpu/sparse_transformer.py:101-110) -> colsum_partial[B * ceil(s/128)][3 * H * 64] fp32, columns
    * ordered [q heads | k heads | v heads]; requires s_q == s_k; finish with cogv_colsum_finalize. */
   float* colsum_partial;
-  /* forward only, optional: gathered keys (sparse_attention_inference, mpu/sparse_transformer.py:727-750): key slot j of
+  /* optional (forward only unless sparse_window > 0): gathered keys (sparse_attention_inference, mpu/sparse_transformer.py:727-750): key slot j of
    * batch b is row kv_index[b * kv_index_bs + j] of k and v; s_k is the number of slots (<= 4096).  The left-to-right
    * rule applies to SLOTS: the last s_q slots are the queries' own positions. */
   const int* kv_index; long long kv_index_bs;
@@ -144,6 +144,17 @@ typedef struct cogv_attn_desc {
 } cogv_attn_desc;
 int cogv_attention_fwd(const cogv_attn_desc* d, void* stream);
 int cogv_attention_bwd(const cogv_attn_desc* d, void* stream);
+/* Sparse training form, backward: cogv_attention_bwd with sparse_window > 0 writes dq as usual, but dk / dv are
+ * SLOT-SPACE buffers [B * s_q / sparse_window][s_k slots][H][64] (dk_bs / dv_bs = the stride of one (batch, query block)
+ * plane) -- the gradient of each gathered copy of a key, the same quantity the reference's autograd holds for pivot_k
+ * / window_k before torch.gather / the padded-window view scatter it back (mpu/sparse_transformer.py:689-705).
+ * cogv_sparse_slot_reduce folds them onto the keys: dk[b][r] = sum over the window slots of r (blocks r/w ... r/w +
+ * times - 1) + the pivot slot pivot_inv[b][r] (-1: r is no pivot; pivots are distinct per sample, as the reference's
+ * random.sample draws them) of the blocks that see it.  fp32 sums in a fixed order (deterministic).
+ * dk_slots / dv_slots: contiguous [B][s / window][n_pivots + times * window][H * 64]. */
+int cogv_sparse_slot_reduce(int dtype, const void* dk_slots, const void* dv_slots, const int* pivot_inv, void* dk, void* dv,
+                            long long dk_bs, int dk_rs, long long dv_bs, int dv_rs, int B, int s, int H, int window,
+                            int times, int n_pivots, void* stream);
 
 /* ------------------------------------------------------------------ embedding
  * out = dropout( table[ids - vocab_start] (0 outside the shard) [+ pos_table[pos_ids]] ), abs-max of out.

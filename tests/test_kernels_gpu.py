@@ -483,3 +483,53 @@ def test_sparse_attention_training_form_forward(ops, dtype):
     qd, kd, vd = [dev(t).permute(0, 2, 1, 3).contiguous() for t in (q, k, v)]          # [b, s, H, 64]
     out, _ = ops.attention_fwd(qd, kd, vd, kv_index=tab, sparse=(w, n_piv, math.log(s // n_piv)))
     assert rel(out.permute(0, 2, 1, 3), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("times,n_piv", [(2, 40), (3, 72)])
+def test_sparse_attention_training_form_backward(ops, dtype, times, n_piv):
+    """mpu.sparse_attention (drop-in for mpu/sparse_transformer.py:675-725) forward + input gradients against the
+    oracle restatement's autograd: dQ gathers keys through the slot table, dK/dV are computed per (batch, query block)
+    in slot space and folded back onto the keys by cogv_sparse_slot_reduce (window copies + pivot copies)."""
+    from cogview_amd import mpu
+    g = torch.Generator().manual_seed(33 + times)
+    b, nh, w = 2, 3, 128
+    s = 5 * w
+    q, k, v, dout = [rnd((b, nh, s, 64), dtype, g) for _ in range(4)]
+    pivot_idx = torch.stack([torch.cat((torch.arange(9), 9 + torch.randperm(s - 9, generator=g)[:n_piv - 9])) for _ in range(b)])
+    pam = O.sparse_rmask(s, w, times).expand(b, s, s).gather(-1, pivot_idx.unsqueeze(1).expand(b, s, n_piv))
+    qf, kf, vf = [t.float().requires_grad_(True) for t in (q, k, v)]
+    ref = O.sparse_attention(qf, kf, vf, pivot_idx, pam, w, times)
+    ref.backward(dout.float())
+    qd, kd, vd = [dev(t).requires_grad_(True) for t in (q, k, v)]
+    out = mpu.transformer.sparse_attention(qd, kd, vd, dev(pivot_idx), dev(pam), w, times)
+    out.backward(dev(dout))
+    assert rel(out, ref) < TOL[dtype]
+    for name, a, r in (("dq", qd.grad, qf.grad), ("dk", kd.grad, kf.grad), ("dv", vd.grad, vf.grad)):
+        e = rel(a, r)
+        assert e < 2 * TOL[dtype], f"{name}: {e}"
+
+
+def test_sparse_attention_training_form_dropout_adjoint(ops):
+    """With attention dropout the context is still linear in V for a fixed mask, so <dO, O(V)> == <dV, V> holds iff
+    the backward kernels regenerate exactly the forward's keep mask in slot space (row, slot counters)."""
+    from cogview_amd import mpu
+    from cogview_amd import functional as F_
+    g = torch.Generator().manual_seed(5)
+    b, nh, w, times, n_piv = 1, 2, 128, 2, 24
+    s = 3 * w
+    q, k, v, dout = [dev(rnd((b, s, nh, 64), torch.float16, g)) for _ in range(4)]
+    pivot_idx = dev(torch.stack([torch.randperm(s, generator=g)[:n_piv] for _ in range(b)]))
+    tab, inv = F_.sparse_pivot_plan(pivot_idx, s, w, times)
+    sp = (w, n_piv, math.log(s // n_piv))
+    drop = (0.25, 1234, 77)
+    o, lse = ops.attention_fwd(q, k, v, dropout=drop, kv_index=tab, sparse=sp)
+    o0, _ = ops.attention_fwd(q, k, v, kv_index=tab, sparse=sp)
+    assert 0.2 < rel(o, o0) < 2.0                   # dropout really happened
+    dq, dk, dv = ops.sparse_attention_bwd(dout, q, k, v, o, lse, tab, sp, inv, times, dropout=drop)
+    lhs = (dout.double() * o.double()).sum().item()
+    rhs = (dv.double() * v.double()).sum().item()
+    assert abs(lhs - rhs) < 5e-3 * (dout.double().norm() * o.double().norm()).item(), (lhs, rhs)
+    # the dropout-free gradient differs (sanity: the identity above is not trivially true)
+    _, _, dv0 = ops.sparse_attention_bwd(dout, q, k, v, o0, lse, tab, sp, inv, times)
+    assert rel(dv0, dv) > 0.1

@@ -531,3 +531,42 @@ def test_sparse_inference_mode_equals_dense_when_every_key_is_reachable(golden_d
     print(f"last 4 tokens on memories: all keys as pivots {e_full:.2e}, 2 text + sampled pivots {e_few:.2e} vs dense")
     assert e_full < 3e-3
     assert torch.isfinite(few_tail).all() and e_few > 1e-3          # fewer reachable keys: a different (finite) result
+
+
+def test_sparse_training_mode_equals_dense_when_the_window_covers_the_sequence():
+    """is_sparse = 1 (sparse attention training, mpu/sparse_transformer.py:492-505, 553-570, 675-725) through the whole
+    model and its backward.  With key_window_times * query_window >= sequence length every earlier key is a window slot
+    and every pivot is masked (rmask: a pivot counts only in front of the window), so loss and parameter gradients
+    must reproduce the dense model's -- through the pivot draw, the slot table, the gathered forward / dQ kernels, the
+    slot-space dK/dV kernel and the slot reduction."""
+    import random
+    from cogview_amd.fp16 import FP16_Module
+    from cogview_amd.model import GPT2Model
+    L_, V_, H_, NH_, S_, B_ = 2, 512, 128, 2, 256, 2
+    torch.manual_seed(3)
+    random.seed(3)
+    m = GPT2Model(L_, V_, H_, NH_, 0.0, 0.0, 0.0, S_, 0, False, query_window=128, key_window_times=2, num_pivot=24)
+    model = FP16_Module(m.cuda(), dtype=torch.float16, keep_half_outputs=True).train()
+    tokens = torch.randint(0, V_, (B_, S_), device="cuda")
+    labels = torch.randint(0, V_, (B_, S_), device="cuda")
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    txt = torch.zeros(B_, S_, dtype=torch.bool, device="cuda")
+    txt[:, :8] = True
+    from cogview_amd import mpu
+    grads = {}
+    for mode in (0, 1):
+        model.module._cogv_arena.zero_grad()
+        logits, = model(tokens, pos, 0, txt, ~txt, mode)
+        loss = mpu.vocab_parallel_cross_entropy(logits.contiguous(), labels).mean()
+        (loss * 64.0).backward()
+        from cogview_amd import functional as F_
+        F_.flush_weight_grads()
+        torch.cuda.synchronize()
+        grads[mode] = (loss.item(), logits.detach().float().cpu(),
+                       {n: p_.grad.detach().float().cpu().clone() for n, p_ in model.named_parameters() if p_.grad is not None})
+    assert abs(grads[0][0] - grads[1][0]) < 2e-3 * abs(grads[0][0])
+    e_log = rel(grads[1][1], grads[0][1])
+    worst = max(rel(grads[1][2][n], grads[0][2][n]) for n in grads[0][2])
+    print(f"is_sparse=1 vs dense (window covers the sequence): logits rel-L2 {e_log:.2e}, worst gradient rel-L2 {worst:.2e}")
+    assert set(grads[0][2]) == set(grads[1][2])
+    assert e_log < 3e-3 and worst < 1.5e-2
