@@ -101,3 +101,44 @@ def test_mask_translation():
     bad[0, 0, 3, 9] = 1
     with pytest.raises(NotImplementedError):
         mask_to_sep(bad, 16, 16)
+
+
+def test_sparse_pivot_plan_matches_reference_masks(golden_dir):
+    """The slot table / inverse pivot map the sparse-training kernels consume (functional.sparse_pivot_plan) against the
+    reference's own masks in tests/golden/sparse_attention.npz: a pivot slot is unmasked exactly where the reference's
+    pivot_attention_mask (rmask gathered at the pivots) is 1, a window slot holds key (g - times + 1) w + c, front
+    padding is masked, and every key is reachable from the slots cogv_sparse_slot_reduce sums for it."""
+    import os
+    import numpy as np
+    import cogview_amd.mpu  # noqa: F401  (package import order)
+    from cogview_amd.functional import sparse_pivot_plan
+    z = np.load(os.path.join(golden_dir, "sparse_attention.npz"))
+    b, nh, s, hn, w, times, n_piv = [int(x) for x in z["cfg"]]
+    pivot_idx = torch.from_numpy(z["pivot_idx"])
+    pam = torch.from_numpy(z["pivot_attention_mask"])                       # [b, s, n_piv] from the reference
+    tab, inv = sparse_pivot_plan(pivot_idx, s, w, times)
+    G = s // w
+    assert tab.shape == (b, G, n_piv + times * w) and tab.dtype == torch.int32 and inv.shape == (b, s)
+    rows = (tab & 0x7fffffff).long()
+    flag = tab < 0
+    for g in range(G):
+        # pivot slots: same for all queries of a block (the reference's mask is block-constant there)
+        blk = pam[:, g * w:(g + 1) * w]
+        assert torch.equal(blk.min(1).values, blk.max(1).values)
+        assert torch.equal(~flag[:, g, :n_piv], blk[:, 0] > 0.5)
+        assert torch.equal(rows[:, g, :n_piv], pivot_idx.long())
+        key = (g - times + 1) * w + torch.arange(times * w)
+        assert torch.equal(flag[0, g, n_piv:], key < 0)
+        assert torch.equal(rows[0, g, n_piv:][key >= 0], key[key >= 0])
+    # slot reduction coverage: unmasked slots holding key r == the slots the reduce kernel visits for r
+    for bi in range(b):
+        for r in range(0, s, 7):
+            have = {(g, j) for g in range(G) for j in torch.nonzero((rows[bi, g] == r) & ~flag[bi, g]).flatten().tolist()}
+            want = {(g, n_piv + r - (g - times + 1) * w) for g in range(r // w, min(G - 1, r // w + times - 1) + 1)}
+            pj = int(inv[bi, r])
+            if pj >= 0:
+                assert int(pivot_idx[bi, pj]) == r
+                want |= {(g, pj) for g in range(r // w + times, G)}
+            else:
+                assert r not in pivot_idx[bi].tolist()
+            assert have == want, (bi, r)
