@@ -31,6 +31,19 @@ def sources():
     return sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hip"))
 
 
+# Extra translation units compiled from a source that is already in sources(), with a macro selecting what is
+# instantiated: the generation-4 GEMM kernel's 2 dtypes x 4 layouts build as eight objects in parallel
+# (gemm.hip -DCOGV_W4_TU=k defines only cogv_w4_launch_k).
+EXTRA_UNITS = [("gemm.hip", f"gemm_w4_{k}.o", [f"-DCOGV_W4_TU={k}"]) for k in range(8)]
+
+
+def units():
+    """(source, object, extra flags) of every object that goes into the library."""
+    out = [(src, os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o"), []) for src in sources()]
+    out += [(os.path.join(HERE, src), os.path.join(OBJ_DIR, obj), flags) for src, obj, flags in EXTRA_UNITS]
+    return out
+
+
 def _deps_mtime():
     hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".cuh", ".h"))]
     hdrs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
@@ -39,10 +52,10 @@ def _deps_mtime():
 
 # Kernels that issue LDS reads through inline asm and wait for them in a LATER statement: a compiler spill of
 # the destination register between the two would store garbage.  They must be spill-free.
-NO_SPILL_KERNELS = ("attn_fwd_kernel", "attn_bwd_dq_kernel", "gemm_glds_kernel", "gemm_pp64_kernel")
+NO_SPILL_KERNELS = ("attn_fwd_kernel", "attn_bwd_dq_kernel", "gemm_glds_kernel", "gemm_pp64_kernel", "gemm_w4_kernel")
 
 
-def _scratch_in_mfma_loops(src):
+def _scratch_in_mfma_loops(src, extra=()):
     """Compile `src` to device assembly and return the kernels that touch scratch INSIDE an innermost loop
     containing MFMAs (the k-loop, where the asynchronous asm LDS reads live).  A spill outside it -- e.g. a value
     parked across the persistent tile loop and reloaded at the top of each item -- cannot sit between an asm read
@@ -50,7 +63,7 @@ def _scratch_in_mfma_loops(src):
     import re, tempfile
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "k.s")
-        r = subprocess.run([_hipcc()] + FLAGS + ["--cuda-device-only", "-S", src, "-o", asm], capture_output=True, text=True)
+        r = subprocess.run([_hipcc()] + FLAGS + list(extra) + ["--cuda-device-only", "-S", src, "-o", asm], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
         lines = open(asm).read().splitlines()
@@ -93,7 +106,7 @@ def _scratch_in_mfma_loops(src):
     return bad
 
 
-def _check_no_spill(src, log):
+def _check_no_spill(src, log, extra=()):
     import re
     name, spilling = None, []
     for line in log.splitlines():
@@ -104,18 +117,18 @@ def _check_no_spill(src, log):
         if m and name and any(k in name for k in NO_SPILL_KERNELS) and int(m.group(1)) != 0:
             spilling.append((name, m.group(1)))
     if spilling:
-        bad = _scratch_in_mfma_loops(src)
+        bad = _scratch_in_mfma_loops(src, extra)
         if bad:
             raise RuntimeError(f"{src}: kernel(s) {bad} use asynchronous asm LDS reads and spill registers inside the "
                                f"MFMA loop: unsafe, refusing to build")
 
 
-def _compile(src, obj):
-    cmd = [_hipcc()] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
+def _compile(src, obj, extra=()):
+    cmd = [_hipcc()] + FLAGS + list(extra) + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-    _check_no_spill(src, r.stderr)
+    _check_no_spill(src, r.stderr, extra)
     return obj
 
 
@@ -124,15 +137,14 @@ def build(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     dep_t = _deps_mtime()
     jobs, objs = [], []
-    for src in sources():
-        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+    for src, obj, flags in units():
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), dep_t):
-            jobs.append((src, obj))
+            jobs.append((src, obj, flags))
     if jobs:
         if verbose:
             print(f"[cogview_amd] hipcc {ARCH}: compiling {len(jobs)} file(s)", flush=True)
-        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 8, len(jobs))) as ex:
             list(ex.map(lambda a: _compile(*a), jobs))
     if jobs or not os.path.exists(LIB_PATH) or any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs):
         cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs

@@ -1155,6 +1155,332 @@ void gemm_pp64_kernel(const GroupArgs ga) {
   }
 }
 
+// =====================================================================================================
+// Generation-4 kernel: the same 256x256x64 tile, persistent queues, LDS-DMA granule ring and epilogue as
+// generation 3, but FOUR waves of 128x128 (one per SIMD, accumulators in the 256 AGPRs) instead of eight of
+// 128x64.  A 128x128 wave tile reads 256 B of fragments per MFMA instead of 384 B: the GEMM is power limited
+// and the probe (tools/probes/gemm_exp.py) puts the fragment reads at ~19 % of the loop's cost, so fewer LDS
+// bytes per flop is the lever -- at the price of no second wave per SIMD to hide latency: the next fragments
+// are read between the MFMAs of the same wave (software pipeline, order pinned by sched_barrier).
+//
+// k-tile = 4 granules of 16 KiB (128 rows or columns x 64 k): A01 = tile rows [0,64) u [128,192), A23 = the
+// rest, B01 / B23 likewise over the tile's columns; wave (wr, wc) owns granule rows wr*64.. of the A granules
+// and wc*64.. of the B granules.  A k-tile is four quarter-steps of 32 MFMAs, each against one A half and one
+// B half, ordered so that only ONE half changes between consecutive quarter-steps; its 8 fragments are read
+// during the previous quarter-step into the register set that just died (4 sets of 32 registers):
+//
+//   q0  A01 x B01   reads B23(T)          | half-step 2T  : DMA A01(T+2), B01(T+2)
+//   q1  A01 x B23   reads A23(T)          |
+//   q2  A23 x B23   reads A01(T+1)        | half-step 2T+1: DMA B23(T+2), A23(T+2)
+//   q3  A23 x B01   reads B01(T+1)        |
+//
+// One barrier per half-step.  The granules read during half-step h were issued in half-step h-3 and are
+// certified by every wave's vmcnt(16) (8 DMA instructions per wave per half-step) before the barrier that opens
+// h; the granules read during h-1 are free from that barrier on and are re-issued (for two k-tiles later) in h.
+// LDS: A granules in [0, 64 KiB) at buffer * 32 KiB + half * 16 KiB, B granules likewise in [64, 128 KiB), then 4 private
+// 2-KiB epilogue strips.  Every fragment read is "per-lane register + immediate" (the buffer / granule / k-step part
+// fits the 16-bit offset field), so the loop holds 16 address registers instead of one per (buffer, granule, block).
+template <int OFF>
+__device__ __forceinline__ void nat_issue_o(uint32_t addr, u32x4& o) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(o) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF, int ROWB>
+__device__ __forceinline__ void tr_issue16_o(uint32_t addr, TrRaw& o) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=&v"(o.lo), "=&v"(o.hi) : "v"(addr), "n"(OFF), "n"(OFF + 4 * ROWB) : "memory");
+}
+// MFMA with the accumulator pinned to the AGPR file and updated in place.  With all 256 AGPRs holding accumulators the
+// register allocator has no slack: left to itself (builtin form) it parks parts of the loop-carried accumulators in
+// VGPRs, picks untied destination registers and copies / spills around every MFMA.
+template <typename T>
+__device__ __forceinline__ void mfma16_inplace(f32x4& c, const typename HT<T>::v8& a, const typename HT<T>::v8& b) {
+  if constexpr (std::is_same<T, bf16_t>::value)
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// LDS-DMA of 16 bytes per lane in the "SGPR base + 32-bit lane offset" form, LDS destination (wave-uniform) through M0
+__device__ __forceinline__ void dma16(const void* base, uint32_t lane_off, uint32_t lds_addr) {
+  const uint64_t b64 = (uint64_t)(uintptr_t)base;
+  const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
+  base = reinterpret_cast<const void*>((uintptr_t)bu);
+  lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_off), "s"(base), "s"(lds_addr) : "memory", "m0");
+}
+template <int V> using IC = std::integral_constant<int, V>;
+template <typename F, int... R>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, R...>) { (f(IC<R>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <typename T, bool AT, bool BT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gemm_w4_kernel(const GroupArgs ga) {
+  constexpr int NW = 4, TBM = 256, TBN = 256, KT = 64;
+  constexpr int GRAN = 16384, BUF = 32768, BREG = 65536, ROWB = 256;   // BUF: buffer stride inside an operand's region
+  constexpr int G_A01 = 0, G_A23 = 1, G_B01 = 2, G_B23 = 3;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];     // 2 * BUF + NW * 2048
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l15 = lane & 15, kb = lane >> 4;
+  const int nitems = ga.item_start[ga.count];
+  const uint32_t smem_u32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)smem);
+
+  struct Item {
+    int pi, m0, n0, ksplit, kt0, nk;
+    uint32_t off[4][4];                // [granule][piece]: per-lane byte offsets against a wave-uniform base
+  };
+  auto setup = [&](int item, Item& it) {
+    int pi = 0;
+#pragma unroll
+    for (int t = 1; t < MAX_GROUP; ++t) pi += (t < ga.count && item >= ga.item_start[t]) ? 1 : 0;
+    const GemmArgs& p = ga.g[pi];
+    const int local = item - ga.item_start[pi];
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = local % nwg;
+    it.pi = pi; it.ksplit = local / nwg;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    constexpr int GROUP_M = 4;
+    const int in_group = GROUP_M * p.tiles_n;
+    const int group_id = wgid / in_group;
+    const int first_m = group_id * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tile_m = first_m + (wgid % in_group) % gsz;
+    const int tile_n = (wgid % in_group) / gsz;
+    // (the integer divisions above run on the VALU: bring the wave-uniform results back to SGPRs, so that the k-loop
+    //  counter, the DMA base pointers and the LDS destinations stay scalar)
+    it.ksplit = __builtin_amdgcn_readfirstlane(it.ksplit);
+    it.m0 = __builtin_amdgcn_readfirstlane(tile_m * TBM); it.n0 = __builtin_amdgcn_readfirstlane(tile_n * TBN);
+    it.kt0 = it.ksplit * p.ktiles_per_split;
+    it.nk = min(p.K / KT, it.kt0 + p.ktiles_per_split) - it.kt0;       // >= 1 by construction
+    // Piece = one 1-KiB LDS-DMA instruction; a granule is 16 pieces, wave w owns pieces i*4 + w.
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const bool isB = gi >= 2;
+      const bool trn = isB ? BT : AT;
+      const int g = gi & 1;
+      const int t0 = isB ? it.n0 : it.m0, lim = isB ? p.N : p.M, ld = isB ? p.ldb : p.lda;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int piece = i * NW + wave;
+        if (!trn) {
+          const int row = piece * 8 + (lane >> 3);                 // granule row 0..127
+          const int c = (lane & 7) ^ swz(row);
+          const int tr = (row & 63) + 128 * (row >> 6) + 64 * g;   // tile row / column
+          const int gm = min(t0 + tr, lim - 1);
+          it.off[gi][i] = (uint32_t)(((size_t)gm * ld + c * 8) * 2);
+        } else {
+          const int off = piece * 1024 + lane * 16;
+          const int krow = off / ROWB, pc = (off % ROWB) >> 4;
+          const int c = pc ^ trswz16(krow);
+          const int gc = c * 8;                                    // granule column 0..127
+          const int tcol = (gc & 63) + 128 * (gc >> 6) + 64 * g;
+          const int col = min(t0 + tcol, lim - 8);
+          it.off[gi][i] = (uint32_t)(((size_t)krow * ld + col) * 2);
+        }
+      }
+    }
+  };
+  auto dma = [&](const Item& it, int gi, int i, int kt, int buf) {
+    if (COGV_EXP & 1) return;
+    const GemmArgs& p = ga.g[it.pi];
+    const bool isB = gi >= 2;
+    const bool trn = isB ? BT : AT;
+    const int ld = isB ? p.ldb : p.lda;
+    const size_t kstride = trn ? (size_t)KT * ld * 2 : (size_t)KT * 2;
+    const char* g = reinterpret_cast<const char*>(isB ? p.B : p.A) + (size_t)(it.kt0 + kt) * kstride;
+    const uint32_t l = smem_u32 + (uint32_t)((isB ? BREG : 0) + buf * BUF + (gi & 1) * GRAN + (i * NW + wave) * 1024);
+    dma16(g, it.off[gi][i], l);
+  };
+  // two whole k-tiles, in the order the loop certifies them: [A01 B01](0) [B23 A23](0) [A01 B01](1) [B23 A23](1)
+  auto prologue = [&](const Item& it) {
+    const int t1 = min(1, it.nk - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(it, G_A01, i, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(it, G_B01, i, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(it, G_B23, i, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(it, G_A23, i, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(it, G_A01, i, t1, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(it, G_B01, i, t1, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(it, G_B23, i, t1, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(it, G_A23, i, t1, 1);
+  };
+
+  // per-lane fragment addresses inside a granule (k-step 0): v_mfma_f32_16x16x32, lane l supplies row (l & 15)
+  // of a 16-row block and the 8 contraction slots of k-block (l >> 4)
+  uint32_t adA[2][4], adB[2][4];       // [k-step][block] (a natural region's k-step flips address bit 6: not an add)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wr * 64 + 16 * i, rb = wc * 64 + 16 * i;
+    adA[0][i] = AT ? tr_addr16<ROWB>(smem, ra, lane)
+                   : (uint32_t)(uintptr_t)smem + (uint32_t)((ra + l15) * 128 + ((kb ^ swz(ra + l15)) << 4));
+    adB[0][i] = BT ? tr_addr16<ROWB>(smem + BREG, rb, lane)
+                   : (uint32_t)(uintptr_t)(smem + BREG) + (uint32_t)((rb + l15) * 128 + ((kb ^ swz(rb + l15)) << 4));
+    adA[1][i] = adA[0][i] ^ 64u; adB[1][i] = adB[0][i] ^ 64u;
+  }
+
+  struct Frag { u32x4 n[2][4]; TrRaw t[2][4]; };     // [k-step][16-row block]; one of the two forms is live
+  // one fragment (k-step ks, block blk) of granule gi in buffer buf
+  auto read1 = [&](Frag& f, auto gic, auto bufc, auto ksc, auto blkc) {
+    if (COGV_EXP & 2) return;
+    constexpr int gi = decltype(gic)::value, buf = decltype(bufc)::value, ks = decltype(ksc)::value, blk = decltype(blkc)::value;
+    constexpr bool isB = gi >= 2;
+    constexpr int off = buf * BUF + (gi & 1) * GRAN;
+    if (isB ? BT : AT) tr_issue16_o<off + ks * 32 * ROWB, ROWB>(isB ? adB[0][blk] : adA[0][blk], f.t[ks][blk]);
+    else nat_issue_o<off>(isB ? adB[ks][blk] : adA[ks][blk], f.n[ks][blk]);
+  };
+  auto land = [&](Frag& f, bool trn) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (trn) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.t[ks][b].lo), "+v"(f.t[ks][b].hi) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.n[ks][b]) : : "memory");
+      }
+  };
+
+  __shared__ int s_next;
+  const int xq = blockIdx.x & 7;
+  if (threadIdx.x == 0) s_next = xq + 8 * atomicAdd(ga.sched + xq, 1);
+  __syncthreads();
+  Item cur;
+  int item = __builtin_amdgcn_readfirstlane(s_next);     // wave-uniform by construction: keeps the DMA bases in SGPRs
+  if (item < nitems) { setup(item, cur); prologue(cur); }
+#pragma unroll 1
+  while (item < nitems) {
+    const GemmArgs& p = ga.g[cur.pi];
+    const int nk = cur.nk;
+    f32x4 acc[2][8][4];                // [column half][16-row block 4a+i][16-column block j]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Frag fA, fI, fB0, fB1;
+    // pre-step: the first A01 / B01 fragments (the only exposed LDS latency of the item)
+    wait_vmcnt<24>();
+    __builtin_amdgcn_s_barrier();
+    int grabbed = 0;                                       // the item after this one: asked for now, used after the k-loop
+    if (threadIdx.x == 0) grabbed = atomicAdd(ga.sched + xq, 1);
+    static_for<8>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      read1(fA, IC<G_A01>{}, IC<0>{}, IC<(r >> 2)>{}, IC<(r & 3)>{});
+      read1(fB0, IC<G_B01>{}, IC<0>{}, IC<(r >> 2)>{}, IC<(r & 3)>{});
+    });
+    land(fA, AT); land(fB0, BT);
+
+    // one quarter-step: acc[bh][4 ah + i][j] += A(fa) x B(fb) while granule gin of buffer bin is read into fin and
+    // granule gd of k-tile ktd is DMA'd into buffer bd
+    auto quarter = [&](auto ahc, auto bhc, Frag& fa, Frag& fb, Frag& fin, auto ginc, auto binc, int gd, int ktd, int bd) {
+      constexpr int ah = decltype(ahc)::value, bh = decltype(bhc)::value, gin = decltype(ginc)::value;
+      static_for<8>([&](auto rc) {
+          constexpr int r = decltype(rc)::value, ks = r >> 2, i = r & 3;
+          // the 8 incoming fragments go out in front of the first four MFMA groups (two each: >= 256 MFMA cycles
+          // before land()), the 4 DMA pieces in front of the last four
+          if constexpr (r < 4) {
+            read1(fin, ginc, binc, IC<((2 * r) >> 2)>{}, IC<((2 * r) & 3)>{});
+            read1(fin, ginc, binc, IC<((2 * r + 1) >> 2)>{}, IC<((2 * r + 1) & 3)>{});
+          } else {
+            dma(cur, gd, r - 4, ktd, bd);
+          }
+          typename HT<T>::v8 va;
+          if (AT) va = tr_pack<T>(fa.t[ks][i]); else __builtin_memcpy(&va, &fa.n[ks][i], 16);
+          if (COGV_EXP & 4) asm volatile("" :: "v"(va));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            typename HT<T>::v8 vb;
+            if (BT) vb = tr_pack<T>(fb.t[ks][j]); else __builtin_memcpy(&vb, &fb.n[ks][j], 16);
+            if (COGV_EXP & 4) { asm volatile("" :: "v"(vb)); continue; }
+            // operands swapped: D[n][m] -> lane (m = l & 15) holds columns n = 4 (l >> 4) .. +3 of its row
+            mfma16_inplace<T>(acc[bh][4 * ah + i][j], vb, va);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+      });
+      land(fin, gin >= 2 ? BT : AT);
+    };
+    // one k-tile; fb01 holds B01(kt), fbx is free and ends up holding B01(kt + 1)
+    auto tile = [&](int kt, auto bufc, Frag& fb01, Frag& fbx) {
+      constexpr int buf = decltype(bufc)::value;
+      const int t2 = min(kt + 2, nk - 1);
+      wait_vmcnt<16>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      quarter(IC<0>{}, IC<0>{}, fA, fb01, fbx, IC<G_B23>{}, IC<buf>{}, G_A01, t2, buf);
+      quarter(IC<0>{}, IC<1>{}, fA, fbx, fI, IC<G_A23>{}, IC<buf>{}, G_B01, t2, buf);
+      wait_vmcnt<16>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      quarter(IC<1>{}, IC<1>{}, fI, fbx, fA, IC<G_A01>{}, IC<(buf ^ 1)>{}, G_B23, t2, buf);
+      quarter(IC<1>{}, IC<0>{}, fI, fb01, fbx, IC<G_B01>{}, IC<(buf ^ 1)>{}, G_A23, t2, buf);
+    };
+    for (int kt = 0; kt + 1 < nk; kt += 2) {               // two k-tiles per trip: the B register sets swap roles
+      tile(kt, IC<0>{}, fB0, fB1);
+      tile(kt + 1, IC<1>{}, fB1, fB0);
+    }
+    if (nk & 1) tile(nk - 1, IC<0>{}, fB0, fB1);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vmcnt<0>();                                        // the (redundant) tail prefetches of this item
+
+    // ---- next item's prologue goes out BEFORE this item's epilogue (the barrier also retires every wave's last reads)
+    if (threadIdx.x == 0) s_next = xq + 8 * grabbed;
+    __syncthreads();
+    const int next = __builtin_amdgcn_readfirstlane(s_next);
+    const Item done = cur;
+    if (next < nitems) { setup(next, cur); prologue(cur); }
+
+    uint32_t amax_pk = 0u;
+    float* strip = reinterpret_cast<float*>(smem + 2 * BREG + wave * 2048);
+    constexpr int F_FWD_DROP = COGV_EPI_BIAS | COGV_EPI_DROPOUT | COGV_EPI_ABSMAX, F_FWD_GELU = COGV_EPI_BIAS | COGV_EPI_GELU;
+    const int mb = done.m0 + wr * 128, nb = done.n0 + wc * 128, csr = (done.m0 >> 7) + wr;
+#define W4_EPI(F_)                                                                                   \
+  do {                                                                                               \
+    pp64_epilogue<T, F_>(p, acc[0], strip, mb, nb, done.ksplit, lane, amax_pk, csr);                 \
+    pp64_epilogue<T, F_>(p, acc[1], strip, mb, nb + 64, done.ksplit, lane, amax_pk, csr);            \
+  } while (0)
+    if (p.splitk > 1) W4_EPI(-2);
+    else if (p.out_f32) W4_EPI(-1);
+    else if (p.flags == 0) W4_EPI(0);
+    else if (p.flags == COGV_EPI_BIAS) W4_EPI(COGV_EPI_BIAS);
+    else if (p.flags == COGV_EPI_ACCUM) W4_EPI(COGV_EPI_ACCUM);
+    else if (p.flags == F_FWD_DROP) W4_EPI(F_FWD_DROP);
+    else if (p.flags == F_FWD_GELU) W4_EPI(F_FWD_GELU);
+    else if (p.flags == (COGV_EPI_DGELU | COGV_EPI_COLSUM)) W4_EPI(COGV_EPI_DGELU | COGV_EPI_COLSUM);
+    else if (p.flags == COGV_EPI_DGELU) W4_EPI(COGV_EPI_DGELU);
+    else W4_EPI(-1);
+#undef W4_EPI
+    if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
+      uint32_t wv = max(amax_pk & 0xffffu, amax_pk >> 16);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) wv = max(wv, (uint32_t)__shfl_xor((int)wv, o, 64));
+      if (lane == 0) atomic_max_nonneg(p.absmax, bits_to_f<T>((uint16_t)wv));
+    }
+    item = next;
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(ga.sched + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) ga.sched[t] = 0;
+      __threadfence();
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   __shared__ float red[16];
@@ -1229,7 +1555,22 @@ int* sched_slot() {
   return pool[dev] + 16 * (turn[dev]++ % SLOTS);
 }
 
-template <typename T, bool AT, bool BT>
+#ifndef COGV_W4_TU
+// The generation-4 kernel's eight instantiations (2 dtypes x 4 layouts) are compiled from this same file in eight
+// separate translation units (-DCOGV_W4_TU=k, see build.py: they build in parallel); unit k exports cogv_w4_launch_k.
+#define W4_DECL(k) extern "C" __attribute__((visibility("hidden"))) int cogv_w4_launch_##k(const void* ga, int grid, void* stream);
+W4_DECL(0) W4_DECL(1) W4_DECL(2) W4_DECL(3) W4_DECL(4) W4_DECL(5) W4_DECL(6) W4_DECL(7)
+#undef W4_DECL
+typedef int (*w4_launch_fn)(const void*, int, void*);
+const w4_launch_fn W4_LAUNCH[8] = {cogv_w4_launch_0, cogv_w4_launch_1, cogv_w4_launch_2, cogv_w4_launch_3,
+                                   cogv_w4_launch_4, cogv_w4_launch_5, cogv_w4_launch_6, cogv_w4_launch_7};
+// unit index: bit 2 = fp16 (else bf16), bits 1..0 = layout: 0 NT (forward), 1 NN (dgrad: B stored [K, N]),
+// 2 TN (wgrad: both stored contraction-major), 3 A stored [K, M] only
+template <typename T, bool AT, bool BT> constexpr int w4_unit() {
+  return (std::is_same<T, f16_t>::value ? 4 : 0) + (AT ? (BT ? 2 : 3) : (BT ? 1 : 0));
+}
+
+template <typename T, bool AT, bool BT, int GEN = 3>
 int launch_pp64(GroupArgs& ga, hipStream_t st) {
   constexpr int shmem = 2 * 65536;
   ga.sched = sched_slot();
@@ -1241,23 +1582,27 @@ int launch_pp64(GroupArgs& ga, hipStream_t st) {
     ga.item_start[i + 1] = ga.item_start[i] + a.tiles_m * a.tiles_n * a.splitk;
   }
   for (int i = ga.count; i < MAX_GROUP; ++i) ga.item_start[i + 1] = ga.item_start[ga.count];
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp64_kernel<T, AT, BT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-    attr_set = true;
-  }
   const int num_cu = num_cus();
   const int items = ga.item_start[ga.count];
-  hipLaunchKernelGGL((gemm_pp64_kernel<T, AT, BT>), dim3(items < num_cu ? items : num_cu), dim3(512), shmem, st, ga);
-  return COGV_OK;
+  if constexpr (GEN == 4) {
+    return W4_LAUNCH[w4_unit<T, AT, BT>()](&ga, items < num_cu ? items : num_cu, st);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp64_kernel<T, AT, BT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_pp64_kernel<T, AT, BT>), dim3(items < num_cu ? items : num_cu), dim3(512), shmem, st, ga);
+    return COGV_OK;
+  }
 }
-template <typename T>
+template <typename T, int GEN = 3>
 int launch_pp64_layout(int trans_a, int trans_b, GroupArgs& ga, hipStream_t st) {
-  if (!trans_a && !trans_b) return launch_pp64<T, false, false>(ga, st);
-  if (!trans_a && trans_b) return launch_pp64<T, false, true>(ga, st);
-  if (trans_a && trans_b) return launch_pp64<T, true, true>(ga, st);
-  return launch_pp64<T, true, false>(ga, st);
+  if (!trans_a && !trans_b) return launch_pp64<T, false, false, GEN>(ga, st);
+  if (!trans_a && trans_b) return launch_pp64<T, false, true, GEN>(ga, st);
+  if (trans_a && trans_b) return launch_pp64<T, true, true, GEN>(ga, st);
+  return launch_pp64<T, true, false, GEN>(ga, st);
 }
 template <typename T>
 void launch_splitk_reduce(GemmArgs& a, hipStream_t st) {
@@ -1273,17 +1618,19 @@ int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
   if ((d->flags & COGV_EPI_COLSUM) && !glds_ok) return COGV_ERR_UNSUPPORTED;
   if (glds_ok) {
     // variant 3: generation 2 -- 256x128x32, 4 waves (128x64 each), two workgroups per CU (M or N < 256, huge operands)
-    // variant 9: generation 3 -- 256x256x64 ping-pong, persistent, 16x16x32 MFMAs: default whenever its 256 tile
-    //            slots per round are filled about as well as variant 3's 512
+    // variant 9: generation 3 -- 256x256x64 ping-pong (8 waves), persistent, 16x16x32 MFMAs
+    // variant 10: generation 4 -- the same tile and ring with 4 waves of 128x128 (a third fewer LDS fragment bytes per
+    //            flop: +5-7 % forward / dgrad, +15 % wgrad over generation 3): default whenever the 256 tile slots per
+    //            round are filled about as well as variant 3's 512
     // (the intermediate designs -- 256x128x64 / 128x128x32 / 256x256x32 rings, ping-pong on 32-deep tiles -- measured
     //  within +-5 % of variant 3 and were removed; DESIGN.md section 4 keeps the numbers)
     int variant = d->kernel_variant;
     const size_t a_span = (size_t)(d->trans_a ? a.K : a.M) * a.lda * 2, b_span = (size_t)(d->trans_b ? a.K : a.N) * a.ldb * 2;
     const bool v9_ok = a.M >= 256 && a.N >= 256 && a_span < (1ull << 32) && b_span < (1ull << 32);   // 32-bit DMA offsets
-    if (variant != 0 && variant != 3 && variant != 9) variant = 0;
-    if ((d->flags & COGV_EPI_COLSUM) && (!v9_ok || (variant != 0 && variant != 9))) return COGV_ERR_UNSUPPORTED;
-    if (d->flags & COGV_EPI_COLSUM) variant = 9;
-    if (variant == 9 && !v9_ok) variant = 0;
+    if (variant != 0 && variant != 3 && variant != 9 && variant != 10) variant = 0;
+    if ((d->flags & COGV_EPI_COLSUM) && (!v9_ok || (variant != 0 && variant != 9 && variant != 10))) return COGV_ERR_UNSUPPORTED;
+    if ((d->flags & COGV_EPI_COLSUM) && variant != 9) variant = 10;
+    if ((variant == 9 || variant == 10) && !v9_ok) variant = 0;
     if (variant == 0) {
       variant = 3;
       if (v9_ok) {
@@ -1291,13 +1638,14 @@ int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
         const int i3 = ((a.M + 255) / 256) * ((a.N + 127) / 128) * a.splitk, i9 = ((a.M + 255) / 256) * ((a.N + 255) / 256) * a.splitk;
         const float e3 = (float)i3 / (float)(((i3 + 2 * cu - 1) / (2 * cu)) * 2 * cu);
         const float e9 = (float)i9 / (float)(((i9 + cu - 1) / cu) * cu);
-        if (e9 * 1.1f >= e3) variant = 9;      // measured 1.1-1.4x at equal fill (16x16x32 MFMAs: less power per flop)
+        if (e9 * 1.1f >= e3) variant = 10;     // measured 1.1-1.4x at equal fill (16x16x32 MFMAs: less power per flop)
       }
     }
     if (variant == 3) launch_glds_layout<T, 2, 2, 4, 2, 32>(d, a, st);
-    else if (variant == 9) {                                                            // generation 3 (operands < 4 GiB)
+    else if (variant == 9 || variant == 10) {                                           // generations 3 / 4 (operands < 4 GiB)
       GroupArgs ga; ga.count = 1; ga.g[0] = a;
-      const int rc = launch_pp64_layout<T>(d->trans_a, d->trans_b, ga, st);
+      const int rc = variant == 10 ? launch_pp64_layout<T, 4>(d->trans_a, d->trans_b, ga, st)
+                                   : launch_pp64_layout<T, 3>(d->trans_a, d->trans_b, ga, st);
       if (rc != COGV_OK) return rc;
       a.tiles_m = ga.g[0].tiles_m; a.tiles_n = ga.g[0].tiles_n;
     }
@@ -1436,8 +1784,8 @@ extern "C" int cogv_gemm_grouped(const cogv_gemm_desc* descs, int count, void* s
     if (d->trans_b && (a.N & 7)) return COGV_ERR_UNSUPPORTED;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int lrc = descs[0].dtype == COGV_F16 ? launch_pp64_layout<f16_t>(descs[0].trans_a, descs[0].trans_b, ga, st)
-                                             : launch_pp64_layout<bf16_t>(descs[0].trans_a, descs[0].trans_b, ga, st);
+  const int lrc = descs[0].dtype == COGV_F16 ? launch_pp64_layout<f16_t, 4>(descs[0].trans_a, descs[0].trans_b, ga, st)
+                                             : launch_pp64_layout<bf16_t, 4>(descs[0].trans_a, descs[0].trans_b, ga, st);
   if (lrc != COGV_OK) return lrc;
   for (int i = 0; i < count; ++i)
     if (ga.g[i].splitk > 1) {
@@ -1446,3 +1794,24 @@ extern "C" int cogv_gemm_grouped(const cogv_gemm_desc* descs, int count, void* s
     }
   return cogv_check_launch();
 }
+#else   // COGV_W4_TU: one instantiation of the generation-4 kernel and its launcher
+}  // namespace
+
+#define W4_CAT2(a, b) a##b
+#define W4_CAT(a, b) W4_CAT2(a, b)
+extern "C" __attribute__((visibility("hidden"))) int W4_CAT(cogv_w4_launch_, COGV_W4_TU)(const void* ga, int grid, void* stream) {
+  using T = std::conditional<(COGV_W4_TU & 4) != 0, f16_t, bf16_t>::type;
+  constexpr int L = COGV_W4_TU & 3;
+  constexpr bool AT = L >= 2, BT = L == 1 || L == 2;
+  constexpr int shmem = 2 * 65536 + 4 * 2048;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<T, AT, BT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_w4_kernel<T, AT, BT>), dim3(grid), dim3(256), shmem, reinterpret_cast<hipStream_t>(stream),
+                     *reinterpret_cast<const GroupArgs*>(ga));
+  return COGV_OK;
+}
+#endif

@@ -163,7 +163,7 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
     if accumulate:
         flags |= L.EPI_ACCUM
     lib = L.lib()
-    fuse_colsum = (colsum_out is not None and M >= 256 and N >= 256 and K % 64 == 0 and variant in (0, 9)
+    fuse_colsum = (colsum_out is not None and M >= 256 and N >= 256 and K % 64 == 0 and variant in (0, 9, 10)
                    and out.dtype != torch.float32 and a.stride(0) * a.shape[0] * 2 < 2 ** 32
                    and b.stride(0) * b.shape[0] * 2 < 2 ** 32 and (trans_b is False or N % 8 == 0) and not trans_a)
     if fuse_colsum:
