@@ -219,8 +219,8 @@ def main():
         "mfma_roofline_frac_end_to_end": value / world * fpt / 1e12 / PEAK_MFMA_TFLOPS,
     }
     if gemm_stats is not None:
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp64_kernel<%s> (256x256x64 ping-pong, persistent work queues, 16x16x32 MFMA; NT fwd, NN dgrad, "
-                                                       "TN wgrad grouped four per launch)" % args.dtype,
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_w4_kernel<%s> (256x256x64 tiles, 4 waves of 128x128, persistent work queues, 16x16x32 MFMA; NT fwd, "
+                                                       "NN dgrad, TN wgrad grouped four per launch)" % args.dtype,
                            "achieved": gemm_stats["tflops"], "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": gemm_stats["tflops"] / PEAK_MFMA_TFLOPS, "traffic": None,
                            "launches": gemm_stats["launches"], "avg_launch_ms": gemm_stats["avg_ms"],

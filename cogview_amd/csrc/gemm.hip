@@ -11,22 +11,26 @@
 // "trans" means the operand is stored with the contraction index as the SLOW dimension (A stored [K][M], B stored
 // [K][N]): dgrad's W and both weight-gradient operands.  No transposed copies exist in HBM.
 //
-// Three kernels, newest first (dispatch: launch_gemm):
-//   generation 3  gemm_pp64_kernel   256x256x64 tiles, 8 waves ping-pong, v_mfma_f32_16x16x32, LDS-DMA granule ring,
-//                                    persistent with per-XCD work queues, up to 16 problems per launch.  Default.
+// Four kernels, newest first (dispatch: launch_gemm):
+//   generation 4  gemm_w4_kernel     256x256x64 tiles, 4 waves of 128x128 (accumulators fill the AGPR file), software-
+//                                    pipelined quarter-steps, LDS-DMA granule ring, persistent with per-XCD work queues,
+//                                    up to 16 problems per launch.  Default for M, N >= 256.  Its 2 x 4 instantiations
+//                                    compile as separate translation units (-DCOGV_W4_TU=k, build.py).
+//   generation 3  gemm_pp64_kernel   the same tile, ring and queues with 8 waves of 128x64 in a ping-pong schedule
+//                                    (kernel_variant 9; 5-15 % slower than generation 4: 1.5x the LDS fragment bytes).
 //   generation 2  gemm_glds_kernel   256x128x32 tiles, 4 waves, 3-stage LDS-DMA ring, 2 workgroups per CU.
 //                                    For M or N < 256 and operands >= 4 GiB.
 //   generation 1  gemm_kernel        128x128x64 tiles, register-staged with register transposes.  For K % 64 != 0 and
 //                                    other unaligned shapes.
 // All share the fused epilogue (epilogue8): bias, GeLU (+ stored pre-activation), dGeLU, dropout, += C, abs-max for
-// Sandwich-LN, and (generation 3) the bias-gradient column sums of the output.
+// Sandwich-LN, and (generations 3, 4) the bias-gradient column sums of the output.
 #include "common.cuh"
 #include "cogview_hip.h"
 
 #include <type_traits>
 
 #ifndef COGV_EXP
-#define COGV_EXP 0     // schedule experiments of tools/probes/gemm_exp.py (bit 0: no DMA, 1: no reads, 2: no MFMA, 3: DMA re-reads k-tiles 0..3, 4: clock probe, 6: no epilogue)
+#define COGV_EXP 0     // schedule experiments of tools/probes/{gemm_exp,w4_dev}.py (bit 0: no DMA, 1: no reads, 2: no MFMA, 3: DMA re-reads k-tiles 0..3, 4: clock probe, 6: no epilogue math/stores, 11: no epilogue at all, 12: no barriers, 13: no DMA waits)
 #endif
 
 namespace {
@@ -720,6 +724,7 @@ template <typename T, int F>
 __device__ __forceinline__ void pp64_epilogue(const GemmArgs& p, f32x4 (&acc)[8][4], float* strip, int m_base, int n_base,
                                               int ksplit, int lane, uint32_t& amax_pk, int colsum_row) {
   const int l15 = lane & 15, kb = lane >> 4;
+  if ((COGV_EXP & 2048) && acc[0][0][0] != 12345.f) return;      // probe: no strip transposition either
   const bool want_cs = (F == -1) ? ((p.flags & COGV_EPI_COLSUM) != 0 && !p.out_f32) : (F >= 0 && (F & COGV_EPI_COLSUM));
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int sr = lane >> 3, sc = lane & 7;           // read side: strip row, 8-column group
@@ -1415,15 +1420,15 @@ void gemm_w4_kernel(const GroupArgs ga) {
     auto tile = [&](int kt, auto bufc, Frag& fb01, Frag& fbx) {
       constexpr int buf = decltype(bufc)::value;
       const int t2 = min(kt + 2, nk - 1);
-      wait_vmcnt<16>();
+      if (!(COGV_EXP & 8192)) wait_vmcnt<16>();
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      if (!(COGV_EXP & 4096)) __builtin_amdgcn_s_barrier();      // probes: results are garbage without them
       __builtin_amdgcn_sched_barrier(0);
       quarter(IC<0>{}, IC<0>{}, fA, fb01, fbx, IC<G_B23>{}, IC<buf>{}, G_A01, t2, buf);
       quarter(IC<0>{}, IC<1>{}, fA, fbx, fI, IC<G_A23>{}, IC<buf>{}, G_B01, t2, buf);
-      wait_vmcnt<16>();
+      if (!(COGV_EXP & 8192)) wait_vmcnt<16>();
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      if (!(COGV_EXP & 4096)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       quarter(IC<1>{}, IC<1>{}, fI, fbx, fA, IC<G_A01>{}, IC<(buf ^ 1)>{}, G_B23, t2, buf);
       quarter(IC<1>{}, IC<0>{}, fI, fb01, fbx, IC<G_B01>{}, IC<(buf ^ 1)>{}, G_A23, t2, buf);

@@ -1,70 +1,75 @@
-"""Development loop for the generation-4 GEMM kernel: build gemm.hip with -DCOGV_W4_DEV=<layout> (only that kernel,
-bf16, one layout: 1 NT forward, 2 NN dgrad, 3 TN wgrad -- seconds to compile) into tools/probes/_exp/libw4_<layout>.so,
-check it against torch.matmul and time it next to the production library's generation-3 kernel.
-  build (CPU box):  python tools/probes/w4_dev.py build 1
-  run   (GPU box):  python tools/probes/w4_dev.py run 1
+"""Probe builds of the generation-4 GEMM kernel: compile the bf16 units (gemm.hip -DCOGV_W4_TU=0..2) with extra flags
+(e.g. -DCOGV_EXP=64: no epilogue) into tools/probes/_exp/lib<tag>.so next to the production objects, then time the
+4B model's GEMMs (with their real epilogues) against the production library.
+  build (CPU box):  python tools/probes/w4_dev.py build <tag> [flags...]
+  run   (GPU box):  python tools/probes/w4_dev.py run <tag> [<tag> ...]      ("prod" = the production library)
 """
-import os, subprocess, sys
+import concurrent.futures, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "probes", "_exp")
-SHAPES = [(26112, 2560, 10240), (26112, 10240, 2560), (26112, 7680, 2560), (26112, 2560, 2560)]
 
 
-def build(layout, extra=()):
+def build(tag, extra):
     from cogview_amd.csrc import build as B
     os.makedirs(OUT, exist_ok=True)
-    others = [os.path.join(B.OBJ_DIR, os.path.basename(s)[:-4] + ".o") for s in B.sources() if not s.endswith("gemm.hip")]
-    obj = os.path.join(OUT, f"w4_{layout}.o")
-    subprocess.run([B._hipcc()] + B.FLAGS + [f"-DCOGV_W4_DEV={layout}"] + list(extra) + ["-c", os.path.join(B.HERE, "gemm.hip"), "-o", obj], check=True)
-    subprocess.run([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-o", os.path.join(OUT, f"libw4_{layout}.so"), obj] + others, check=True)
-    os.remove(obj)
-    print("built", layout, flush=True)
+    objs, jobs = [], []
+    for src, obj, flags in B.units():
+        name = os.path.basename(obj)
+        if name in ("gemm_w4_0.o", "gemm_w4_1.o", "gemm_w4_2.o"):
+            o2 = os.path.join(OUT, f"{tag}_{name}")
+            jobs.append([B._hipcc()] + B.FLAGS + flags + list(extra) + ["-c", src, "-o", o2])
+            objs.append(o2)
+        else:
+            objs.append(obj)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=3) as ex:
+        list(ex.map(lambda c: subprocess.run(c, check=True, capture_output=True), jobs))
+    subprocess.run([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-o", os.path.join(OUT, f"lib{tag}.so")] + objs, check=True)
+    for o in objs:
+        if o.startswith(OUT):
+            os.remove(o)
+    print("built", tag, flush=True)
 
 
-def operands(layout, M, N, K, gen):
-    import torch
-    a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16, generator=gen)
-    b = torch.randn(N, K, device="cuda", dtype=torch.bfloat16, generator=gen) * 0.05
-    if layout == 1:      # C = A B^T, both K-contiguous
-        return dict(a=a, b=b), a, b
-    if layout == 2:      # C = A Bs, Bs [K, N] (dgrad: dY [M,K'] x W [K',N])
-        bs = b.t().contiguous()
-        return dict(a=a, b=bs, trans_b=True), a, b
-    at = a.t().contiguous()   # wgrad: A stored [K, M], B stored [K, N]
-    bs = b.t().contiguous()
-    return dict(a=at, b=bs, trans_a=True, trans_b=True), a, b
-
-
-def run_one(layout, variant):
+def run_one(tag):
     import torch
     from cogview_amd import ops
     from tools.microbench import timeit
-    gen = torch.Generator(device="cuda").manual_seed(1)
-    if variant == 10:       # correctness on a small ragged-free case and one real shape
-        for (M, N, K) in [(512, 768, 256), (1024, 512, 1024), (26112, 2560, 2560)]:
-            kw, a, b = operands(layout, M, N, K, gen)
-            y = ops.gemm(kw["a"], kw["b"], trans_a=kw.get("trans_a", False), trans_b=kw.get("trans_b", False), variant=10, splitk=1)
-            ref = a.float() @ b.float().t()
-            err = ((y.float() - ref).norm() / ref.norm()).item()
-            print(f"   check {M}x{N}x{K}: rel-L2 {err:.2e}", flush=True)
-            assert err < 5e-3, err
-    for (M, N, K) in SHAPES:
-        if layout == 3:
-            M, N, K = K, N, M     # weight gradient: the token dimension is the contraction
-        kw, a, b = operands(layout, M, N, K, gen)
-        f = lambda: ops.gemm(kw["a"], kw["b"], trans_a=kw.get("trans_a", False), trans_b=kw.get("trans_b", False), variant=variant, splitk=1)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, h = 26112, 2560
+    dt = torch.bfloat16
+    rn = lambda *s: torch.randn(*s, device="cuda", dtype=dt, generator=g)
+    x, x4 = rn(M, h), rn(M, 4 * h)
+    w_qkv, w_d, w_1, w_2 = rn(3 * h, h) * 0.02, rn(h, h) * 0.02, rn(4 * h, h) * 0.02, rn(h, 4 * h) * 0.02
+    b1, bh = rn(4 * h) * 0.02, rn(h) * 0.02
+    aux = torch.empty(M, 4 * h, device="cuda", dtype=dt)
+    cs = torch.zeros(4 * h, device="cuda", dtype=dt)
+    amax = torch.zeros(1, device="cuda", dtype=torch.float32)
+    cases = [
+        ("fwd  h->4h  bias+gelu (epi 3)", 2.0 * M * 4 * h * h, lambda: ops.gemm(x, w_1, bias=b1, gelu=True, gelu_aux=aux)),
+        ("fwd  4h->h  bias+drop+amax (25)", 2.0 * M * 4 * h * h, lambda: ops.gemm(x4, w_2, bias=bh, dropout=(0.1, 1, 2), absmax=amax)),
+        ("fwd  h->h   bias+drop+amax (25)", 2.0 * M * h * h, lambda: ops.gemm(x, w_d, bias=bh, dropout=(0.1, 1, 2), absmax=amax)),
+        ("fwd  qkv    bias (1)", 2.0 * M * 3 * h * h, lambda: ops.gemm(x, w_qkv, bias=torch.cat((bh, bh, bh)))),
+        ("dgrad 4h<-h dgelu+colsum (68)", 2.0 * M * 4 * h * h, lambda: ops.gemm(x, w_2, trans_b=True, dgelu_aux=aux, colsum_out=cs)),
+        ("dgrad h<-4h plain (0)", 2.0 * M * 4 * h * h, lambda: ops.gemm(x4, w_1, trans_b=True)),
+        ("dgrad h<-h  plain (0)", 2.0 * M * h * h, lambda: ops.gemm(x, w_d, trans_b=True)),
+    ]
+    for nm, y, ref in (("NT", ops.gemm(x, w_d), x.float() @ w_d.float().t()), ("NN", ops.gemm(x, w_d, trans_b=True), x.float() @ w_d.float()),
+                       ("TN", ops.gemm(x, x4[:, :h].contiguous(), trans_a=True, trans_b=True, splitk=1), x.float().t() @ x4[:, :h].float())):
+        print(f"[{tag:10s}] check {nm}: rel-L2 {((y.float() - ref).norm() / ref.norm()).item():.2e}", flush=True)
+    for name, fl, f in cases:
         t = min(timeit(f, iters=10, warm=3) for _ in range(2))
-        print(f"v{variant} layout {layout} {M}x{N}x{K}: {t*1e6:8.1f} us  {2.0*M*N*K/t/1e12:7.1f} TF", flush=True)
+        print(f"[{tag:10s}] {name:34s} {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF", flush=True)
 
 
 if __name__ == "__main__":
-    layout = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     if sys.argv[1] == "build":
-        build(layout, sys.argv[3:])
+        build(sys.argv[2], sys.argv[3:])
     elif sys.argv[1] == "run":
-        subprocess.run([sys.executable, os.path.abspath(__file__), "one", str(layout), "9"])
-        env = dict(os.environ, COGVIEW_HIP_LIB=os.path.join(OUT, f"libw4_{layout}.so"))
-        subprocess.run([sys.executable, os.path.abspath(__file__), "one", str(layout), "10"], env=env)
+        for tag in sys.argv[2:]:
+            env = dict(os.environ)
+            if tag != "prod":
+                env["COGVIEW_HIP_LIB"] = os.path.join(OUT, f"lib{tag}.so")
+            subprocess.run([sys.executable, os.path.abspath(__file__), "one", tag], env=env)
     else:
-        run_one(layout, int(sys.argv[3]))
+        run_one(sys.argv[2])
