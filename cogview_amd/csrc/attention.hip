@@ -255,7 +255,7 @@ __device__ __forceinline__ void tile_colsum(const float (&vals)[2][16], float* l
 // =====================================================================================================
 // forward: grid (ceil(s_q/128), H, B); wave w owns queries q0 + 32w .. +31.  Ring stage = K tile | V tile.
 // =====================================================================================================
-template <typename T>
+template <typename T, bool IDX>
 __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 stages x 16 KiB
   constexpr int STAGE = 2 * TILE, LPT = 4;
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   const int fr = lane & 31, fg = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
   const int q0 = blockIdx.x * 128, q0w = q0 + wave * 32;
-  const bool spw = p.sp_w > 0;                      // sparse training form (slot space)
+  // IDX (compile time): gathered keys / the sparse training form; the dense instantiation carries none of that code
+  const bool spw = IDX && p.sp_w > 0;               // sparse training form (slot space)
   const int gblk = spw ? q0 / p.sp_w : 0;
   const int off = spw ? (p.s_k - p.sp_w - gblk * p.sp_w) : (p.s_k - p.s_q);
   const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + head * HD;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   // gathered form (sparse_attention_inference, mpu/sparse_transformer.py:727-750): key slot j is row kv_index[b][j] of
   // K and V; the table (<= 4096 slots) is staged once behind the ring
   int* lidx = nullptr;
-  if (p.kv_index) {
+  if (IDX && p.kv_index) {
     lidx = reinterpret_cast<int*>(smem + 3 * STAGE);
     const int* gi = p.kv_index + (long long)b * p.kv_index_bs + (long long)gblk * p.kv_index_gs;
     for (int i = threadIdx.x; i < p.s_k; i += NT) lidx[i] = gi[i];
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
 // dQ: grid (ceil(s_q/128), H, B); lane = query.   dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
 // Ring stage = K tile | V tile (K serves both S^T (natural read) and dQ^T (transposing read)).
 // =====================================================================================================
-template <typename T>
+template <typename T, bool IDX>
 __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 2 * TILE, LPT = 4;
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const int fr = lane & 31, fg = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
   const int q0 = blockIdx.x * 128, q0w = q0 + wave * 32;
-  const bool spw = p.sp_w > 0;                      // sparse training form (slot space), see attn_fwd_kernel
+  const bool spw = IDX && p.sp_w > 0;               // sparse training form (slot space), see attn_fwd_kernel
   const int gblk = spw ? q0 / p.sp_w : 0;
   const int off = spw ? (p.s_k - p.sp_w - gblk * p.sp_w) : (p.s_k - p.s_q);
   const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + head * HD;
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
 
   int* lidx = nullptr;
-  if (p.kv_index) {
+  if (IDX && p.kv_index) {
     lidx = reinterpret_cast<int*>(smem + 3 * STAGE);
     const int* gi = p.kv_index + (long long)b * p.kv_index_bs + (long long)gblk * p.kv_index_gs;
     for (int i = threadIdx.x; i < p.s_k; i += NT) lidx[i] = gi[i];
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 // Ring stage = Q tile | dO tile | LSE[64] | D[64]  (64 queries per stage; Q and dO each serve a natural and a
 // transposing read).
 // =====================================================================================================
-template <typename T>
+template <typename T, bool IDX>
 __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 2 * TILE + 512, LPT = 6;
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   const int fr = lane & 31, fg = lane >> 5;
   // sparse training form (sp_w > 0): grid z = (b, query block g); keys are the block's slots, queries its sp_w rows,
   // dK / dV go to slot-space buffers [z][slot] which cogv_sparse_slot_reduce folds back onto the keys
-  const bool spw = p.sp_w > 0;
+  const bool spw = IDX && p.sp_w > 0;
   const int nblk = spw ? p.s_q / p.sp_w : 1;
   const int zb = blockIdx.z, head = blockIdx.y;
   const int b = spw ? zb / nblk : zb, gblk = spw ? zb - b * nblk : 0;
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
 
   int krow = mykey;
   bool kflag = false;
-  if (p.kv_index) {
+  if (IDX && p.kv_index) {
     const int raw = kvalid ? p.kv_index[(long long)b * p.kv_index_bs + (long long)gblk * p.kv_index_gs + mykey] : 0;
     kflag = raw < 0; krow = raw & 0x7fffffff;
   }
@@ -933,8 +934,13 @@ extern "C" int cogv_attention_fwd(const cogv_attn_desc* d, void* stream) {
   int sh = 3 * 2 * TILE;
   if ((rc = index_args(d, a))) return rc;
   if (a.kv_index) sh += ((a.s_k * 4 + 15) / 16) * 16;
-  if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), grid, dim3(NT), sh, st, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, dim3(NT), sh, st, a);
+  if (a.kv_index) {
+    if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t, true>), grid, dim3(NT), sh, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, true>), grid, dim3(NT), sh, st, a);
+  } else {
+    if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t, false>), grid, dim3(NT), sh, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, false>), grid, dim3(NT), sh, st, a);
+  }
   return cogv_check_launch();
 }
 
@@ -964,19 +970,29 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   static int attr_q = 0;
   static bool attr = false;
   if (!attr) {
-    set_smem(&attn_bwd_dkdv_kernel<f16_t>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t>, sh_k);
+    set_smem(&attn_bwd_dkdv_kernel<f16_t, false>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false>, sh_k);
+    set_smem(&attn_bwd_dkdv_kernel<f16_t, true>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t, true>, sh_k);
+    set_smem(&attn_bwd_dq_kernel<f16_t, false>, 3 * 2 * TILE); set_smem(&attn_bwd_dq_kernel<bf16_t, false>, 3 * 2 * TILE);
     attr = true;
   }
-  if (sh_q > attr_q) {
-    set_smem(&attn_bwd_dq_kernel<f16_t>, sh_q); set_smem(&attn_bwd_dq_kernel<bf16_t>, sh_q);
+  if (a.kv_index && sh_q > attr_q) {
+    set_smem(&attn_bwd_dq_kernel<f16_t, true>, sh_q); set_smem(&attn_bwd_dq_kernel<bf16_t, true>, sh_q);
     attr_q = sh_q;
   }
-  if (d->dtype == COGV_F16) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t>), gq, dim3(NT), sh_q, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t>), gk, dim3(NT), sh_k, st, a);
+  if (a.kv_index) {       // sparse training form: the instantiation with the gather and the slot attributes
+    if (d->dtype == COGV_F16) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, true>), gq, dim3(NT), sh_q, st, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t, true>), gk, dim3(NT), sh_k, st, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, true>), gq, dim3(NT), sh_q, st, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t, true>), gk, dim3(NT), sh_k, st, a);
+    }
+  } else if (d->dtype == COGV_F16) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, false>), gq, dim3(NT), sh_q, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t, false>), gk, dim3(NT), sh_k, st, a);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t>), gq, dim3(NT), sh_q, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t>), gk, dim3(NT), sh_k, st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, false>), gq, dim3(NT), sh_q, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t, false>), gk, dim3(NT), sh_k, st, a);
   }
   return cogv_check_launch();
 }

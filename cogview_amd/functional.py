@@ -537,7 +537,8 @@ class _DeferredWeightGrads:
         self.problems, self.callbacks = [], []
 
 
-WGRAD_GROUP_LAYERS = 1
+import os as _os
+WGRAD_GROUP_LAYERS = int(_os.environ.get("COGV_WGRAD_GROUP_LAYERS", "1"))
 _WGRADS = _DeferredWeightGrads()
 
 

@@ -51,6 +51,9 @@ def test_gemm_nt_bias(ops, dtype, M, N, K):
     assert rel(out, ref) < TOL[dtype]
     out1 = ops.gemm(dev(a), dev(b), bias=dev(bias), splitk=1)
     assert rel(out1, ref) < TOL[dtype]
+    if M >= 256 and N >= 256 and K % 64 == 0:      # the explicit kernel generations (default dispatch picks 4)
+        for variant in (9, 10):
+            assert rel(ops.gemm(dev(a), dev(b), bias=dev(bias), variant=variant), ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -88,6 +91,18 @@ def test_gemm_wgrad_tn(ops, dtype, M, N, K, splitk):
     acc = dev(prev.clone())
     ops.gemm(dev(dy), dev(x), trans_a=True, trans_b=True, out=acc, accumulate=True, splitk=splitk)
     assert rel(acc, ref + prev.float()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(512, 768, 320), (264, 136, 200)])
+def test_gemm_a_transposed_only(ops, dtype, M, N, K):
+    """C[M,N] = A[K,M]^T B[N,K]^T: the fourth operand layout of the C ABI (trans_a without trans_b; no caller on the
+    training path, but every layout of every kernel generation is a separate instantiation)."""
+    g = torch.Generator().manual_seed(K + 3)
+    a, b = rnd((K, M), dtype, g), rnd((N, K), dtype, g, 0.1)
+    ref = a.float().t() @ b.float().t()
+    assert rel(ops.gemm(dev(a), dev(b), trans_a=True), ref) < TOL[dtype]
+    assert rel(ops.gemm(dev(a), dev(b), trans_a=True, variant=9), ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
