@@ -23,14 +23,28 @@ text = torch.randint(0, 58219, (b, 1089)).cuda(); lm = torch.ones(b, 1089, devic
 batch = training.get_batch(text, lm)
 for _ in range(2): training.train_step(batch, model, opt, clip_grad=1.0, log=False, world_size=1)
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+import traceback
+from torch.utils._python_dispatch import TorchDispatchMode
+cnt = collections.Counter(); size = collections.Counter()
+
+
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = str(func)
+        if any(k in name for k in ("copy_", "fill_", "zero_", "clone", "zeros", "_to_copy", "sum", "add", "mul", "cat", "ones", "full")):
+            st = [f for f in traceback.extract_stack() if "cogview_amd" in f.filename or "tools" in f.filename]
+            site = f"{os.path.relpath(st[-1].filename, ROOT)}:{st[-1].lineno}" if st else "?"
+            t = out if isinstance(out, torch.Tensor) else (args[0] if args and isinstance(args[0], torch.Tensor) else None)
+            cnt[(name, site)] += 1
+            if t is not None and t.is_cuda:
+                size[(name, site)] += t.numel() * t.element_size()
+        return out
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with Log():
     training.train_step(batch, model, opt, clip_grad=1.0, log=False, world_size=1)
     torch.cuda.synchronize()
-cnt = collections.Counter()
-for ev in prof.events():
-    if ev.name.startswith("aten::") and ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::_to_copy", "aten::clone", "aten::contiguous", "aten::zeros", "aten::add_", "aten::mul_", "aten::sum"):
-        st = [s for s in (ev.stack or []) if "cogview_amd" in s or "bench" in s or "tools" in s]
-        cnt[(ev.name, st[0] if st else "?")] += 1
-for (name, site), n in cnt.most_common(40):
-    print(f"{n:5d} {name:18s} {site}")
+for (name, site), n in cnt.most_common(60):
+    print(f"{n:5d} {name:28s} {size[(name, site)] / 1e6:10.2f} MB  {site}")
