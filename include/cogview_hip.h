@@ -73,7 +73,7 @@ typedef struct cogv_gemm_desc {
   float* absmax;        /* device scalar, caller zeroes it */
   float dropout_p; uint64_t seed; uint64_t stream_id;
   int splitk;           /* >1: contraction split over this many workgroups + reduce pass */
-  int kernel_variant;   /* 0 = auto; 1 = generation 1 (register-staged 128x128x64); 3 = generation 2 (256x128x32 LDS-DMA ring); 9 = generation 3 (256x256x64 ping-pong, persistent) */
+  int kernel_variant;   /* 0 = auto; 1 = generation 1 (register-staged 128x128x64); 3 = generation 2 (256x128x32 LDS-DMA ring); 9 = generation 3 (256x256x64, 8 waves ping-pong, persistent); 10 = generation 4 (256x256x64, 4 waves of 128x128, persistent: what auto picks for M, N >= 256) */
   void* workspace; size_t workspace_bytes;   /* >= cogv_gemm_workspace_bytes() when splitk > 1 */
   float* colsum_partial;                     /* COGV_EPI_COLSUM: [cogv_gemm_colsum_rows(M)][N] fp32, fully written */
 } cogv_gemm_desc;

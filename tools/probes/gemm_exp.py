@@ -10,15 +10,22 @@ OUT = os.path.join(ROOT, "tools", "probes", "_exp")
 MASKS = [int(m) for m in os.environ.get("EXP_MASKS", "0,1,2,3,4,5,6").split(",")]
 
 def build():
+    """gemm.hip itself (generations 1-3: EXP_VARIANT=9 probes the ping-pong kernel) and the bf16 NT unit of generation 4
+    are rebuilt with the mask; the other objects come from the production build (run cogview_amd.csrc.build first)."""
     from cogview_amd.csrc import build as B
     os.makedirs(OUT, exist_ok=True)
-    others = [os.path.join(B.OBJ_DIR, os.path.basename(s)[:-4] + ".o") for s in B.sources() if not s.endswith("gemm.hip")]
     for m in MASKS:
-        obj = os.path.join(OUT, f"gemm_{m}.o")
-        subprocess.run([B._hipcc()] + B.FLAGS + [f"-DCOGV_EXP={m}", "-c", os.path.join(B.HERE, "gemm.hip"), "-o", obj], check=True,
-                       capture_output=True)
-        subprocess.run([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-o", os.path.join(OUT, f"libexp_{m}.so"), obj] + others, check=True)
-        os.remove(obj)
+        objs, tmp = [], []
+        for src, obj, flags in B.units():
+            if os.path.basename(obj) in ("gemm.o", "gemm_w4_0.o"):
+                o2 = os.path.join(OUT, f"m{m}_" + os.path.basename(obj))
+                subprocess.run([B._hipcc()] + B.FLAGS + flags + [f"-DCOGV_EXP={m}", "-c", src, "-o", o2], check=True, capture_output=True)
+                objs.append(o2); tmp.append(o2)
+            else:
+                objs.append(obj)
+        subprocess.run([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-o", os.path.join(OUT, f"libexp_{m}.so")] + objs, check=True)
+        for o in tmp:
+            os.remove(o)
         print("built", m, flush=True)
 
 def run_one():
@@ -29,10 +36,10 @@ def run_one():
     pad = int(os.environ.get("EXP_PAD", 0))     # leading-dimension padding (elements): channel-camping probe
     x = torch.randn(M, K + pad, device="cuda", dtype=torch.bfloat16)[:, :K]
     w = (torch.randn(N, K + pad, device="cuda", dtype=torch.bfloat16) * 0.05)[:, :K]
-    v = int(os.environ.get("EXP_VARIANT", 6))
+    v = int(os.environ.get("EXP_VARIANT", 10))
     t = timeit(lambda: ops.gemm(x, w, variant=v), iters=10, warm=3)
     if int(os.environ["EXP_MASK"]) & 16:
-        TM, TN = (256, 128) if v in (2, 3, 8) else (128, 128) if v == 4 else (256, 256)
+        TM, TN = (256, 128) if v == 3 else (128, 128) if v == 1 else (256, 256)
         y = ops.gemm(x, w, variant=v, out_dtype=torch.float32)
         torch.cuda.synchronize()
         print(f"   shader clock first/last workgroup: {y[0, 0].item():.0f} / {y[(M - 1) // TM * TM, (N - 1) // TN * TN].item():.0f} MHz")
