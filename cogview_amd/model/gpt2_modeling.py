@@ -38,7 +38,7 @@ class GPT2Model(torch.nn.Module):
     def __init__(self, num_layers, vocab_size, hidden_size, num_attention_heads, embedding_dropout_prob,
                  attention_dropout_prob, output_dropout_prob, max_sequence_length, max_memory_length,
                  checkpoint_activations, checkpoint_num_layers=1, parallel_output=True, query_window=128,
-                 key_window_times=6, num_pivot=768):
+                 key_window_times=6, num_pivot=768, kv_cache=False):
         super().__init__()
         self.parallel_output = parallel_output
         self.word_embeddings = mpu.VocabParallelEmbedding(vocab_size, hidden_size,
@@ -47,7 +47,7 @@ class GPT2Model(torch.nn.Module):
         self.transformer = mpu.GPT2ParallelTransformer(
             num_layers, hidden_size, num_attention_heads, max_sequence_length, max_memory_length,
             embedding_dropout_prob, attention_dropout_prob, output_dropout_prob, checkpoint_activations,
-            checkpoint_num_layers, **sparse_cfg)
+            checkpoint_num_layers, kv_cache=kv_cache, **sparse_cfg)
 
     def forward(self, input_ids, position_ids, attention_mask, txt_indices_bool, img_indices_bool, is_sparse, *mems):
         h0 = self.transformer.embed(input_ids, position_ids, self.word_embeddings)

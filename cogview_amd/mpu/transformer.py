@@ -61,6 +61,47 @@ class _Dropout(torch.nn.Module):
         return F_.dropout(x, self.p, self.training)
 
 
+class KVCacheSlot:
+    """One layer's key/value cache travelling through the `*mems` arguments in K/V-cache mode (SURVEY section 8f item 2:
+    "replace layer-input mems with a real K/V cache behind the same *mems signature").
+
+    The memory tensor the caller sees is a [b, s_mem, 2 * hp] view (keys | values of the positions decoded so far)
+    of a buffer with spare capacity; the view object carries the buffer as an attribute, so when the caller hands the
+    same object back (generation/sampling.py does) the new keys/values are appended in place: O(new tokens) per step
+    instead of the reference's QKV projection over the whole memory (mpu/sparse_transformer.py:135-140).  A memory that
+    lost the attribute (expanded to more beams, re-indexed by shrink_beams) is copied into a fresh buffer once."""
+    GROW = 256
+
+    def __init__(self, mem, max_len=0):
+        self.mem, self.max_len, self.out = mem, int(max_len), None
+
+    def append(self, k_new, v_new):
+        """k_new, v_new [b, sq, hp] -> (cache view [b, s_mem + sq, 2 hp], keys view, values view)."""
+        b, sq, hp = k_new.shape
+        mem = self.mem
+        s_mem = 0 if mem is None else mem.size(1)
+        buf = getattr(mem, "_cogv_kv_buf", None) if mem is not None else None
+        need = s_mem + sq
+        if buf is None or buf.size(0) != b or buf.size(1) < need or mem.data_ptr() != buf.data_ptr():
+            cap = ((need + self.GROW - 1) // self.GROW + 1) * self.GROW
+            buf = torch.empty((b, cap, 2 * hp), dtype=k_new.dtype, device=k_new.device)
+            if s_mem:
+                buf[:, :s_mem].copy_(mem)
+        buf[:, s_mem:need, :hp].copy_(k_new)
+        buf[:, s_mem:need, hp:].copy_(v_new)
+        view = buf[:, :need]
+        view._cogv_kv_buf = buf
+        self.out = view
+        if self.max_len > 0 and need > self.max_len:
+            # memory window (max_memory_length, mpu/sparse_transformer.py:615-626): this step still attends everything it
+            # was given; the memory handed back keeps the last max_len positions, at the front of a fresh buffer
+            nb = torch.empty_like(buf)
+            nb[:, :self.max_len].copy_(buf[:, need - self.max_len:need])
+            self.out = nb[:, :self.max_len]
+            self.out._cogv_kv_buf = nb
+        return view, view[:, :, :hp], view[:, :, hp:]
+
+
 class GPT2ParallelSelfAttention(torch.nn.Module):
     """mpu/sparse_transformer.py:46-169."""
 
@@ -89,11 +130,19 @@ class GPT2ParallelSelfAttention(torch.nn.Module):
 
     def forward(self, hidden_states, ltor_mask, pivot_idx=None, is_sparse=0, mem=None):
         query_length = hidden_states.size(1)
-        src = hidden_states if mem is None else torch.cat((mem, hidden_states), 1)
-        mixed = self.query_key_value(src)
-        q, k, v = split_tensor_along_last_dim(mixed, 3)
-        if mem is not None:
-            q = q[:, -query_length:]
+        if isinstance(mem, KVCacheSlot):
+            # K/V-cache mode: project only the new positions, append their keys / values to the layer's cache and
+            # attend over the cache (strided views: the attention kernels take any row stride)
+            assert int(is_sparse) == 0
+            mixed = self.query_key_value(hidden_states)
+            q, k, v = split_tensor_along_last_dim(mixed, 3)
+            _, k, v = mem.append(k, v)
+        else:
+            src = hidden_states if mem is None else torch.cat((mem, hidden_states), 1)
+            mixed = self.query_key_value(src)
+            q, k, v = split_tensor_along_last_dim(mixed, 3)
+            if mem is not None:
+                q = q[:, -query_length:]
         if int(is_sparse) == 1:          # mpu/sparse_transformer.py:147-148: ltor_mask carries the pivot attention mask
             assert mem is None
             ctx = sparse_attention(self._transpose_for_scores(q), self._transpose_for_scores(k),
@@ -159,7 +208,8 @@ class GPT2ParallelTransformerLayer(torch.nn.Module):
                                         self.training, recompute, on_backward_done)
         # op-by-op composition (memories / no Sandwich-LN), exactly the reference's dataflow
         a = self.input_layernorm(hidden_states)
-        mem = self.input_layernorm(mem) if mem is not None else None
+        if mem is not None and not isinstance(mem, KVCacheSlot):
+            mem = self.input_layernorm(mem)
         att = self.attention(a, ltor_mask, pivot_idx, is_sparse, mem)
         if self.scale_normalization:
             att = self.third_layernorm(att)
@@ -190,8 +240,12 @@ class GPT2ParallelTransformer(torch.nn.Module):
     def __init__(self, num_layers, hidden_size, num_attention_heads, max_sequence_length, max_memory_length,
                  embedding_dropout_prob, attention_dropout_prob, output_dropout_prob, checkpoint_activations,
                  checkpoint_num_layers=1, layernorm_epsilon=1.0e-5, init_method_std=0.02,
-                 use_scaled_init_for_output_weights=True, query_window=128, key_window_times=6, num_pivot=768):
+                 use_scaled_init_for_output_weights=True, query_window=128, key_window_times=6, num_pivot=768,
+                 kv_cache=False):
         super().__init__()
+        # kv_cache (extension): the memories returned / accepted by forward are per-layer
+        # key/value caches [b, s_mem, 2 * hidden/p] instead of the reference's layer inputs [b, s_mem, hidden]
+        self.kv_cache = bool(kv_cache)
         self.checkpoint_activations = checkpoint_activations
         self.checkpoint_num_layers = checkpoint_num_layers
         self.max_memory_length = max_memory_length
@@ -264,8 +318,16 @@ class GPT2ParallelTransformer(torch.nn.Module):
             ratio = self.num_pivot / self.max_sequence_length
             max_text_num = max(len(t) for t in txt_indices)
             num_pivot = max_text_num + int((left - max_text_num) * ratio)
+        kv_mode = self.kv_cache and self.max_memory_length > 0 and is_sparse == 0 and not torch.is_grad_enabled()
+        if kv_mode:
+            mem_layers = []
         for i, layer in enumerate(self.layers):
             mem_i = mems[i] if mems else None
+            if kv_mode:
+                slot = KVCacheSlot(mem_i, self.max_memory_length)
+                hidden_states = layer(hidden_states, sep, mem=slot)
+                mem_layers.append(slot.out)
+                continue
             if is_sparse == 1:
                 if i % max(1, int(self.checkpoint_num_layers)) == 0:
                     pivot_idx = torch.stack([
@@ -292,7 +354,9 @@ class GPT2ParallelTransformer(torch.nn.Module):
             if self.max_memory_length > 0:
                 mem_layers.append(hidden_states.detach())
         output = self.final_layernorm(hidden_states)
-        if self.max_memory_length > 0:
+        if kv_mode:       # same count as the reference's memories (layer inputs + final output): the last one is empty
+            mem_layers.append(mem_layers[0].new_empty((mem_layers[0].size(0), mem_layers[0].size(1), 0)))
+        elif self.max_memory_length > 0:
             mem_layers = self.update_mems(mem_layers, mems)
         return (output, *mem_layers)
 

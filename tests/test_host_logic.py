@@ -142,3 +142,28 @@ def test_sparse_pivot_plan_matches_reference_masks(golden_dir):
             else:
                 assert r not in pivot_idx[bi].tolist()
             assert have == want, (bi, r)
+
+
+def test_sampling_helpers_match_reference_golden(golden_dir):
+    """generation.sampling's host-side pieces (top-k / nucleus filtering, beam shrinking, beam marks) against outputs of
+    the reference's own functions (oracle/gen_golden_sampling.py -> tests/golden/sampling.npz), and the id layout of
+    the unified tokenizer (data_utils/unified_tokenizer.py:33-68: '[POS0]' is 58210, 58219 ids in total)."""
+    import os
+    import numpy as np
+    import cogview_amd.mpu  # noqa: F401
+    from cogview_amd.generation import IdSpace, add_interlacing_beam_marks, shrink_beams, top_k_logits
+    z = np.load(os.path.join(golden_dir, "sampling.npz"))
+    logits = torch.from_numpy(z["logits"])
+    assert np.array_equal(top_k_logits(logits.clone(), top_k=40).numpy(), z["topk_40"])
+    assert np.array_equal(top_k_logits(logits.clone(), top_k=1).numpy(), z["topk_1"])
+    assert np.array_equal(top_k_logits(logits[:1].clone(), top_p=0.9).numpy(), z["topp_09"])
+    assert np.array_equal(top_k_logits(logits[1:2].clone(), top_k=30, top_p=0.5).numpy(), z["topk_topp"])
+    tokens = torch.arange(12).view(3, 4)
+    mems = [torch.arange(3 * 5 * 2, dtype=torch.float32).view(3, 5, 2), torch.ones(3, 5, 0)]
+    t2, m2, s2 = shrink_beams(tokens, mems, 1, [-3.0, -1.5, -2.0])
+    assert np.array_equal(t2.numpy(), z["shrink_tokens"]) and np.array_equal(m2[0].numpy(), z["shrink_mem0"]) and s2 == [0]
+    seq = [5, 6, -1, -1, -1, 7, -1, -1, -1, -1, -1, 9]
+    add_interlacing_beam_marks(seq, nb=3, period=2)
+    assert seq == z["marks"].tolist()
+    ids = IdSpace()
+    assert len(ids) == 58219 and ids['[POS0]'] == 58210 and ids['[BOI1]'] == 58193 and ids.img_tokenizer.num_tokens == 8192

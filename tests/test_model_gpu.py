@@ -570,3 +570,83 @@ def test_sparse_training_mode_equals_dense_when_the_window_covers_the_sequence()
     print(f"is_sparse=1 vs dense (window covers the sequence): logits rel-L2 {e_log:.2e}, worst gradient rel-L2 {worst:.2e}")
     assert set(grads[0][2]) == set(grads[1][2])
     assert e_log < 3e-3 and worst < 1.5e-2
+
+
+def test_kv_cache_decoding_matches_full_sequence(golden_dir):
+    """memories as per-layer key/value caches (GPT2Model(kv_cache=True)).  A prefix pass followed
+    by single-token steps must reproduce the full-sequence logits, append in place (one buffer per layer for the whole
+    decode) and agree with the reference-style layer-input memories."""
+    from cogview_amd.fp16 import FP16_Module
+    from cogview_amd.model import GPT2Model
+    g = _golden(golden_dir)
+    L_, V_, H_, NH_, P_, S_, B_ = [int(v) for v in g["cfg"]]
+    tokens = g["tokens"].cuda()
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    outs = {}
+    for kv in (False, True):
+        torch.manual_seed(0)
+        m = GPT2Model(L_, V_, H_, NH_, 0.0, 0.0, 0.0, P_, 64, False, kv_cache=kv)
+        m.load_state_dict({k[6:]: v for k, v in g.items() if k.startswith("param.")})
+        model = FP16_Module(m.cuda(), dtype=torch.float16, keep_half_outputs=True).eval()
+        with torch.no_grad():
+            full, *_ = model(tokens, pos, 0, None, None, 0)
+            pre = S_ - 8
+            logits, *mems = model(tokens[:, :pre], pos[:, :pre], 0, None, None, 0)
+            assert len(mems) == L_ + 1 and mems[0].shape[1] == pre
+            if kv:
+                assert mems[0].shape[2] == 2 * H_ and mems[L_].shape[2] == 0
+                bufs = [mm._cogv_kv_buf for mm in mems[:L_]]
+            steps = [logits[:, -1:]]
+            for t in range(pre, S_ - 1):
+                logits, *mems = model(tokens[:, t:t + 1], pos[:, t:t + 1], 0, None, None, 0, *mems)
+                steps.append(logits)
+            if kv:      # appended in place: still the buffers of the prefix pass
+                assert all(mm._cogv_kv_buf is bb for mm, bb in zip(mems[:L_], bufs)) and mems[0].shape[1] == S_ - 1
+            # the memory window: with max_memory_length exceeded the tail is kept
+        outs[kv] = torch.cat(steps, 1)
+        e = rel(outs[kv], full[:, pre - 1:S_ - 1])
+        print(f"kv_cache={kv}: incremental vs full-sequence logits rel-L2 {e:.2e}")
+        assert e < 3e-3
+    assert rel(outs[True], outs[False]) < 3e-3
+
+
+def test_filling_sequence_greedy_equals_full_forward_argmax(golden_dir):
+    """generation.filling_sequence (the reference's generation/sampling.py:65-186 loop) with top_k = 1 is greedy decoding:
+    every generated token must be the argmax of a fresh full-sequence forward over what has been decoded so far -- with
+    K/V-cache memories and with layer-input memories, through the invalid-slice rule (text ids only before an image)."""
+    from types import SimpleNamespace
+    from cogview_amd.fp16 import FP16_Module
+    from cogview_amd.generation import IdSpace, filling_sequence
+    from cogview_amd.model import GPT2Model
+    g = _golden(golden_dir)
+    L_, V_, H_, NH_, P_, S_, B_ = [int(v) for v in g["cfg"]]
+    ids = IdSpace(img_tokens=V_ // 4, txt_tokens=V_ - V_ // 4 - 27)
+    assert len(ids) == V_
+    args = SimpleNamespace(temperature=1.0, top_k=1, top_p=0.0, is_sparse=0)
+    ctx, n_new = 9, 7
+    seq = torch.cat((g["tokens"][0, :ctx].clamp(min=V_ // 4, max=V_ - 28), torch.full((n_new,), -1, dtype=torch.long))).cuda()
+    res = {}
+    for kv in (True, False):
+        torch.manual_seed(0)
+        m = GPT2Model(L_, V_, H_, NH_, 0.0, 0.0, 0.0, P_, 64, False, kv_cache=kv)
+        m.load_state_dict({k[6:]: v for k, v in g.items() if k.startswith("param.")})
+        model = FP16_Module(m.cuda(), dtype=torch.float16, keep_half_outputs=True).eval()
+        out = filling_sequence(model, seq.clone(), args, tokenizer=ids)
+        assert out.shape == (1, ctx + n_new) and torch.equal(out[0, :ctx], seq[:ctx])
+        # greedy reference: full forward over the decoded prefix each time, image ids forbidden
+        toks = seq[:ctx].unsqueeze(0)
+        with torch.no_grad():
+            for _ in range(n_new):
+                pos = torch.arange(toks.shape[1], device="cuda").unsqueeze(0)
+                lg, *_ = model(toks, pos, 0, None, None, 0)
+                lg = lg[:, -1].float()
+                lg[:, :V_ // 4] = -float("inf")
+                top2 = torch.topk(lg, 2).values[0]
+                nxt = lg.argmax(-1, keepdim=True)
+                if (top2[0] - top2[1]).item() < 2e-2:          # a numerical near-tie: follow the loop's choice
+                    nxt = out[:, toks.shape[1]:toks.shape[1] + 1]
+                toks = torch.cat((toks, nxt), 1)
+        assert torch.equal(out, toks), (out.tolist(), toks.tolist())
+        assert int(out[0, ctx:].min()) >= V_ // 4
+        res[kv] = out
+    print("greedy continuation:", res[True][0, ctx:].tolist())
