@@ -336,8 +336,10 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
       // V^T fragments of the first 32 keys: issued now, consumed after the softmax
       TrRaw vr[2][2];
       tr_frags_issue<T, 0>(lv, loff, vr);
-      if (spw) {
-        // slot attributes of this block, one slot per lane: masked flag (bit 31 of the index entry) and "is a pivot"
+      if (IDX && lidx) {
+        // slot attributes of this block, one slot per lane: masked flag (bit 31 of the index entry; honoured in both
+        // gathered forms -- a decode step over a fixed-capacity key/value cache flags the slots not written yet) and
+        // "is a pivot" (training form only: sp_npiv = 0 otherwise)
         int raw;
         const uint32_t ia = (uint32_t)(uintptr_t)(lidx + min(kb * 64 + lane, p.s_k - 1));
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(ia) : "memory");

@@ -102,6 +102,22 @@ class KVCacheSlot:
         return view, view[:, :, :hp], view[:, :, hp:]
 
 
+class StaticKVSlot(KVCacheSlot):
+    """A layer's key/value cache with FIXED capacity and address for captured decode steps (generation/decoder.py): the
+    new keys / values are written at the device-side position `pos_index`, attention runs over all `cap` slots through
+    the gathered form, whose index table flags the slots not written yet -- no launch parameter depends on the length."""
+
+    def __init__(self, cache, pos_index, table):
+        super().__init__(None, 0)
+        self.cache, self.pos_index, self.table = cache, pos_index, table
+
+    def append(self, k_new, v_new):
+        hp = k_new.shape[-1]
+        self.cache.index_copy_(1, self.pos_index, torch.cat((k_new, v_new), -1))
+        self.out = self.cache
+        return self.cache, self.cache[:, :, :hp], self.cache[:, :, hp:]
+
+
 class GPT2ParallelSelfAttention(torch.nn.Module):
     """mpu/sparse_transformer.py:46-169."""
 
@@ -143,7 +159,11 @@ class GPT2ParallelSelfAttention(torch.nn.Module):
             q, k, v = split_tensor_along_last_dim(mixed, 3)
             if mem is not None:
                 q = q[:, -query_length:]
-        if int(is_sparse) == 1:          # mpu/sparse_transformer.py:147-148: ltor_mask carries the pivot attention mask
+        if isinstance(mem, StaticKVSlot):   # captured decode step: every slot of the fixed-capacity cache, unwritten ones flagged
+            o, _ = ops.attention_fwd(F_._as_bshd(self._transpose_for_scores(q)), F_._as_bshd(self._transpose_for_scores(k)),
+                                     F_._as_bshd(self._transpose_for_scores(v)), kv_index=mem.table)
+            ctx = o.permute(0, 2, 1, 3)
+        elif int(is_sparse) == 1:        # mpu/sparse_transformer.py:147-148: ltor_mask carries the pivot attention mask
             assert mem is None
             ctx = sparse_attention(self._transpose_for_scores(q), self._transpose_for_scores(k),
                                    self._transpose_for_scores(v), pivot_idx, ltor_mask, self.query_window,

@@ -68,6 +68,31 @@ class _ScalarPool:
 _scalars = _ScalarPool()
 
 
+class scalar_slab:
+    """Context manager: abs-max slots come, in order, from the caller's zeroed fp32 slab instead of the pool.  A captured
+    decode step (generation/decoder.py) needs slots at FIXED addresses that its own first node clears on every replay."""
+
+    def __init__(self, slab):
+        self.slab, self.i = slab, 0
+
+    def next(self, device):
+        assert self.i < self.slab.numel(), "scalar slab exhausted"
+        s = self.slab[self.i:self.i + 1]
+        self.i += 1
+        return s
+
+    def __enter__(self):
+        global _scalars
+        self.saved, _scalars = _scalars, self
+        self.i = 0
+        return self
+
+    def __exit__(self, *exc):
+        global _scalars
+        _scalars = self.saved
+        return False
+
+
 def new_absmax_slot(device):
     return _scalars.next(device)
 

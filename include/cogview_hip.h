@@ -132,7 +132,9 @@ typedef struct cogv_attn_desc {
   float* colsum_partial;
   /* optional (forward only unless sparse_window > 0): gathered keys (sparse_attention_inference, mpu/sparse_transformer.py:727-750): key slot j of
    * batch b is row kv_index[b * kv_index_bs + j] of k and v; s_k is the number of slots (<= 4096).  The left-to-right
-   * rule applies to SLOTS: the last s_q slots are the queries' own positions. */
+   * rule applies to SLOTS: the last s_q slots are the queries' own positions.  Bit 31 of an entry marks a masked slot
+   * (score -10000): a decode step over a fixed-capacity key/value cache flags the slots it has not written yet, so the
+   * launch parameters stay constant from step to step (HIP-graph replay, cogview_amd/generation/decoder.py). */
   const int* kv_index; long long kv_index_bs;
   /* sparse TRAINING form (sparse_attention, mpu/sparse_transformer.py:675-725) in "slot space": sparse_window > 0 (the
    * reference's query_window, a multiple of 128 dividing s_q).  Each block of sparse_window queries has its own index
