@@ -11,7 +11,8 @@
 // "trans" means the operand is stored with the contraction index as the SLOW dimension (A stored [K][M], B stored
 // [K][N]): dgrad's W and both weight-gradient operands.  No transposed copies exist in HBM.
 //
-// Four kernels, newest first (dispatch: launch_gemm):
+// Four tile kernels, newest first, plus gemv_kernel for M <= 8 (decode steps: a pure HBM stream of the weights);
+// dispatch: launch_gemm:
 //   generation 4  gemm_w4_kernel     256x256x64 tiles, 4 waves of 128x128 (accumulators fill the AGPR file), software-
 //                                    pipelined quarter-steps, LDS-DMA granule ring, persistent with per-XCD work queues,
 //                                    up to 16 problems per launch.  Default for M, N >= 256.  Its 2 x 4 instantiations
@@ -1486,6 +1487,74 @@ void gemm_w4_kernel(const GroupArgs ga) {
   }
 }
 
+// =====================================================================================================
+// Skinny-M kernel (M <= 8: incremental decoding, one row per beam): C[M,N] = epilogue(A[M,K] B[N,K]^T) is a matrix-VECTOR
+// product per row -- every weight byte is used M times, so the kernel is a pure HBM stream of B (the 4B model reads its
+// 7.9 GB of weights once per generated token).  A workgroup owns 8 output columns (8 rows of B); its 4 waves take the
+// 512-element chunks of K round robin (16 bytes per lane per row: 8 independent 1-KiB loads per chunk in flight), each
+// reduces its partial dot products with DPP, the four partials meet in LDS and lane 0 of wave 0 runs the shared fused
+// epilogue on its 8 consecutive columns.  The MFMA tile kernels spend the same traffic on 128 rows of which one is real.
+constexpr int GEMV_MAX_M = 8;
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_kernel(const GemmArgs p) {
+  __shared__ float part[4][GEMV_MAX_M][8];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x * 8;
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* B = reinterpret_cast<const T*>(p.B) + (size_t)n0 * p.ldb;
+  float acc[GEMV_MAX_M][8];
+#pragma unroll
+  for (int m = 0; m < GEMV_MAX_M; ++m)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[m][j] = 0.f;
+  const int nchunk = p.K >> 9;
+  for (int c = wave; c < nchunk; c += 4) {
+    const int k = (c << 9) + lane * 8;
+    u32x4 w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const u32x4*>(B + (size_t)j * p.ldb + k);
+#pragma unroll
+    for (int m = 0; m < GEMV_MAX_M; ++m) {
+      if (m < p.M) {
+        float x[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(A + (size_t)m * p.lda + k), x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float wf[8];
+          unpack8<T>(w[j], wf);
+          float t = acc[m][j];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t = fmaf(x[e], wf[e], t);
+          acc[m][j] = t;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < GEMV_MAX_M; ++m)
+    if (m < p.M) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = wave_sum_uniform(acc[m][j]);
+        if (lane == 0) part[wave][m][j] = t;
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t amax_pk = 0u;
+    for (int m = 0; m < p.M; ++m) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[0][m][j] + part[1][m][j] + part[2][m][j] + part[3][m][j];
+      amax_pk = absmax_pk(amax_pk, epilogue8<T>(p, m, n0, v));
+    }
+    if (p.flags & COGV_EPI_ABSMAX) {
+      const uint32_t wv = max(amax_pk & 0xffffu, amax_pk >> 16);
+      atomic_max_nonneg(p.absmax, bits_to_f<T>((uint16_t)wv));
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   __shared__ float red[16];
@@ -1618,6 +1687,13 @@ void launch_splitk_reduce(GemmArgs& a, hipStream_t st) {
 
 template <typename T>
 int launch_gemm(const cogv_gemm_desc* d, GemmArgs& a, hipStream_t st) {
+  // skinny M (decode steps): the HBM-streaming matrix-vector kernel; takes every fused epilogue except the column sums
+  if (a.M <= GEMV_MAX_M && !d->trans_a && !d->trans_b && (a.K & 511) == 0 && (a.N & 7) == 0 && !(d->flags & COGV_EPI_COLSUM) &&
+      (a.lda & 7) == 0 && (a.ldb & 7) == 0 && d->kernel_variant == 0) {
+    a.splitk = 1;
+    hipLaunchKernelGGL((gemv_kernel<T>), dim3(a.N / 8), dim3(256), 0, st, a);
+    return cogv_check_launch();
+  }
   const bool glds_ok = (a.K % BK) == 0 && a.M >= 64 && a.N >= 64 && (!d->trans_a || (a.M & 7) == 0) &&
                        (!d->trans_b || (a.N & 7) == 0) && d->kernel_variant != 1;
   if ((d->flags & COGV_EPI_COLSUM) && !glds_ok) return COGV_ERR_UNSUPPORTED;

@@ -413,8 +413,10 @@ class _LayerCtx:
                  "d_attn", "d_ao", "d_mo")
 
 
-def _layer_forward(layer, x, absmax_x, sep, drops, keep):
+def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
     """x [b,s,h] -> (out, absmax_out); `keep` is a _LayerCtx to fill (None: inference, nothing retained).
+    kv_slot (inference): the layer's key/value cache (mpu.transformer.KVCacheSlot): the new keys / values are appended
+    and attention runs over the cache.
     Kernel chain (MP=1): LN1 | QKV GEMM+bias | attention | dense GEMM+bias+dropout+absmax | LN3+residual+absmax |
     LN2 | h->4h GEMM+bias+GeLU | 4h->h GEMM+bias+dropout+absmax | LN4+residual+absmax."""
     att_m, mlp_m = layer.attention, layer.mlp
@@ -433,7 +435,16 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep):
     q = qkv[:, :, 0:hp].view(b, s, npp, 64)
     k = qkv[:, :, hp:2 * hp].view(b, s, npp, 64)
     v = qkv[:, :, 2 * hp:].view(b, s, npp, 64)
-    att, lse = ops.attention_fwd(q, k, v, sep=sep, dropout=d_attn)
+    if kv_slot is None:
+        att, lse = ops.attention_fwd(q, k, v, sep=sep, dropout=d_attn)
+    else:
+        _, kc, vc = kv_slot.append(qkv[:, :, hp:2 * hp], qkv[:, :, 2 * hp:])
+        kc, vc = kc.view(b, kc.shape[1], npp, 64), vc.view(b, vc.shape[1], npp, 64)
+        table = getattr(kv_slot, "table", None)     # fixed-capacity cache of a captured decode step: gathered form
+        if table is not None:
+            att, lse = ops.attention_fwd(q, kc, vc, kv_index=table)
+        else:
+            att, lse = ops.attention_fwd(q, kc, vc, sep=sep, dropout=d_attn)
 
     slot_ao = ops.new_absmax_slot(dev)
     if mp == 1:
@@ -580,6 +591,17 @@ class _TransformerLayer(torch.autograd.Function):
         if getattr(ctx.layer, "_cogv_index", 0) % WGRAD_GROUP_LAYERS == 0:
             flush_weight_grads()
         return dx, None, None, None, None, None, None
+
+
+def transformer_layer_kv(layer, x, absmax_x, sep, kv_slot):
+    """The fused layer chain for incremental decoding (no gradient): 9 kernels + the cache append instead of the ~20 of
+    the op-by-op composition."""
+    xc = x if x.is_contiguous() else x.contiguous()
+    if absmax_x is None:
+        absmax_x = ops.absmax(xc)
+    out, slot = _layer_forward(layer, xc, absmax_x, sep, (None, None, None), None, kv_slot=kv_slot)
+    out._cogv_absmax = slot
+    return out
 
 
 def transformer_layer(layer, x, absmax_x, sep, training, recompute=False, on_backward_done=None):

@@ -226,6 +226,10 @@ class GPT2ParallelTransformerLayer(torch.nn.Module):
             sep = F_.mask_to_sep(ltor_mask, s, s)
             return F_.transformer_layer(self, hidden_states, getattr(hidden_states, "_cogv_absmax", None), sep,
                                         self.training, recompute, on_backward_done)
+        if isinstance(mem, KVCacheSlot) and self.scale_normalization and is_sparse == 0 and not torch.is_grad_enabled():
+            sep = ltor_mask if isinstance(ltor_mask, int) else F_.mask_to_sep(ltor_mask, hidden_states.size(1),
+                                                                              hidden_states.size(1))
+            return F_.transformer_layer_kv(self, hidden_states, getattr(hidden_states, "_cogv_absmax", None), sep, mem)
         # op-by-op composition (memories / no Sandwich-LN), exactly the reference's dataflow
         a = self.input_layernorm(hidden_states)
         if mem is not None and not isinstance(mem, KVCacheSlot):

@@ -170,6 +170,27 @@ def test_gemm_gelu_dgelu_epilogues(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [1, 3, 8])
+@pytest.mark.parametrize("N,K", [(768, 512), (2560, 2560), (136, 1024)])
+def test_gemm_skinny_m_decode_shapes(ops, dtype, M, N, K):
+    """M <= 8 (one row per beam in a decode step) runs the HBM-streaming matrix-vector kernel; it must agree with the
+    tile kernels' results (explicit kernel_variant) and the oracle through the same fused epilogues."""
+    g = torch.Generator().manual_seed(M * 31 + N + K)
+    a, w, bias = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 0.1), rnd((N,), dtype, g)
+    ref = O.linear(a.float(), w.float(), bias.float())
+    slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    out = ops.gemm(dev(a), dev(w), bias=dev(bias), absmax=slot)
+    assert rel(out, ref) < TOL[dtype]
+    assert abs(slot.item() - out.float().abs().max().item()) <= 1e-6 * max(1.0, slot.item())
+    tiles = ops.gemm(dev(a), dev(w), bias=dev(bias), variant=1, splitk=1)          # generation-1 tile kernel
+    assert rel(out, tiles.float().cpu()) < TOL[dtype]
+    aux = torch.empty((M, N), dtype=dtype, device="cuda")
+    act = ops.gemm(dev(a), dev(w), bias=dev(bias), gelu=True, gelu_aux=aux)
+    assert rel(aux, ref) < TOL[dtype] and rel(act, O.gelu(aux.float().cpu())) < TOL[dtype]
+    assert rel(ops.gemm(dev(a), dev(w)), a.float() @ w.float().t()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_dropout_absmax(ops, dtype):
     g = torch.Generator().manual_seed(4)
     M, N, K = 200, 384, 64

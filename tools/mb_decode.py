@@ -32,6 +32,8 @@ with torch.no_grad():
         print(f"GraphDecoder {mode}: decode {dt*1e3:.2f} ms/token at memory length ~{pre}", flush=True)
 del model, dec
 torch.cuda.empty_cache()
+if os.environ.get("MB_DECODE_GRAPH_ONLY") == "1":
+    sys.exit(0)
 for kv in (True, False):
     model = FP16_Module(GPT2Model(L, V, h, heads, 0.1, 0.1, 0.1, 1089, 1089, False, kv_cache=kv).cuda(), dtype=torch.bfloat16,
                         keep_half_outputs=True).eval()
