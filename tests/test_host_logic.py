@@ -167,3 +167,56 @@ def test_sampling_helpers_match_reference_golden(golden_dir):
     assert seq == z["marks"].tolist()
     ids = IdSpace()
     assert len(ids) == 58219 and ids['[POS0]'] == 58210 and ids['[BOI1]'] == 58193 and ids.img_tokenizer.num_tokens == 8192
+
+
+def test_checkpoint_files_follow_the_reference_layout(tmp_path):
+    """cogview_amd.utils save/load_checkpoint (utils.py:158-380): directory layout, tracker file, dictionary keys, the
+    'release' form, --finetune semantics, and a DeepSpeed-style model-states file ('module' + foreign keys)."""
+    import os
+    from types import SimpleNamespace
+    import cogview_amd.mpu  # noqa: F401
+    from cogview_amd import utils
+    from cogview_amd.model import GPT2Model
+
+    def build(seed):
+        torch.manual_seed(seed)
+        return GPT2Model(2, 96, 64, 1, 0.0, 0.0, 0.0, 24, 0, False)
+
+    class Sched:
+        def __init__(self):
+            self.n = 0
+        def state_dict(self):
+            return {"n": self.n}
+        def load_state_dict(self, sd):
+            self.n = sd["n"]
+
+    args = SimpleNamespace(save=str(tmp_path), load=str(tmp_path), deepspeed=False, no_save_optim=False, no_save_rng=False,
+                           no_load_optim=False, no_load_rng=False, finetune=False)
+    m1, sch = build(1), Sched()
+    sch.n = 7
+    utils.save_checkpoint(1200, m1, None, sch, args)
+    name = os.path.join(str(tmp_path), "1200", "mp_rank_00_model_states.pt")
+    assert os.path.isfile(name) and open(os.path.join(str(tmp_path), "latest_checkpointed_iteration.txt")).read() == "1200"
+    sd = torch.load(name, map_location="cpu", weights_only=False)
+    assert {"iteration", "module", "lr_scheduler", "random_rng_state", "np_rng_state", "torch_rng_state",
+            "rng_tracker_states"} <= set(sd) and sd["iteration"] == 1200
+    assert list(sd["module"])[0] == "word_embeddings.weight" and "transformer.layers.0.attention.query_key_value.weight" in sd["module"]
+    m2, sch2 = build(2), Sched()
+    assert utils.load_checkpoint(m2, None, sch2, args) == 1200 and sch2.n == 7
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    args.finetune = True
+    assert utils.load_checkpoint(build(3), None, None, args) == 0
+    # a released / DeepSpeed-written model-states file: tracker says "release", foreign keys are ignored
+    rel = tmp_path / "rel"
+    os.makedirs(rel / "release")
+    torch.save({"module": m1.state_dict(), "dp_world_size": 64, "mp_world_size": 1, "global_steps": 300000},
+               rel / "release" / "mp_rank_00_model_states.pt")
+    (rel / "latest_checkpointed_iteration.txt").write_text("release")
+    args2 = SimpleNamespace(load=str(rel), deepspeed=False, no_load_optim=False, no_load_rng=False, finetune=False)
+    m3 = build(4)
+    assert utils.load_checkpoint(m3, None, None, args2) == 0
+    assert torch.equal(m3.state_dict()["transformer.final_layernorm.weight"], m1.state_dict()["transformer.final_layernorm.weight"])
+    assert utils.get_checkpoint_iteration(SimpleNamespace(load=str(tmp_path / "nothing"))) == (0, False, False)
+    w = torch.arange(6.0).view(3, 2)
+    assert torch.equal(utils.extend_position_embedding(w, 6), torch.cat((w, w)))
