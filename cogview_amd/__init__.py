@@ -5,3 +5,7 @@ package unchanged:  cogview_amd.mpu, cogview_amd.model, cogview_amd.fp16, cogvie
 All arithmetic runs in libcogview_hip.so (hand-written HIP for gfx950, include/cogview_hip.h); there is no
 CPU fallback."""
 __version__ = "0.1.0"
+
+# mpu first: functional <-> mpu.transformer import each other, and this is the order that resolves (any sub-package can
+# then be the first thing a script imports)
+from . import mpu  # noqa: E402,F401

@@ -25,5 +25,18 @@ class IdSpace:
     def __getitem__(self, command_token):
         return self.command_tokens[command_token]
 
+    def wrap_code(self, code, idx=1):
+        """data_utils/unified_tokenizer.py:125-150: [size token] [BOIidx] code [EOIidx]; the size token follows from the
+        code length (8x8 [TINY], 16x16 [SMALL], 32x32 [BASE], 64x64 [BIG])."""
+        import numpy as np
+        s = int(round(len(code) ** 0.5))
+        assert s * s == len(code)
+        prefix = {8: '[TINY]', 16: '[SMALL]', 32: '[BASE]', 64: '[BIG]'}[s]
+        head = [self.command_tokens[prefix], self.command_tokens['[BOI%d]' % idx]]
+        tail = [self.command_tokens['[EOI%d]' % idx]]
+        if isinstance(code, list):
+            return head + code + tail
+        return np.concatenate((np.array(head), np.asarray(code), np.array(tail)), axis=0)
+
     def __len__(self):
         return self.num_tokens

@@ -220,3 +220,35 @@ def test_checkpoint_files_follow_the_reference_layout(tmp_path):
     assert utils.get_checkpoint_iteration(SimpleNamespace(load=str(tmp_path / "nothing"))) == (0, False, False)
     w = torch.arange(6.0).view(3, 2)
     assert torch.equal(utils.extend_position_embedding(w, 6), torch.cat((w, w)))
+
+
+def test_data_readers_match_reference_golden(golden_dir, tmp_path):
+    """data_utils: the CompactBinaryDataset reader, the sample template and the RandomMappingDataset index map against the
+    reference's own classes (oracle/gen_golden_data.py -> tests/golden/data_utils.npz), and the writer <-> reader round
+    trip."""
+    import os
+    from types import SimpleNamespace
+    import numpy as np
+    import cogview_amd.mpu  # noqa: F401
+    from cogview_amd.data_utils import (BinaryDataset, RandomMappingDataset, get_dataset_by_type, write_compact_binary)
+    from cogview_amd.generation import IdSpace
+    z = np.load(os.path.join(golden_dir, "data_utils.npz"))
+    rows = z["rows"]
+    path = str(tmp_path / "rows.bin")
+    texts = [r[:64][r[:64] > -1].tolist() for r in rows]
+    assert write_compact_binary(path, texts, rows[:, 64:]) == 7
+    assert np.array_equal(np.fromfile(path, dtype=np.int32).reshape(-1, 1088), rows)          # same bytes as the reference reads
+    raw = BinaryDataset(path, lambda r: np.array(r))
+    assert len(raw) == int(z["n"]) and np.array_equal(np.stack([raw[i] for i in range(7)]), z["read_back"])
+    rm = RandomMappingDataset(list(range(1000)))
+    assert len(rm) == int(z["mapping_len"]) and [rm[i] for i in range(64)] == z["mapping"].tolist()
+    ids = IdSpace()
+    ds = get_dataset_by_type("CompactBinaryDataset", path, SimpleNamespace(max_position_embeddings=1089, finetune=False))
+    s = ds[2]
+    n_txt = len(texts[2])
+    want = [ids['[ROI1]']] + texts[2] + [ids['[BASE]'], ids['[BOI1]']] + rows[2, 64:].tolist() + [ids['[EOI1]']]
+    assert s["text"][:len(want)].tolist() == want and len(s["text"]) == 1089
+    assert set(s["text"][len(want):].tolist()) <= {ids['[PAD]']}
+    assert s["loss_mask"].sum() == len(want) == n_txt + 1028 and s["loss_mask"][:len(want)].all()
+    tok = get_dataset_by_type("TokenizedDataset", [np.arange(5), np.arange(2000)], SimpleNamespace(max_position_embeddings=1089))
+    assert tok[0]["loss_mask"].sum() == 5 and len(tok[1]["text"]) == 1089 and tok[1]["loss_mask"].all()

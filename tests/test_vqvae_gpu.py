@@ -82,3 +82,25 @@ def test_production_size_vs_oracle():
     a, b = vqvae.img2code(m, big), vqvae.img2code(m, big)
     assert torch.equal(a, b)
     assert torch.equal(vqvae.img2code(m, big[3:5]), a[3:5])
+
+
+def test_images_to_compact_binary_pipeline(tmp_path):
+    """The img2code stage of the preprocessing (preprocess/preprocess_text_image_data.py:28-64) writing the
+    CompactBinaryDataset file: batched encoding, row layout, and what the dataset reader then hands the trainer."""
+    from types import SimpleNamespace
+    from cogview_amd import vqvae
+    from cogview_amd.data_utils import get_dataset_by_type, images_to_compact_binary
+    from cogview_amd.generation import IdSpace
+    torch.manual_seed(5)
+    model = vqvae.new_model().cuda().eval()
+    imgs = torch.rand(3, 3, 256, 256, device="cuda") * 2 - 1
+    texts = [[8192 + 5, 8192 + 77], [8192 + 9], list(range(9000, 9010))]
+    path = str(tmp_path / "train.bin")
+    assert images_to_compact_binary(model, imgs, texts, path, batch_size=2) == 3
+    rows = np.fromfile(path, dtype=np.int32).reshape(-1, 64 + 1024)
+    codes = vqvae.img2code(model, imgs).reshape(3, -1).cpu().numpy()
+    assert rows.shape[0] == 3 and np.array_equal(rows[:, 64:], codes) and codes.min() >= 0 and codes.max() < 8192
+    assert rows[0, :2].tolist() == texts[0] and (rows[0, 2:64] == -1).all()
+    ids = IdSpace()
+    s = get_dataset_by_type("CompactBinaryDataset", path, SimpleNamespace(max_position_embeddings=1089))[1]
+    assert s["text"][:4].tolist() == [ids['[ROI1]'], 8192 + 9, ids['[BASE]'], ids['[BOI1]']] and s["loss_mask"].sum() == 1 + 1 + 2 + 1024 + 1
