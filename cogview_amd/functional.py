@@ -539,9 +539,10 @@ class _DeferredWeightGrads:
     is ever left behind); the data-parallel callbacks of the deferred layers run after the flush, in backward order,
     because only then are their weight gradients complete.
     Measured at 4B: one layer per launch is 1200 tiles = 4.7 rounds of the 256 CUs (6 % lost in the partial last
-    round) at 1207 TFLOP/s; four layers per launch (18.75 rounds, 1.3 % tail) ran at 1136 TFLOP/s -- a 14 ms
-    uninterrupted GEMM sits at the sustained power limit, while 3.4 ms launches separated by the lighter LN /
-    attention kernels clock higher.  Hence the default of 1."""
+    round) at 1328 TFLOP/s (generation-4 GEMM; 1207 with generation 3); four layers per launch (18.75 rounds, 1.3 %
+    tail) ran at 1267 (1136) TFLOP/s -- a 13 ms uninterrupted GEMM sits at the sustained power limit, while 3 ms
+    launches separated by the lighter LN / attention kernels clock higher.  Hence the default of 1
+    (COGV_WGRAD_GROUP_LAYERS overrides it for experiments)."""
     __slots__ = ("problems", "callbacks")
 
     def __init__(self):
