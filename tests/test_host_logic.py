@@ -252,3 +252,34 @@ def test_data_readers_match_reference_golden(golden_dir, tmp_path):
     assert s["loss_mask"].sum() == len(want) == n_txt + 1028 and s["loss_mask"][:len(want)].all()
     tok = get_dataset_by_type("TokenizedDataset", [np.arange(5), np.arange(2000)], SimpleNamespace(max_position_embeddings=1089))
     assert tok[0]["loss_mask"].sum() == 5 and len(tok[1]["text"]) == 1089 and tok[1]["loss_mask"].all()
+
+
+def test_kv_cache_slot_bookkeeping():
+    """mpu.transformer.KVCacheSlot (pure tensor bookkeeping): in-place append while the caller hands the same view
+    back, one copy when the memory was expanded / re-indexed (beams), and the max_memory_length window -- the step
+    attends everything it was given, the memory handed back keeps the tail (mpu/sparse_transformer.py:615-626)."""
+    from cogview_amd.mpu.transformer import KVCacheSlot
+    g = torch.Generator().manual_seed(0)
+    b, hp = 2, 8
+    ks, vs = torch.randn(b, 20, hp, generator=g), torch.randn(b, 20, hp, generator=g)
+    slot = KVCacheSlot(None, 0)
+    mem, k, v = slot.append(ks[:, :5], vs[:, :5])
+    assert mem.shape == (b, 5, 2 * hp) and torch.equal(k, ks[:, :5]) and torch.equal(v, vs[:, :5]) and slot.out is mem
+    buf = mem._cogv_kv_buf
+    for t in range(5, 9):                                   # same object handed back: appended in place
+        slot = KVCacheSlot(mem, 0)
+        mem, k, v = slot.append(ks[:, t:t + 1], vs[:, t:t + 1])
+        assert mem._cogv_kv_buf is buf and mem.shape[1] == t + 1
+    assert torch.equal(k, ks[:, :9]) and torch.equal(v, vs[:, :9])
+    wide = mem.expand(b, -1, -1)[:1].expand(3, -1, -1)       # beams: 1 -> 3, the attribute is gone
+    slot = KVCacheSlot(wide, 0)
+    mem3, k3, _ = slot.append(ks[:1, 9:10].expand(3, -1, -1), vs[:1, 9:10].expand(3, -1, -1))
+    assert mem3.shape == (3, 10, 2 * hp) and mem3._cogv_kv_buf is not buf and torch.equal(k3[1], ks[0, :10])
+    # window of 6 positions: this step sees 9 + 3 keys, the memory returned holds the last 6
+    slot = KVCacheSlot(mem, 6)
+    full, k, v = slot.append(ks[:, 9:12], vs[:, 9:12])
+    assert full.shape[1] == 12 and torch.equal(k, ks[:, :12])
+    assert slot.out.shape == (b, 6, 2 * hp) and torch.equal(slot.out[:, :, :hp], ks[:, 6:12]) and torch.equal(slot.out[:, :, hp:], vs[:, 6:12])
+    nxt = KVCacheSlot(slot.out, 6)
+    _, k, _ = nxt.append(ks[:, 12:13], vs[:, 12:13])
+    assert torch.equal(k, ks[:, 6:13]) and torch.equal(nxt.out[:, :, :hp], ks[:, 7:13])
