@@ -177,7 +177,39 @@ def w_sharding_rule(rank, world):
     assert col.bias.model_parallel and not hasattr(row.bias, "model_parallel")
 
 
+def w_checkpoint_mp2_dp2(rank, world):
+    """utils.save/load_checkpoint on a 2 x 2 grid: each model-parallel rank's file is written once (by its data-parallel
+    rank 0), the tracker by global rank 0, and every rank reloads its own shard."""
+    import tempfile
+    from types import SimpleNamespace
+    from cogview_amd import mpu, utils
+    from cogview_amd.model import GPT2Model
+    mpu.initialize_model_parallel(2)
+    box = [tempfile.mkdtemp() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    args = SimpleNamespace(save=box[0], load=box[0], deepspeed=False, no_save_optim=True, no_save_rng=True,
+                           no_load_optim=True, no_load_rng=True, finetune=False)
+    torch.manual_seed(3)
+    m = GPT2Model(2, 64, 128, 2, 0.0, 0.0, 0.0, 16, 0, False)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.add_(float(mpu.get_model_parallel_rank()))          # make the two shards' files distinguishable
+    utils.save_checkpoint(40, m, None, None, args)
+    files = sorted(os.listdir(os.path.join(box[0], "40")))
+    assert files == ["mp_rank_00_model_states.pt", "mp_rank_01_model_states.pt"], files
+    torch.manual_seed(9)
+    m2 = GPT2Model(2, 64, 128, 2, 0.0, 0.0, 0.0, 16, 0, False)
+    assert utils.load_checkpoint(m2, None, None, args) == 40
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    assert m2.transformer.layers[0].attention.query_key_value.weight.shape == (3 * 128 // 2, 128)
+
+
 # ------------------------------------------------------------------------------------------------ tests
+def test_checkpoint_files_world4_mp2():
+    _run("w_checkpoint_mp2_dp2", 4)
+
+
 def test_topology_world4_mp2():
     _run("w_topology", 4)
 
