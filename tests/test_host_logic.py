@@ -283,3 +283,31 @@ def test_kv_cache_slot_bookkeeping():
     nxt = KVCacheSlot(slot.out, 6)
     _, k, _ = nxt.append(ks[:, 12:13], vs[:, 12:13])
     assert torch.equal(k, ks[:, 6:13]) and torch.equal(nxt.out[:, :, :hp], ks[:, 7:13])
+
+
+def test_annealing_lr_matches_reference_golden(golden_dir):
+    """cogview_amd.learning_rates.AnnealingLR against trajectories of the reference's class (oracle/gen_golden_lr.py):
+    warm-up, linear / cosine / constant decay, and resuming from a state_dict in the middle of a run."""
+    import os
+    import numpy as np
+    from cogview_amd.learning_rates import AnnealingLR
+    z = np.load(os.path.join(golden_dir, "learning_rates.npz"))
+
+    class Opt:
+        def __init__(self):
+            self.param_groups = [{'lr': 0.0}, {'lr': 0.0}]
+
+    for style in ("linear", "cosine", "constant"):
+        o = Opt()
+        s = AnnealingLR(o, 3e-4, 50, 400, decay_style=style, decay_ratio=0.1)
+        lrs = []
+        for i in range(480):
+            if i == 200:                                  # checkpoint / resume
+                sd = s.state_dict()
+                o = Opt()
+                s = AnnealingLR(o, 3e-4, 50, 400, decay_style=style, decay_ratio=0.1)
+                s.load_state_dict(sd)
+            s.step()
+            lrs.append(o.param_groups[1]['lr'])
+        assert np.array_equal(np.array(lrs), z[style]), style
+        assert s.state_dict()['num_iters'] == int(z[style + "_sd_num_iters"]) and s.state_dict()['decay_ratio'] == float(z[style + "_decay_ratio"])
