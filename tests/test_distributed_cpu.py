@@ -205,7 +205,54 @@ def w_checkpoint_mp2_dp2(rank, world):
     assert m2.transformer.layers[0].attention.query_key_value.weight.shape == (3 * 128 // 2, 128)
 
 
+def w_trainer_data_path(rank, world):
+    """pretrain_gpt2: flags, the learning-rate scheduler wiring and the data path -- CompactBinaryDataset ->
+    RandomMappingDataset -> global batches sliced per data-parallel rank, resumable at an iteration."""
+    import tempfile
+    import numpy as np
+    from cogview_amd import mpu
+    from cogview_amd import pretrain_gpt2 as P
+    from cogview_amd.data_utils import write_compact_binary
+    mpu.initialize_model_parallel(1)
+    box = [tempfile.mkdtemp() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    path = os.path.join(box[0], "train.bin")
+    if rank == 0:
+        rs = np.random.RandomState(0)
+        write_compact_binary(path, [rs.randint(8192, 58192, rs.randint(2, 30)).tolist() for _ in range(40)],
+                             rs.randint(0, 8192, (40, 1024)))
+    dist.barrier()
+    args = P.get_args(["--num-layers", "2", "--hidden-size", "128", "--num-attention-heads", "2", "--fp16", "--batch-size", "3",
+                       "--train-data", path, "--num-workers", "0", "--lr", "2e-4", "--lr-decay-style", "cosine",
+                       "--train-iters", "100", "--warmup", "0.1"])
+    assert args.dynamic_loss_scale and args.deepspeed is False and args.max_position_embeddings == 1089
+
+    class Opt:
+        param_groups = [{"lr": 0.0}]
+    sch = P.get_learning_rate_scheduler(Opt(), args)
+    assert sch.warmup_iter == 10 and sch.end_iter == 100 and sch.decay_style == "cosine"
+    it = P.make_data_iterator(args)
+    first = [next(it) for _ in range(3)]
+    assert first[0]["text"].shape == (3, 1089) and first[0]["loss_mask"].shape == (3, 1089)
+    mine = torch.stack([b_["text"] for b_ in first])
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    assert not torch.equal(both[0], both[1])                   # the two ranks hold different slices of each global batch
+    args.iteration = 2                                          # resume: the third batch again
+    again = next(P.make_data_iterator(args))
+    assert torch.equal(again["text"], first[2]["text"])
+    # the global batch is what a single rank would draw: 6 consecutive virtual indices of the index-seeded mapping
+    from cogview_amd.data_utils import RandomMappingDataset, get_dataset_by_type
+    ds = RandomMappingDataset(get_dataset_by_type(args.dataset_type, path, args))
+    want = torch.stack([torch.from_numpy(np.asarray(ds[i]["text"])) for i in range(rank * 3, rank * 3 + 3)])
+    assert torch.equal(first[0]["text"], want)
+
+
 # ------------------------------------------------------------------------------------------------ tests
+def test_trainer_data_path_world2():
+    _run("w_trainer_data_path", 2)
+
+
 def test_checkpoint_files_world4_mp2():
     _run("w_checkpoint_mp2_dp2", 4)
 
