@@ -246,6 +246,9 @@ class FP16_Optimizer(object):
         return self.clip_grad_norm(fp32_params, max_norm, norm_type)
 
     def state_dict(self):
+        if self._arena is not None:
+            for g in self.optimizer.param_groups:     # where the generic path / apex FusedAdam keep the step
+                g['step'] = self._step_count
         return {'loss_scaler': self.loss_scaler, 'dynamic_loss_scale': self.dynamic_loss_scale,
                 'overflow': self.overflow, 'first_closure_call_this_step': self.first_closure_call_this_step,
                 'optimizer_state_dict': self.optimizer.state_dict(), 'fp32_from_fp16': self.fp32_from_fp16_groups,
@@ -273,6 +276,14 @@ class FP16_Optimizer(object):
                         g[k] = v
             if state_dict.get('cogv_step_count') is not None:
                 self._step_count = state_dict['cogv_step_count']
+            else:
+                # a checkpoint written by the generic path or by the reference (apex FusedAdam): the step lives in
+                # the param groups, or (older apex / torch.optim.Adam) in the per-parameter state
+                step = saved['param_groups'][0].get('step') if saved['param_groups'] else None
+                if step is None:
+                    steps = [st['step'] for st in saved['state'].values() if isinstance(st, dict) and 'step' in st]
+                    step = steps[0] if steps else 0
+                self._step_count = int(step)
         for current_group, saved_group in zip(self.fp32_from_fp16_groups, state_dict['fp32_from_fp16']):
             for current, saved in zip(current_group, saved_group):
                 current.data.copy_(saved.data)

@@ -120,6 +120,17 @@ class DistributedDataParallel(Module):
                     if not no_scale and reduce_after:
                         p.grad.data.div_(self.world)
             return
+        # the exchange below moves slices of arena.grad: every parameter's .grad must still be its view of that buffer
+        # (an optimizer that set .grad = None makes backward allocate loose tensors the exchange would never see)
+        esz = self.arena.grad.element_size()
+        base = self.arena.grad.data_ptr()
+        for p, off in zip(self.arena.params, self.arena.offsets):
+            if p.grad is not None and p.grad.data_ptr() != base + off * esz:
+                self.arena.grad[off:off + p.numel()].view(p.shape).copy_(p.grad)
+                p.grad = self.arena.grad[off:off + p.numel()].view(p.shape)
+                if self._pending:
+                    raise RuntimeError("a parameter gradient left the flat arena while overlapped gradient slices were "
+                                       "already reduced: zero gradients with arena.zero_grad(), not by setting .grad = None")
         done = sorted(self._pending)
         self._pending = []
         if self._comm_stream is not None:

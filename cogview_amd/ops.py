@@ -138,6 +138,29 @@ def collect_gemm_timing():
                          for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}}
 
 
+class timed_launch:
+    """Bracket a launch of any other kernel family with HIP events on the launch stream while bench.py's timed region
+    runs (same record list as the GEMMs): `with timed_launch("conv", flops, bytes, "label"): <launch>`."""
+    __slots__ = ("rec",)
+
+    def __init__(self, family, flops, nbytes, label):
+        self.rec = None
+        if _GEMM_TIMING is not None:
+            self.rec = [family, float(flops), float(nbytes), torch.cuda.Event(enable_timing=True),
+                        torch.cuda.Event(enable_timing=True), label]
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.rec[3].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None and _GEMM_TIMING is not None:
+            self.rec[4].record()
+            _GEMM_TIMING.append(tuple(self.rec))
+        return False
+
+
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, gelu_aux=None, dgelu_aux=None,
          dropout=None, absmax=None, accumulate=False, splitk=None, out_dtype=None, variant=0, colsum_out=None,
          colsum_accumulate=True):

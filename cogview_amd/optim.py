@@ -19,9 +19,32 @@ class FusedAdam(torch.optim.Optimizer):
         self.set_grad_none = set_grad_none
 
     def zero_grad(self, set_to_none=None):
+        """Arena-backed parameters keep `param.grad` as a view of the flat gradient buffer (one memset): the
+        data-parallel exchange reduces slices of that buffer, so dropping the views would silently stop the gradient
+        synchronisation.  Loose parameters follow apex's set_grad_none default."""
         if set_to_none is None:
             set_to_none = self.set_grad_none
-        super().zero_grad(set_to_none=set_to_none)
+        arenas, loose = {}, False
+        for group in self.param_groups:
+            for p in group['params']:
+                e = getattr(p, '_cogv_arena', None)
+                if e is not None:
+                    arenas[id(e[0])] = e[0]
+                else:
+                    loose = True
+        for a in arenas.values():
+            a.zero_grad()
+        if not loose:
+            return
+        for group in self.param_groups:
+            for p in group['params']:
+                if getattr(p, '_cogv_arena', None) is not None or p.grad is None:
+                    continue
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.detach_()
+                    p.grad.zero_()
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -221,16 +221,26 @@ def train(model, optimizer, lr_scheduler, train_data_iterator, args):
     while args.iteration < args.train_iters:
         batch = get_batch(train_data_iterator, args)
         log = (args.iteration + 1) % args.log_interval == 0
-        lm_loss, _, img_loss, txt_loss = training.forward_step(batch, model, args.txt_loss_scale, args.is_sparse, log=log,
+        # the reference's train_step (:406-448): forward, the nan / inf guard on the all-reduced partial losses,
+        # backward + gradient exchange + clip, optimizer step; the logged loss is the mean over all ranks (:361-365)
+        lm_loss, _, img_loss, txt_loss = training.forward_step(batch, model, args.txt_loss_scale, args.is_sparse, log=True,
                                                                world_size=args.world_size)
-        training.backward_step(optimizer, model, lm_loss, args.clip_grad, half)
+        if not bool(torch.isfinite(img_loss + txt_loss).all().item()):
+            print('Skipping backward and optimizer step for nan or inf in forwarding!')
+            if hasattr(model, 'needs_reduction'):
+                model.needs_reduction = False
+            skipped_iters += 1
+            args.iteration += 1
+            continue
+        lm_loss = training.backward_step(optimizer, model, lm_loss, args.clip_grad, half, world_size=args.world_size,
+                                         reduce_loss=True)
         optimizer.step()
         if half and optimizer.overflow:
             skipped_iters += 1
         else:
             lr_scheduler.step()
         args.iteration += 1
-        total += lm_loss.detach().float()
+        total += lm_loss.detach().float().view(())
         if log:
             total_img, total_txt = img_loss.float().item(), txt_loss.float().item()
             dt = (time.time() - t0) * 1000.0 / args.log_interval

@@ -52,13 +52,18 @@ def forward_step(batch, model, txt_loss_scale=1.0, is_sparse=0, mems=(), log=Tru
     return loss, mems, img_loss, txt_loss
 
 
-def backward_step(optimizer, model, lm_loss, clip_grad=1.0, fp16=True):
-    """pretrain_gpt2.py:344-391 (non-DeepSpeed branch)."""
+def backward_step(optimizer, model, lm_loss, clip_grad=1.0, fp16=True, world_size=1, reduce_loss=False):
+    """pretrain_gpt2.py:344-391 (non-DeepSpeed branch).  Returns the loss averaged over all ranks when
+    `reduce_loss` is set (the reference's lm_loss_reduced, :361-365), else the local loss."""
     optimizer.zero_grad()
     if fp16:
         optimizer.backward(lm_loss, update_master_grads=False)
     else:
         lm_loss.backward()
+    reduced = lm_loss.detach().clone().view(1)
+    if reduce_loss and world_size > 1:
+        torch.distributed.all_reduce(reduced)
+        reduced /= world_size
     ddp = model if hasattr(model, 'allreduce_params') else None
     if ddp is not None:
         ddp.allreduce_params(reduce_after=False)
@@ -69,14 +74,26 @@ def backward_step(optimizer, model, lm_loss, clip_grad=1.0, fp16=True):
             optimizer.clip_master_grads(clip_grad)
         else:
             mpu.clip_grad_norm(model.parameters(), clip_grad)
-    return lm_loss.detach()
+    return reduced
 
 
 def train_step(batch, model, optimizer, lr_scheduler=None, clip_grad=1.0, txt_loss_scale=1.0, fp16=True, log=False,
-               world_size=1):
-    """pretrain_gpt2.py:406-448.  Returns (loss, skipped_iter)."""
-    lm_loss, _, img_loss, txt_loss = forward_step(batch, model, txt_loss_scale, log=log, world_size=world_size)
-    backward_step(optimizer, model, lm_loss, clip_grad, fp16)
+               world_size=1, is_sparse=0, check_forward_nan=False):
+    """pretrain_gpt2.py:406-448.  Returns (loss, skipped_iter).
+    check_forward_nan: the reference's guard (:414-416) -- the all-reduced image + text losses are read on the host
+    after the forward pass and a non-finite value skips backward and the optimizer step (all ranks agree because the
+    value is all-reduced).  It needs the partial losses, i.e. it implies `log`."""
+    log = log or check_forward_nan
+    lm_loss, _, img_loss, txt_loss = forward_step(batch, model, txt_loss_scale, is_sparse=is_sparse, log=log,
+                                                  world_size=world_size)
+    if check_forward_nan:
+        tot = img_loss + txt_loss
+        if not bool(torch.isfinite(tot).all().item()):
+            print('Skipping backward and optimizer step for nan or inf in forwarding!')
+            if hasattr(model, 'needs_reduction'):
+                model.needs_reduction = False
+            return tot.detach(), 1
+    lm_loss = backward_step(optimizer, model, lm_loss, clip_grad, fp16, world_size=world_size, reduce_loss=log)
     optimizer.step()
     skipped = 0
     if not (fp16 and optimizer.overflow):
@@ -84,4 +101,4 @@ def train_step(batch, model, optimizer, lr_scheduler=None, clip_grad=1.0, txt_lo
             lr_scheduler.step()
     else:
         skipped = 1
-    return lm_loss.detach(), skipped
+    return lm_loss.view(()), skipped

@@ -85,6 +85,10 @@ def save_checkpoint(iteration, model, optimizer, lr_scheduler, args):
             if torch.cuda.is_available():
                 sd['cuda_rng_state'] = torch.cuda.get_rng_state()
             sd['rng_tracker_states'] = mpu.get_cuda_rng_tracker().get_states()
+            # the counter-based dropout generator's default (seed, offset) pair: what torch.cuda's generator state is
+            # to the reference's hidden / embedding dropout (not covered by 'cuda_rng_state' here)
+            st = mpu.random.get_default_state()
+            sd['cogv_default_dropout_state'] = (st.seed, st.offset)
         ensure_directory_exists(name)
         torch.save(sd, name)
         print('  successfully saved {}'.format(name))
@@ -136,16 +140,23 @@ def load_checkpoint(model, optimizer, lr_scheduler, args, load_optimizer_states=
         raise KeyError('a metadata file exists but {} holds no model ("module")'.format(name))
     model.load_state_dict(sd['module'])
     finetune = getattr(args, 'finetune', False)
+    optimizer_restored = False
     if not release and not finetune and not getattr(args, 'no_load_optim', False):
         if optimizer is not None and load_optimizer_states:
             if 'optimizer' not in sd:
                 raise KeyError('{} holds no optimizer state: pass --no-load-optim or --finetune'.format(name))
             optimizer.load_state_dict(sd['optimizer'])
+            optimizer_restored = True
         if lr_scheduler is not None:
             if 'lr_scheduler' in sd:
                 lr_scheduler.load_state_dict(sd['lr_scheduler'])
             elif 'client_lr_scheduler' in sd:            # DeepSpeed's name for it (utils.py:307-309)
                 lr_scheduler.load_state_dict(sd['client_lr_scheduler'])
+    if optimizer is not None and not optimizer_restored and hasattr(optimizer, '_model_params_to_master_params'):
+        # weights loaded without optimizer state (--finetune, --no-load-optim, a release file): the fp32 master copy
+        # still holds the random initialisation and the first step would write it back over the loaded weights.
+        # The reference refreshes the masters in this case (utils.py:300-301 refresh_fp32_params).
+        optimizer._model_params_to_master_params()
     if finetune or release:
         iteration = 0
     else:
@@ -157,6 +168,9 @@ def load_checkpoint(model, optimizer, lr_scheduler, args, load_optimizer_states=
         if torch.cuda.is_available() and 'cuda_rng_state' in sd:
             torch.cuda.set_rng_state(sd['cuda_rng_state'])
         mpu.get_cuda_rng_tracker().set_states(sd['rng_tracker_states'])
+        if 'cogv_default_dropout_state' in sd:
+            seed, offset = sd['cogv_default_dropout_state']
+            mpu.random.set_default_state(mpu.random._State(seed, offset))
     if _dp_rank() == 0:
         print('  successfully loaded {}'.format(name))
     return iteration

@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
+from .. import ops
 
 
 def _stream():
@@ -40,7 +41,12 @@ def _conv(kind, x, w, bias, cout, relu):
     d.kind, d.B, d.IH, d.IW, d.Cin, d.Cout, d.relu = kind, b, ih, iw, cin, cout, int(relu)
     setattr(d, "in", x.data_ptr())
     d.w, d.bias, d.out = w.data_ptr(), bias.data_ptr(), out.data_ptr()
-    L.check(L.lib().cogv_conv2d_nhwc_f32(C.byref(d), _stream()), "cogv_conv2d_nhwc_f32")
+    par = 4 if kind == L.CONVT_4X4_S2 else 1
+    taps = {L.CONV_4X4_S2: 16, L.CONV_1X1: 1, L.CONVT_4X4_S2: 4}[kind]
+    npix_out = b * oh * ow
+    with ops.timed_launch("conv", 2.0 * npix_out * cout * taps * cin, 4.0 * (x.numel() + w.numel() + out.numel()),
+                          f"kind{kind} {b}x{ih}x{iw}x{cin}->{cout}"):
+        L.check(L.lib().cogv_conv2d_nhwc_f32(C.byref(d), _stream()), "cogv_conv2d_nhwc_f32")
     return out
 
 
@@ -97,8 +103,10 @@ class Quantize(nn.Module):
         et, e2 = self._tables()
         flat = x_nhwc.reshape(-1, self.dim)
         ids = torch.empty(flat.shape[0], dtype=torch.int64, device=flat.device)
-        L.check(L.lib().cogv_vq_argmin_f32(_p(flat), _p(et), _p(e2), _p(ids), flat.shape[0], self.dim, self.n_embed,
-                                           _stream()), "cogv_vq_argmin_f32")
+        with ops.timed_launch("vq_argmin", 2.0 * flat.shape[0] * self.dim * self.n_embed,
+                              4.0 * (flat.numel() + et.numel()) + 8.0 * flat.shape[0], f"{flat.shape[0]}x{self.dim}x{self.n_embed}"):
+            L.check(L.lib().cogv_vq_argmin_f32(_p(flat), _p(et), _p(e2), _p(ids), flat.shape[0], self.dim, self.n_embed,
+                                               _stream()), "cogv_vq_argmin_f32")
         return ids.view(*x_nhwc.shape[:-1])
 
     def embed_code(self, embed_id):
@@ -180,8 +188,9 @@ class Decoder(_ConvStack):
         out = torch.empty((b, 3, h, w), dtype=torch.float32, device=y.device)
         sc = (C.c_float * 3)(*scale) if scale is not None else None
         sh = (C.c_float * 3)(*shift) if shift is not None else None
-        L.check(L.lib().cogv_conv1x1_to_rgb_f32(_p(y), _p(w4), _p(b4), _p(out), b, h, w, c, sc, sh, _stream()),
-                "cogv_conv1x1_to_rgb_f32")
+        with ops.timed_launch("conv1x1_rgb", 2.0 * b * h * w * c * 3, 4.0 * (y.numel() + out.numel()), f"{b}x{h}x{w}x{c}->3"):
+            L.check(L.lib().cogv_conv1x1_to_rgb_f32(_p(y), _p(w4), _p(b4), _p(out), b, h, w, c, sc, sh, _stream()),
+                    "cogv_conv1x1_to_rgb_f32")
         return out
 
     def forward(self, input):

@@ -2,7 +2,7 @@
 (a) fixtures produced by the reference itself (tests/golden/gpt2_small.npz) and (b) the CPU oracle.
 
 Stated tolerances (relative L2 against the fp32 reference):
-  logits  fp16 <= 2e-3 (BASELINE target 1e-3 is reported, see test output)   bf16 <= 2e-2
+  logits  fp16 <= 1e-3 (BASELINE.json north_star target; measured 8.5e-4)      bf16 <= 2e-2 (measured 7.6e-3)
   grads   fp16 <= 1e-2 per tensor                                            bf16 <= 6e-2
 """
 import math
@@ -16,7 +16,7 @@ from oracle import cogview_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = {torch.float16: 2e-3, torch.bfloat16: 2e-2}
+LOGIT_TOL = {torch.float16: 1e-3, torch.bfloat16: 2e-2}
 GRAD_TOL = {torch.float16: 1e-2, torch.bfloat16: 6e-2}
 
 
@@ -471,7 +471,7 @@ def test_two_way_tensor_parallel_on_one_gpu():
     model, logits, loss = _tp_build_and_run()
     full = logits.detach().float().cpu()
     e_log = rel(torch.cat([shards[0][1], shards[1][1]], dim=-1), full)
-    assert e_log < 2e-3, e_log
+    assert e_log < 2e-3, e_log          # two fp16 runs against each other (each within 1e-3 of the fp32 reference)
     for r in range(2):
         assert abs(shards[r][2] - loss.item()) < 2e-3 * abs(loss.item())
     worst = 0.0
