@@ -79,7 +79,7 @@ def test_recompute_and_dropout_replay_bitwise(golden_dir):
     for ck in (False, True):
         model = _build(g, torch.float16, drop=0.1, checkpoint=ck)
         model.train()
-        mpu.random.manual_seed(1234)
+        mpu.model_parallel_cuda_manual_seed(1234)       # both dropout states (default + model-parallel tracker)
         pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
         batch = (g["tokens"].cuda(), g["labels"].cuda(), g["loss_mask"].cuda(), 0, pos)
         loss, _, _, _ = training.forward_step(batch, model, log=False)
