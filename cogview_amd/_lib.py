@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("COGVIEW_HIP_LIB") or os.path.join(_HERE, "lib", "libc
 
 F16, BF16, F32 = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_DROPOUT, EPI_ABSMAX, EPI_ACCUM, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
+EPI_GELU_DAUX, EPI_MULAUX = 128, 256
 
 _ERR = {1: "bad argument (shape / alignment / dtype)", 2: "kernel launch failure", 3: "unsupported combination"}
 

@@ -263,6 +263,16 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return fmaf(x * fmaf(-s, s, s), fmaf(C1, x2, C0), s);
 }
 
+// gelu(x) and gelu'(x) from ONE sigmoid evaluation (the forward epilogue stores gelu' for the backward GEMM, so the
+// backward epilogue is a multiply instead of a second exp2 + rcp per element)
+__device__ __forceinline__ void gelu_and_grad_f(float x, float& g, float& gd) {
+  const float x2 = x * x;
+  const float s = gelu_sigmoid_f(x, x2);
+  constexpr float C0 = 2.0f * 0.7978845608028654f, C1 = C0 * 3.0f * 0.044715f;
+  g = x * s;
+  gd = fmaf(x * fmaf(-s, s, s), fmaf(C1, x2, C0), s);
+}
+
 static inline int cogv_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? COGV_OK : COGV_ERR_LAUNCH;

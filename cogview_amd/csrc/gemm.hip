@@ -28,6 +28,7 @@
 #include "common.cuh"
 #include "cogview_hip.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef COGV_EXP
@@ -69,6 +70,7 @@ struct GroupArgs {
   int item_start[MAX_GROUP + 1];     // prefix sums of tiles_m * tiles_n * splitk
   int count;
   int* sched;                        // [0..7] per-XCD item counters, [8] finished workgroups: 0 at launch, re-armed by the last workgroup
+  int group_m;                       // generation 4: tile rows per raster group (the 32 CUs of an XCD work on group_m x 32/group_m tiles)
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
@@ -157,16 +159,31 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
     // the activation is evaluated on the pre-activation ROUNDED to the storage type -- exactly what backward
     // (or a checkpoint recompute that does store it) reads -- whether or not it is stored now
     const u32x4 rv = pack8<T>(v);
-    if (p.aux) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n) = rv;
     unpack8<T>(rv, v);
+    if (flags & COGV_EPI_GELU_DAUX) {
+      // aux receives gelu'(pre-activation) instead of the pre-activation: same bytes, and the backward GEMM's
+      // epilogue (COGV_EPI_MULAUX) becomes one multiply per element
+      float gd[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+      for (int i = 0; i < 8; ++i) gelu_and_grad_f(v[i], v[i], gd[i]);
+      if (p.aux) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n) = pack8<T>(gd);
+    } else {
+      if (p.aux) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n) = rv;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+    }
   }
   if (flags & COGV_EPI_DGELU) {
     u32x4 uv = aux_pre ? *aux_pre : *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
     float u[8]; unpack8<T>(uv, u);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(u[i]);
+  }
+  if (flags & COGV_EPI_MULAUX) {
+    u32x4 uv = aux_pre ? *aux_pre : *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
+    float u[8]; unpack8<T>(uv, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= u[i];
   }
   if ((flags & COGV_EPI_DROPOUT) && p.thr16) {
     const uint64_t e = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;   // n % 8 == 0
@@ -731,7 +748,7 @@ __device__ __forceinline__ void pp64_epilogue(const GemmArgs& p, f32x4 (&acc)[8]
   const int sr = lane >> 3, sc = lane & 7;           // read side: strip row, 8-column group
   // operands of the element-wise pipeline that live in global memory: bias once (the column group of a lane is
   // the same in every pass), the dGeLU pre-activations / the accumulate target for all 16 passes up front
-  constexpr bool PRE_BIAS = F >= 0 && (F & COGV_EPI_BIAS), PRE_AUX = F >= 0 && (F & COGV_EPI_DGELU), PRE_C = F >= 0 && (F & COGV_EPI_ACCUM);
+  constexpr bool PRE_BIAS = F >= 0 && (F & COGV_EPI_BIAS), PRE_AUX = F >= 0 && (F & (COGV_EPI_DGELU | COGV_EPI_MULAUX)), PRE_C = F >= 0 && (F & COGV_EPI_ACCUM);
   u32x4 bias_v = {0u, 0u, 0u, 0u}, aux_v[PRE_AUX ? 16 : 1], c_v[PRE_C ? 16 : 1];
   {
     const int n = n_base + 8 * sc;
@@ -1136,6 +1153,8 @@ void gemm_pp64_kernel(const GroupArgs ga) {
     else if (p.flags == F_FWD_GELU) pp64_epilogue<T, F_FWD_GELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
     else if (p.flags == (COGV_EPI_DGELU | COGV_EPI_COLSUM)) pp64_epilogue<T, COGV_EPI_DGELU | COGV_EPI_COLSUM>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
     else if (p.flags == COGV_EPI_DGELU) pp64_epilogue<T, COGV_EPI_DGELU>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
+    else if (p.flags == (F_FWD_GELU | COGV_EPI_GELU_DAUX)) pp64_epilogue<T, F_FWD_GELU | COGV_EPI_GELU_DAUX>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
+    else if (p.flags == (COGV_EPI_MULAUX | COGV_EPI_COLSUM)) pp64_epilogue<T, COGV_EPI_MULAUX | COGV_EPI_COLSUM>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
     else pp64_epilogue<T, -1>(p, acc, strip, done.m0 + wm, done.n0 + wn, done.ksplit, lane, amax_pk, (done.m0 >> 7) + wr);
     if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
       uint32_t wv = max(amax_pk & 0xffffu, amax_pk >> 16);
@@ -1250,7 +1269,7 @@ void gemm_w4_kernel(const GroupArgs ga) {
     it.pi = pi; it.ksplit = local / nwg;
     const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    constexpr int GROUP_M = 4;
+    const int GROUP_M = ga.group_m;
     const int in_group = GROUP_M * p.tiles_n;
     const int group_id = wgid / in_group;
     const int first_m = group_id * GROUP_M;
@@ -1467,6 +1486,8 @@ void gemm_w4_kernel(const GroupArgs ga) {
     else if (p.flags == F_FWD_GELU) W4_EPI(F_FWD_GELU);
     else if (p.flags == (COGV_EPI_DGELU | COGV_EPI_COLSUM)) W4_EPI(COGV_EPI_DGELU | COGV_EPI_COLSUM);
     else if (p.flags == COGV_EPI_DGELU) W4_EPI(COGV_EPI_DGELU);
+    else if (p.flags == (F_FWD_GELU | COGV_EPI_GELU_DAUX)) W4_EPI(F_FWD_GELU | COGV_EPI_GELU_DAUX);
+    else if (p.flags == (COGV_EPI_MULAUX | COGV_EPI_COLSUM)) W4_EPI(COGV_EPI_MULAUX | COGV_EPI_COLSUM);
     else W4_EPI(-1);
 #undef W4_EPI
     if ((p.flags & COGV_EPI_ABSMAX) && p.splitk <= 1) {
@@ -1649,6 +1670,10 @@ int launch_pp64(GroupArgs& ga, hipStream_t st) {
   constexpr int shmem = 2 * 65536;
   ga.sched = sched_slot();
   if (!ga.sched) return COGV_ERR_LAUNCH;
+  {   // raster group height (experiments: COGV_GEMM_GROUP_M); 4 rows x 8 columns of tiles per XCD by default
+    static const int gm = [] { const char* e = getenv("COGV_GEMM_GROUP_M"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 32 ? v : 4; }();
+    ga.group_m = gm;
+  }
   ga.item_start[0] = 0;
   for (int i = 0; i < ga.count; ++i) {
     GemmArgs& a = ga.g[i];
@@ -1808,8 +1833,10 @@ static int build_gemm_args(const cogv_gemm_desc* d, GemmArgs& a) {
   if (d->trans_a && (d->M & 7)) return COGV_ERR_ARG;
   if (((uintptr_t)d->A | (uintptr_t)d->B | (uintptr_t)d->C) & 15) return COGV_ERR_ARG;
   if ((d->flags & COGV_EPI_BIAS) && (!d->bias || ((uintptr_t)d->bias & 15))) return COGV_ERR_ARG;
-  if ((d->flags & COGV_EPI_DGELU) && !d->aux) return COGV_ERR_ARG;
-  if ((d->flags & (COGV_EPI_DGELU | COGV_EPI_GELU)) && d->aux && ((d->ldaux & 7) || ((uintptr_t)d->aux & 15)))
+  if ((d->flags & (COGV_EPI_DGELU | COGV_EPI_MULAUX)) && !d->aux) return COGV_ERR_ARG;
+  if ((d->flags & COGV_EPI_DGELU) && (d->flags & COGV_EPI_MULAUX)) return COGV_ERR_ARG;      // one aux operand
+  if ((d->flags & COGV_EPI_GELU_DAUX) && !(d->flags & COGV_EPI_GELU)) return COGV_ERR_ARG;
+  if ((d->flags & (COGV_EPI_DGELU | COGV_EPI_GELU | COGV_EPI_MULAUX)) && d->aux && ((d->ldaux & 7) || ((uintptr_t)d->aux & 15)))
     return COGV_ERR_ARG;
   if ((d->flags & COGV_EPI_ABSMAX) && !d->absmax) return COGV_ERR_ARG;
   if ((d->flags & COGV_EPI_DROPOUT) && !(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return COGV_ERR_ARG;

@@ -418,7 +418,7 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
     kv_slot (inference): the layer's key/value cache (mpu.transformer.KVCacheSlot): the new keys / values are appended
     and attention runs over the cache.
     Kernel chain (MP=1): LN1 | QKV GEMM+bias | attention | dense GEMM+bias+dropout+absmax | LN3+residual+absmax |
-    LN2 | h->4h GEMM+bias+GeLU | 4h->h GEMM+bias+dropout+absmax | LN4+residual+absmax."""
+    LN2 | h->4h GEMM+bias+GeLU (+ stored gelu') | 4h->h GEMM+bias+dropout+absmax | LN4+residual+absmax."""
     att_m, mlp_m = layer.attention, layer.mlp
     b, s, h = x.shape
     rows = b * s
@@ -463,7 +463,8 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
                                     eps, slot_y, save_stats=keep is not None)
     f4 = mlp_m.dense_h_to_4h.weight.shape[0]
     u = torch.empty((rows, f4), dtype=x.dtype, device=dev) if keep is not None else None
-    g = ops.gemm(c.view(rows, h), mlp_m.dense_h_to_4h.weight, bias=mlp_m.dense_h_to_4h.bias, gelu=True, gelu_aux=u)
+    # u receives gelu'(pre-activation): backward multiplies by it instead of re-evaluating the sigmoid
+    g = ops.gemm(c.view(rows, h), mlp_m.dense_h_to_4h.weight, bias=mlp_m.dense_h_to_4h.bias, gelu=True, gelu_daux=u)
     slot_mo = ops.new_absmax_slot(dev)
     if mp == 1:
         mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias, dropout=d_mo, absmax=slot_mo)
@@ -505,7 +506,7 @@ def _layer_backward(layer, kp, dout, sep):
     # The four weight gradients dW = dY^T X are deferred to a grouped launch (flush_weight_grads): together their
     # 256x256 tiles fill whole rounds of the 256 CUs (each alone needs split-K slabs or idles half a round).
     wgrads = _WGRADS.problems
-    du = ops.gemm(d_mo, W2, trans_b=True, dgelu_aux=kp.u, colsum_out=G(b1))     # dgrad fused with dGeLU + bias grad of h->4h
+    du = ops.gemm(d_mo, W2, trans_b=True, mul_aux=kp.u, colsum_out=G(b1))       # dgrad x stored gelu' + bias grad of h->4h
     wgrads.append((d_mo, kp.g, G(W2)))
     dc = _mp_allreduce(ops.gemm(du, W1, trans_b=True))
     wgrads.append((du, kp.c.view(rows, h), G(W1)))

@@ -163,9 +163,11 @@ class timed_launch:
 
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, gelu_aux=None, dgelu_aux=None,
          dropout=None, absmax=None, accumulate=False, splitk=None, out_dtype=None, variant=0, colsum_out=None,
-         colsum_accumulate=True):
+         colsum_accumulate=True, gelu_daux=None, mul_aux=None):
     """C[M,N] = epilogue(A_op[M,K] . B_op[N,K]^T); a, b 2-D, last dim contiguous.
     trans_a: `a` is stored [K, M];  trans_b: `b` is stored [K, N].
+    gelu_aux [M,N]: receives the rounded pre-activation; gelu_daux [M,N] (instead): receives gelu'(pre-activation), which
+    the backward GEMM applies with mul_aux (out = x * mul_aux) -- one multiply where dgelu_aux re-evaluates the sigmoid.
     dropout = (p, seed, stream_id).  colsum_out [N]: (+)= column sums of C (the bias gradient of the layer whose
     output gradient C is), fused into the epilogue when the shape allows, otherwise a separate pass.  Returns C."""
     _need_gpu(a, b)
@@ -197,11 +199,19 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
         d.bias = bias.data_ptr()
     if gelu:
         flags |= L.EPI_GELU
+        assert gelu_aux is None or gelu_daux is None
         if gelu_aux is not None:
             d.aux, d.ldaux = gelu_aux.data_ptr(), gelu_aux.stride(0)
+        if gelu_daux is not None:
+            flags |= L.EPI_GELU_DAUX
+            d.aux, d.ldaux = gelu_daux.data_ptr(), gelu_daux.stride(0)
     if dgelu_aux is not None:
         flags |= L.EPI_DGELU
         d.aux, d.ldaux = dgelu_aux.data_ptr(), dgelu_aux.stride(0)
+    if mul_aux is not None:
+        assert dgelu_aux is None and not gelu
+        flags |= L.EPI_MULAUX
+        d.aux, d.ldaux = mul_aux.data_ptr(), mul_aux.stride(0)
     if dropout is not None and dropout[0] > 0.0:
         flags |= L.EPI_DROPOUT
         d.dropout_p, d.seed, d.stream_id = float(dropout[0]), int(dropout[1]), int(dropout[2])

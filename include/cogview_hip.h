@@ -46,7 +46,7 @@ const char* cogv_arch(void);            /* "gfx950" */
  * replaces F.linear at mpu/layers.py:243 (ColumnParallelLinear.forward), mpu/layers.py:319
  * (RowParallelLinear.forward), model/gpt2_modeling.py:117 (tied logits) and their autograd
  * (dgrad: trans_b=1; wgrad: trans_a=trans_b=1).
- * epilogue order: +bias -> [store pre-activation to aux] -> GeLU | x gelu'(aux) -> dropout -> +C -> round
+ * epilogue order: +bias -> [store pre-activation or gelu' to aux] -> GeLU | x gelu'(aux) | x aux -> dropout -> +C -> round
  * -> abs-max.   GeLU is the tanh form of mpu/sparse_transformer.py:172-176.
  */
 #define COGV_EPI_BIAS 1     /* + bias[n]                                                             */
@@ -58,6 +58,12 @@ const char* cogv_arch(void);            /* "gfx950" */
 #define COGV_EPI_COLSUM 64  /* column sums of the (rounded) output per 128-row slab -> colsum_partial:      *
                              * the bias gradient of the layer that produced the GEMM's A operand, without  *
                              * re-reading the output (generation-3 kernel only: M, N >= 256, K % 64 == 0)  */
+
+#define COGV_EPI_GELU_DAUX 128 /* with COGV_EPI_GELU: aux receives gelu'(pre-activation) instead of the pre-activation --  *
+                                * same bytes; the backward GEMM then uses COGV_EPI_MULAUX (one multiply per element)  *
+                                * where COGV_EPI_DGELU re-evaluates the sigmoid (exp2 + rcp per element)              */
+#define COGV_EPI_MULAUX 256    /* out = x * aux[m][n] (autograd of gelu, mpu/sparse_transformer.py:172-179, through   *
+                                * the stored derivative); exclusive with COGV_EPI_DGELU                               */
 
 typedef struct cogv_gemm_desc {
   int dtype;            /* COGV_F16 | COGV_BF16 : type of A, B, bias, aux and (unless out_f32) C */

@@ -170,6 +170,33 @@ def test_gemm_gelu_dgelu_epilogues(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(320, 512, 128), (1088, 1024, 256), (300, 136, 72)])
+def test_gemm_stored_gelu_derivative_epilogues(ops, dtype, M, N, K):
+    """COGV_EPI_GELU_DAUX / COGV_EPI_MULAUX (the fused layer's pair): the forward epilogue stores gelu'(pre-activation)
+    and returns the same activation as the plain GeLU epilogue bit for bit; the backward epilogue multiplies by the
+    stored derivative (and still produces the fused bias-gradient column sums) -- against the oracle's autograd of
+    gelu (mpu/sparse_transformer.py:172-179)."""
+    g = torch.Generator().manual_seed(M + N)
+    a, w, bias = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 0.2), rnd((N,), dtype, g)
+    u_aux = torch.empty((M, N), dtype=dtype, device="cuda")
+    plain = ops.gemm(dev(a), dev(w), bias=dev(bias), gelu=True, gelu_aux=u_aux)
+    d_aux = torch.empty((M, N), dtype=dtype, device="cuda")
+    out = ops.gemm(dev(a), dev(w), bias=dev(bias), gelu=True, gelu_daux=d_aux)
+    assert torch.equal(out, plain)
+    u = u_aux.float().cpu().requires_grad_(True)
+    O.gelu(u).backward(torch.ones_like(u))
+    assert rel(d_aux, u.grad) < TOL[dtype]
+    dy, w2 = rnd((M, K), dtype, g), rnd((K, N), dtype, g, 0.2)
+    ref = (dy.float() @ w2.float()) * u.grad
+    cs = torch.zeros(N, dtype=dtype, device="cuda")
+    out2 = ops.gemm(dev(dy), dev(w2), trans_b=True, mul_aux=d_aux, colsum_out=cs, colsum_accumulate=False)
+    assert rel(out2, ref) < 1.5 * TOL[dtype]              # two 16-bit roundings (stored derivative, output)
+    assert rel(cs, out2.float().sum(0)) < TOL[dtype]
+    old = ops.gemm(dev(dy), dev(w2), trans_b=True, dgelu_aux=u_aux)
+    assert rel(out2, old.float().cpu()) < 1.5 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M", [1, 3, 8])
 @pytest.mark.parametrize("N,K", [(768, 512), (2560, 2560), (136, 1024)])
 def test_gemm_skinny_m_decode_shapes(ops, dtype, M, N, K):
