@@ -20,6 +20,9 @@
 #include "common.cuh"
 #include "cogview_hip.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;   // BK in floats (128 B per LDS row)
@@ -32,58 +35,121 @@ struct ConvArgs {
   int OH, OW, Cout;
   int in_mul, out_mul;
   int ntaps;
-  int8_t dy[4][16], dx[4][16];
-  int8_t ooy[4], oox[4];
+  int kind;                 // COGV_CONV_*: tap offsets are arithmetic (tap_offset), no table in memory
   long long w_parity_stride;
   int relu_out;
+  int nz;                   // parities (4 for the transposed convolution, else 1)
   int K;                    // ntaps * Cin
   int M;                    // B * GH * GW
 };
 
+// input offset (dy, dx) of tap `tap` for output parity z (see the header comment and cogv_conv2d_nhwc_f32):
+//   4x4 s2 p1 conv : tap = ky*4 + kx           -> (ky - 1, kx - 1)
+//   1x1            : (0, 0)
+//   4x4 s2 p1 convT: tap = ty*2 + tx, z = py*2+px -> (py - ty, px - tx)   [py = 0: rows y, y-1;  py = 1: rows y+1, y]
+// Pure integer arithmetic on wave-uniform values: a byte table in the kernel arguments costs a vector memory load and a
+// full memory latency in front of every k-tile's operand loads (scalar loads have no byte form on gfx950).
+__device__ __forceinline__ void tap_offset(int kind, int z, int tap, int& dy, int& dx) {
+  if (kind == COGV_CONV_4X4_S2) { dy = (tap >> 2) - 1; dx = (tap & 3) - 1; }
+  else if (kind == COGV_CONVT_4X4_S2) { dy = (z >> 1) - (tap >> 1); dx = (z & 1) - (tap & 1); }
+  else { dy = 0; dx = 0; }
+}
+
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// Asynchronous 16-byte load: issued through inline asm so that the COMPILER does not track it -- its own vmcnt
+// bookkeeping turned "tile kt+1 is needed, tile kt+2 may stay in flight" into vmcnt(0) (it drained both register sets
+// before every park in LDS, and half of the older set before issuing the newer one).  The consumer must call
+// wait_loads<N>() on the destination registers before the first use (loads return in order: N = number of younger loads
+// that may remain outstanding).  Only for spill-free kernels (cogview_amd/csrc/build.py checks).
+__device__ __forceinline__ void ld4_async(f32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_loads(f32x4 (&a)[4], f32x4 (&b)[4]) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+               : "n"(N) : "memory");
+}
 
-// A tile: 128 pixels x 32 k.  thread -> (row = t/8 + 32p, chunk = t%8); chunk = 4 consecutive k = 4 channels of one tap
-__device__ __forceinline__ void load_a(const ConvArgs& p, int z, int m0, int k0, f32x4 (&r)[4]) {
+// Operand staging.  thread t -> (tile row t/8 + 32 q for q = 0..3, 16-byte chunk t%8 of the 128-byte k-slice).
+// Every load of a k-tile is UNCONDITIONAL, from a clamped (always valid) address, and the rows / taps that fall outside
+// the image are zeroed when the registers are parked in LDS: a `v = 0; if (inside) v = load` form makes the compiler
+// wait for each load before issuing the next one (the select needs the loaded value), which serialises eight memory
+// latencies per k-tile -- measured: MFMA pipe 57 % busy with the waves waiting on vmcnt.
+struct RowCtx {            // per thread, fixed for the whole tile: its four pixels (A) / output channels (B)
+  int pix[4];              // A: element offset of in[b][0][0][0] for row q;   B: row offset n * ldw
+  int y0[4], x0[4];        // A: y * in_mul, x * in_mul
+  uint32_t valid;          // bit q: the row exists (m < M / n < N)
+};
+__device__ __forceinline__ RowCtx make_a_ctx(const ConvArgs& p, int m0) {
+  RowCtx c; c.valid = 0u;
   const int t = threadIdx.x;
-  const int k = k0 + (t & 7) * 4;
-  const int tap = k / p.Cin, ci = k - tap * p.Cin;
-  const bool kok = k < p.K;
-  const int dy = kok ? p.dy[z][tap] : 0, dx = kok ? p.dx[z][tap] : 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int m = m0 + (t >> 3) + 32 * q;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (kok && m < p.M) {
-      const int b = m / (p.GH * p.GW);
-      const int rem = m - b * (p.GH * p.GW);
-      const int y = rem / p.GW, x = rem - y * p.GW;
-      const int iy = y * p.in_mul + dy, ix = x * p.in_mul + dx;
-      if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
-        v = ld4(p.in + (((size_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci);
-    }
-    r[q] = v;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / (p.GH * p.GW);
+    const int rem = mm - b * (p.GH * p.GW);
+    const int y = rem / p.GW, x = rem - y * p.GW;
+    c.pix[q] = b * p.IH * p.IW;                 // pixel index of (b, 0, 0); B * IH * IW < 2^31 (checked by the launcher)
+    c.y0[q] = y * p.in_mul; c.x0[q] = x * p.in_mul;
+    c.valid |= ok ? (1u << q) : 0u;
   }
+  return c;
 }
-// B tile: 128 output channels x 32 k from W[z][co][K]
-__device__ __forceinline__ void load_b(const float* w, int ldw, int n0, int N, int k0, int K, f32x4 (&r)[4]) {
+// A tile: 128 pixels x 32 k; chunk = 4 consecutive k = 4 channels of one tap.  Returns the 4-bit keep mask.
+template <bool UNIFORM_TAP>
+__device__ __forceinline__ uint32_t load_a(const ConvArgs& p, const RowCtx& c, int z, int k0, f32x4 (&r)[4]) {
+  const int t = threadIdx.x;
+  int dy, dx, ci; bool kok;
+  if (UNIFORM_TAP) {           // Cin % 32 == 0: the whole k-tile lies inside one tap -> scalar table lookups
+    const int tap = __builtin_amdgcn_readfirstlane(k0 / p.Cin);
+    kok = true;                                        // K % 32 == 0 as well
+    tap_offset(p.kind, z, tap, dy, dx);
+    ci = k0 - tap * p.Cin + (t & 7) * 4;
+  } else {
+    const int k = k0 + (t & 7) * 4;
+    kok = k < p.K;
+    const int tap = kok ? k / p.Cin : 0;
+    ci = kok ? k - tap * p.Cin : 0;
+    tap_offset(p.kind, z, tap, dy, dx);
+  }
+  uint32_t keep = 0u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int iy = c.y0[q] + dy, ix = c.x0[q] + dx;
+    const bool ok = kok && ((c.valid >> q) & 1u) && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+    const int pixel = ok ? c.pix[q] + iy * p.IW + ix : 0;
+    ld4_async(r[q], p.in + (size_t)pixel * p.Cin + ci);
+    keep |= ok ? (1u << q) : 0u;
+  }
+  return keep;
+}
+// B tile: 128 rows x 32 k from a row-major [N][ldw] matrix (weights W[z][co][K]; x / E^T in the nearest-code search)
+__device__ __forceinline__ uint32_t load_b(const float* w, int ldw, int n0, int N, int k0, int K, f32x4 (&r)[4]) {
   const int t = threadIdx.x;
   const int k = k0 + (t & 7) * 4;
+  const bool kok = k < K;
+  uint32_t keep = 0u;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int n = n0 + (t >> 3) + 32 * q;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (n < N && k < K) v = ld4(w + (size_t)n * ldw + k);
-    r[q] = v;
+    const bool ok = kok && n < N;
+    ld4_async(r[q], w + (ok ? (size_t)n * ldw + k : (size_t)0));
+    keep |= ok ? (1u << q) : 0u;
   }
+  return keep;
 }
-__device__ __forceinline__ void store_tile(char* lds, const f32x4 (&r)[4]) {
+__device__ __forceinline__ void store_tile(char* lds, const f32x4 (&r)[4], uint32_t keep) {
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = (t >> 3) + 32 * q;
-    *reinterpret_cast<f32x4*>(lds + row * 128 + (((t & 7) ^ swz(row)) << 4)) = r[q];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(lds + row * 128 + (((t & 7) ^ swz(row)) << 4)) = ((keep >> q) & 1u) ? r[q] : zero;
   }
 }
 __device__ __forceinline__ f32x4 frag(const char* lds, int row, int chunk) {
@@ -110,10 +176,24 @@ __device__ __forceinline__ void mma_tile(const char* la, const char* lb, int wm,
   }
 }
 
-__global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs p) {
+// Workgroup -> (pixel tile, channel tile, parity): the grid is one-dimensional and XCD-aware.  Hardware hands
+// consecutive workgroup ids to the 8 XCDs round-robin, each XCD has its own 4-MiB L2, and 64 workgroups run on an XCD at
+// a time (2 per CU).  An XCD therefore takes a contiguous chunk of pixel tiles and walks it with (channel tile, parity)
+// varying fastest: the 64 concurrent workgroups are 64 / (channel tiles x parities) neighbouring pixel tiles times ALL
+// their channel tiles / parities, so every activation line is fetched into that L2 once and hit by the other
+// workgroups, and the weight slices are shared by the pixel tiles in flight.  (With a plain 3-D grid the workgroups
+// that read the same activations sat on different XCDs or ran far apart in time: 50 % L2 hit rate, the input tensor
+// streamed from HBM once per channel tile and parity -- 16 times for the last transposed convolution.)
+template <bool UT>      // UT: Cin % 32 == 0 (every k-tile lies inside one tap)
+__global__ __launch_bounds__(NT, 2) void conv_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (A 16K + B 16K) = 64 KiB
-  const int z = blockIdx.z;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
+  const int per = ntiles * p.nz, chunk = (mtiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int mt = xcd * chunk + local / per, yz = local % per;
+  if (mt >= mtiles) return;
+  const int z = yz / ntiles;
+  const int m0 = mt * BM, n0 = (yz - z * ntiles) * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int fr = lane & 31, fg = lane >> 5;
@@ -128,16 +208,33 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = (p.K + BK - 1) / BK;
-  f32x4 ra[4], rb[4];
-  load_a(p, z, m0, 0, ra); load_b(W, p.K, n0, p.Cout, 0, p.K, rb);
-  store_tile(smem, ra); store_tile(smem + 16384, rb);
+  const RowCtx ctx = make_a_ctx(p, m0);
+  // two k-tiles in flight in registers: the loads of kt+2 are issued before the MFMAs of kt, the loads of kt+1
+  // (issued one iteration earlier) are parked in LDS after them -- two MFMA phases between issue and use
+  f32x4 ra[2][4], rb[2][4];
+  uint32_t ka[2] = {0u, 0u}, kb[2] = {0u, 0u};
+  ka[0] = load_a<UT>(p, ctx, z, 0, ra[0]); kb[0] = load_b(W, p.K, n0, p.Cout, 0, p.K, rb[0]);
+  if (nk > 1) { ka[1] = load_a<UT>(p, ctx, z, BK, ra[1]); kb[1] = load_b(W, p.K, n0, p.Cout, BK, p.K, rb[1]); }
+  if (nk > 1) wait_loads<8>(ra[0], rb[0]); else wait_loads<0>(ra[0], rb[0]);
+  store_tile(smem, ra[0], ka[0]); store_tile(smem + 16384, rb[0], kb[0]);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) { load_a(p, z, m0, (kt + 1) * BK, ra); load_b(W, p.K, n0, p.Cout, (kt + 1) * BK, p.K, rb); }
-    mma_tile(smem + cur * 32768, smem + cur * 32768 + 16384, wm, wn, fr, fg, acc);
-    if (kt + 1 < nk) { store_tile(smem + (cur ^ 1) * 32768, ra); store_tile(smem + (cur ^ 1) * 32768 + 16384, rb); }
+  // one iteration: loads of tile kt+2 -> set `l`; MFMAs on LDS buffer `bo`; tile kt+1 (set `s`) -> the other buffer
+  auto step = [&](int kt, auto lc, auto sc, int bo) {
+    constexpr int l = decltype(lc)::value, sset = decltype(sc)::value;
+    if (kt + 2 < nk) { ka[l] = load_a<UT>(p, ctx, z, (kt + 2) * BK, ra[l]); kb[l] = load_b(W, p.K, n0, p.Cout, (kt + 2) * BK, p.K, rb[l]); }
+    __builtin_amdgcn_sched_barrier(0);     // nothing that needs tile kt+1's registers may move above the MFMAs
+    mma_tile(smem + bo, smem + bo + 16384, wm, wn, fr, fg, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) {
+      if (kt + 2 < nk) wait_loads<8>(ra[sset], rb[sset]); else wait_loads<0>(ra[sset], rb[sset]);    // tile kt+2 stays in flight
+      store_tile(smem + (bo ^ 32768), ra[sset], ka[sset]); store_tile(smem + (bo ^ 32768) + 16384, rb[sset], kb[sset]);
+    }
     __syncthreads();
+  };
+#pragma unroll 1
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0);
+    if (kt + 1 < nk) step(kt + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, 32768);
   }
   float* ct = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -163,7 +260,7 @@ __global__ __launch_bounds__(NT) void conv_kernel(const ConvArgs p) {
       const int b = m / (p.GH * p.GW);
       const int rem = m - b * (p.GH * p.GW);
       const int y = rem / p.GW, x = rem - y * p.GW;
-      const int oy = y * p.out_mul + p.ooy[z], ox = x * p.out_mul + p.oox[z];
+      const int oy = y * p.out_mul + (z >> 1), ox = x * p.out_mul + (z & 1);   // z = 0 unless transposed
       float* o = p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.Cout + n;
       *reinterpret_cast<f32x4*>(o) = x0;
       *reinterpret_cast<f32x4*>(o + 4) = x1;
@@ -215,15 +312,16 @@ __global__ __launch_bounds__(NT) void vq_argmin_kernel(const VqArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     f32x4 ra[4], rb[4];
-    load_b(p.x, p.D, m0, p.M, 0, p.D, ra); load_b(p.et, p.D, n0, p.NE, 0, p.D, rb);
+    uint32_t ka = load_b(p.x, p.D, m0, p.M, 0, p.D, ra), kb = load_b(p.et, p.D, n0, p.NE, 0, p.D, rb);
     __syncthreads();
-    store_tile(smem, ra); store_tile(smem + 16384, rb);
+    wait_loads<0>(ra, rb);
+    store_tile(smem, ra, ka); store_tile(smem + 16384, rb, kb);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
-      if (kt + 1 < nk) { load_b(p.x, p.D, m0, p.M, (kt + 1) * BK, p.D, ra); load_b(p.et, p.D, n0, p.NE, (kt + 1) * BK, p.D, rb); }
+      if (kt + 1 < nk) { ka = load_b(p.x, p.D, m0, p.M, (kt + 1) * BK, p.D, ra); kb = load_b(p.et, p.D, n0, p.NE, (kt + 1) * BK, p.D, rb); }
       mma_tile(smem + cur * 32768, smem + cur * 32768 + 16384, wm, wn, fr, fg, acc);
-      if (kt + 1 < nk) { store_tile(smem + (cur ^ 1) * 32768, ra); store_tile(smem + (cur ^ 1) * 32768 + 16384, rb); }
+      if (kt + 1 < nk) { wait_loads<0>(ra, rb); store_tile(smem + (cur ^ 1) * 32768, ra, ka); store_tile(smem + (cur ^ 1) * 32768 + 16384, rb, kb); }
       __syncthreads();
     }
 #pragma unroll
@@ -322,34 +420,34 @@ extern "C" int cogv_conv2d_nhwc_f32(const cogv_conv_desc* d, void* stream) {
   a.in = (const float*)d->in; a.w = (const float*)d->w; a.bias = (const float*)d->bias; a.out = (float*)d->out;
   a.B = d->B; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin; a.Cout = d->Cout; a.relu_out = d->relu;
   int nz = 1;
+  a.kind = d->kind;
   if (d->kind == COGV_CONV_4X4_S2) {
     if ((d->IH & 1) || (d->IW & 1)) return COGV_ERR_ARG;
     a.GH = a.OH = d->IH / 2; a.GW = a.OW = d->IW / 2; a.in_mul = 2; a.out_mul = 1; a.ntaps = 16;
-    for (int ky = 0; ky < 4; ++ky) for (int kx = 0; kx < 4; ++kx) { a.dy[0][ky * 4 + kx] = (int8_t)(ky - 1); a.dx[0][ky * 4 + kx] = (int8_t)(kx - 1); }
-    a.ooy[0] = a.oox[0] = 0;
   } else if (d->kind == COGV_CONV_1X1) {
     a.GH = a.OH = d->IH; a.GW = a.OW = d->IW; a.in_mul = 1; a.out_mul = 1; a.ntaps = 1;
-    a.dy[0][0] = a.dx[0][0] = 0; a.ooy[0] = a.oox[0] = 0;
   } else if (d->kind == COGV_CONVT_4X4_S2) {
     // out[2y+py] gets taps ky with ky = (py+1) mod 2 (+2):  py=0: ky=1 (iy=y), ky=3 (iy=y-1);  py=1: ky=0 (iy=y+1), ky=2 (iy=y)
-    // weights are packed [py*2+px][co][ty*2+tx][ci] with (ty -> ky) = py==0 ? {1,3} : {0,2}, same for x
+    // weights are packed [py*2+px][co][ty*2+tx][ci] with (ty -> ky) = py==0 ? {1,3} : {0,2}, same for x  => dy = py - ty
     a.GH = d->IH; a.GW = d->IW; a.OH = 2 * d->IH; a.OW = 2 * d->IW; a.in_mul = 1; a.out_mul = 2; a.ntaps = 4;
     nz = 4;
-    for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
-      const int z = py * 2 + px;
-      const int offy[2] = {py == 0 ? 0 : 1, py == 0 ? -1 : 0};
-      const int offx[2] = {px == 0 ? 0 : 1, px == 0 ? -1 : 0};
-      for (int ty = 0; ty < 2; ++ty) for (int tx = 0; tx < 2; ++tx) { a.dy[z][ty * 2 + tx] = (int8_t)offy[ty]; a.dx[z][ty * 2 + tx] = (int8_t)offx[tx]; }
-      a.ooy[z] = (int8_t)py; a.oox[z] = (int8_t)px;
-    }
   } else return COGV_ERR_UNSUPPORTED;
   a.K = a.ntaps * a.Cin;
   a.M = a.B * a.GH * a.GW;
   a.w_parity_stride = (long long)a.Cout * a.K;
+  a.nz = nz;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; }
-  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, nz);
-  hipLaunchKernelGGL(conv_kernel, grid, dim3(NT), 65536, reinterpret_cast<hipStream_t>(stream), a);
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr = true;
+  }
+  if ((long long)a.B * a.IH * a.IW >= (1ll << 31)) return COGV_ERR_ARG;
+  const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
+  const long long blocks = 8ll * ((mtiles + 7) / 8) * ntiles * nz;
+  if (blocks > 0x7fffffffll) return COGV_ERR_ARG;
+  if (a.Cin % BK == 0) hipLaunchKernelGGL(conv_kernel<true>, dim3((unsigned)blocks), dim3(NT), 65536, reinterpret_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(conv_kernel<false>, dim3((unsigned)blocks), dim3(NT), 65536, reinterpret_cast<hipStream_t>(stream), a);
   return cogv_check_launch();
 }
 
