@@ -78,8 +78,8 @@ __device__ __forceinline__ void wait_loads(f32x4 (&a)[4], f32x4 (&b)[4]) {
 // the image are zeroed when the registers are parked in LDS: a `v = 0; if (inside) v = load` form makes the compiler
 // wait for each load before issuing the next one (the select needs the loaded value), which serialises eight memory
 // latencies per k-tile -- measured: MFMA pipe 57 % busy with the waves waiting on vmcnt.
-struct RowCtx {            // per thread, fixed for the whole tile: its four pixels (A) / output channels (B)
-  int pix[4];              // A: element offset of in[b][0][0][0] for row q;   B: row offset n * ldw
+struct RowCtx {            // per thread, fixed for the whole tile: its four pixels (A) / rows (B)
+  const float* base[4];    // A: &in[b][0][0][0] of row q's image;   B: &w[n][4 * (t & 7)]
   int y0[4], x0[4];        // A: y * in_mul, x * in_mul
   uint32_t valid;          // bit q: the row exists (m < M / n < N)
 };
@@ -94,18 +94,33 @@ __device__ __forceinline__ RowCtx make_a_ctx(const ConvArgs& p, int m0) {
     const int b = mm / (p.GH * p.GW);
     const int rem = mm - b * (p.GH * p.GW);
     const int y = rem / p.GW, x = rem - y * p.GW;
-    c.pix[q] = b * p.IH * p.IW;                 // pixel index of (b, 0, 0); B * IH * IW < 2^31 (checked by the launcher)
+    c.base[q] = p.in + (size_t)b * p.IH * p.IW * p.Cin;
     c.y0[q] = y * p.in_mul; c.x0[q] = x * p.in_mul;
     c.valid |= ok ? (1u << q) : 0u;
   }
   return c;
 }
+__device__ __forceinline__ RowCtx make_b_ctx(const float* w, int ldw, int n0, int N) {
+  RowCtx c; c.valid = 0u;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = n0 + (t >> 3) + 32 * q;
+    const bool ok = n < N;
+    c.base[q] = w + (size_t)(ok ? n : 0) * ldw + (t & 7) * 4;
+    c.y0[q] = c.x0[q] = 0;
+    c.valid |= ok ? (1u << q) : 0u;
+  }
+  return c;
+}
 // A tile: 128 pixels x 32 k; chunk = 4 consecutive k = 4 channels of one tap.  Returns the 4-bit keep mask.
+// Offsets inside one image are 32-bit (IH * IW * Cin < 2^31, checked by the launcher); the products use the
+// full-rate 24-bit multiplier (iy, ix < 2^15 and IW * Cin, Cin < 2^24, checked by the launcher).
 template <bool UNIFORM_TAP>
 __device__ __forceinline__ uint32_t load_a(const ConvArgs& p, const RowCtx& c, int z, int k0, f32x4 (&r)[4]) {
   const int t = threadIdx.x;
   int dy, dx, ci; bool kok;
-  if (UNIFORM_TAP) {           // Cin % 32 == 0: the whole k-tile lies inside one tap -> scalar table lookups
+  if (UNIFORM_TAP) {           // Cin % 32 == 0: the whole k-tile lies inside one tap -> scalar arithmetic
     const int tap = __builtin_amdgcn_readfirstlane(k0 / p.Cin);
     kok = true;                                        // K % 32 == 0 as well
     tap_offset(p.kind, z, tap, dy, dx);
@@ -117,31 +132,24 @@ __device__ __forceinline__ uint32_t load_a(const ConvArgs& p, const RowCtx& c, i
     ci = kok ? k - tap * p.Cin : 0;
     tap_offset(p.kind, z, tap, dy, dx);
   }
+  const int row_pitch = p.IW * p.Cin;
   uint32_t keep = 0u;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int iy = c.y0[q] + dy, ix = c.x0[q] + dx;
-    const bool ok = kok && ((c.valid >> q) & 1u) && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-    const int pixel = ok ? c.pix[q] + iy * p.IW + ix : 0;
-    ld4_async(r[q], p.in + (size_t)pixel * p.Cin + ci);
+    const bool ok = kok && ((c.valid >> q) & 1u) && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+    const int off = ok ? __mul24(iy, row_pitch) + __mul24(ix, p.Cin) + ci : 0;
+    ld4_async(r[q], c.base[q] + off);
     keep |= ok ? (1u << q) : 0u;
   }
   return keep;
 }
 // B tile: 128 rows x 32 k from a row-major [N][ldw] matrix (weights W[z][co][K]; x / E^T in the nearest-code search)
-__device__ __forceinline__ uint32_t load_b(const float* w, int ldw, int n0, int N, int k0, int K, f32x4 (&r)[4]) {
-  const int t = threadIdx.x;
-  const int k = k0 + (t & 7) * 4;
-  const bool kok = k < K;
-  uint32_t keep = 0u;
+__device__ __forceinline__ uint32_t load_b(const RowCtx& c, int k0, int K, f32x4 (&r)[4]) {
+  const bool kok = k0 + (threadIdx.x & 7) * 4 < K;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int n = n0 + (t >> 3) + 32 * q;
-    const bool ok = kok && n < N;
-    ld4_async(r[q], w + (ok ? (size_t)n * ldw + k : (size_t)0));
-    keep |= ok ? (1u << q) : 0u;
-  }
-  return keep;
+  for (int q = 0; q < 4; ++q) ld4_async(r[q], c.base[q] + (kok ? k0 : 0));
+  return kok ? c.valid : 0u;
 }
 __device__ __forceinline__ void store_tile(char* lds, const f32x4 (&r)[4], uint32_t keep) {
   const int t = threadIdx.x;
@@ -156,23 +164,33 @@ __device__ __forceinline__ f32x4 frag(const char* lds, int row, int chunk) {
   return *reinterpret_cast<const f32x4*>(lds + row * 128 + ((chunk ^ swz(row)) << 4));
 }
 
-// one k-tile (32 floats) of MFMAs for a wave's 64x64 sub-tile
+// one k-tile (32 floats) of MFMAs for a wave's 64x64 sub-tile.  The fragments of k-block kb+1 are read into a second
+// register set BEFORE the 16 MFMAs of k-block kb (the compiler's own order reused one set and exposed the LDS latency
+// four times per k-tile); the scheduling barriers pin that order.
 __device__ __forceinline__ void mma_tile(const char* la, const char* lb, int wm, int wn, int fr, int fg,
                                          f32x16 (&acc)[2][2]) {
+  f32x4 fa[2][2], fb[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { fa[0][i] = frag(la, wm + 32 * i + fr, fg); fb[0][i] = frag(lb, wn + 32 * i + fr, fg); }
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {          // 8 k per step: lanes g=0 take slots 0..3, g=1 slots 4..7
-    f32x4 fa[2], fb[2];
+    const int c = kb & 1;
+    if (kb + 1 < 4) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[i] = frag(la, wm + 32 * i + fr, 2 * kb + fg);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) fb[j] = frag(lb, wn + 32 * j + fr, 2 * kb + fg);
+      for (int i = 0; i < 2; ++i) {
+        fa[c ^ 1][i] = frag(la, wm + 32 * i + fr, 2 * (kb + 1) + fg);
+        fb[c ^ 1][i] = frag(lb, wn + 32 * i + fr, 2 * (kb + 1) + fg);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][s], fb[c][j][s], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -184,7 +202,7 @@ __device__ __forceinline__ void mma_tile(const char* la, const char* lb, int wm,
 // workgroups, and the weight slices are shared by the pixel tiles in flight.  (With a plain 3-D grid the workgroups
 // that read the same activations sat on different XCDs or ran far apart in time: 50 % L2 hit rate, the input tensor
 // streamed from HBM once per channel tile and parity -- 16 times for the last transposed convolution.)
-template <bool UT>      // UT: Cin % 32 == 0 (every k-tile lies inside one tap)
+template <bool UT, int EXP = 0>      // UT: Cin % 32 == 0 (every k-tile lies inside one tap); EXP: timing probes (wrong results)
 __global__ __launch_bounds__(NT, 2) void conv_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (A 16K + B 16K) = 64 KiB
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
@@ -208,28 +226,29 @@ __global__ __launch_bounds__(NT, 2) void conv_kernel(const ConvArgs p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = (p.K + BK - 1) / BK;
-  const RowCtx ctx = make_a_ctx(p, m0);
+  const RowCtx ctx = make_a_ctx(p, m0), bctx = make_b_ctx(W, p.K, n0, p.Cout);
   // two k-tiles in flight in registers: the loads of kt+2 are issued before the MFMAs of kt, the loads of kt+1
   // (issued one iteration earlier) are parked in LDS after them -- two MFMA phases between issue and use
   f32x4 ra[2][4], rb[2][4];
   uint32_t ka[2] = {0u, 0u}, kb[2] = {0u, 0u};
-  ka[0] = load_a<UT>(p, ctx, z, 0, ra[0]); kb[0] = load_b(W, p.K, n0, p.Cout, 0, p.K, rb[0]);
-  if (nk > 1) { ka[1] = load_a<UT>(p, ctx, z, BK, ra[1]); kb[1] = load_b(W, p.K, n0, p.Cout, BK, p.K, rb[1]); }
+  ka[0] = load_a<UT>(p, ctx, z, 0, ra[0]); kb[0] = load_b(bctx, 0, p.K, rb[0]);
+  if (nk > 1) { ka[1] = load_a<UT>(p, ctx, z, BK, ra[1]); kb[1] = load_b(bctx, BK, p.K, rb[1]); }
   if (nk > 1) wait_loads<8>(ra[0], rb[0]); else wait_loads<0>(ra[0], rb[0]);
   store_tile(smem, ra[0], ka[0]); store_tile(smem + 16384, rb[0], kb[0]);
   __syncthreads();
   // one iteration: loads of tile kt+2 -> set `l`; MFMAs on LDS buffer `bo`; tile kt+1 (set `s`) -> the other buffer
   auto step = [&](int kt, auto lc, auto sc, int bo) {
     constexpr int l = decltype(lc)::value, sset = decltype(sc)::value;
-    if (kt + 2 < nk) { ka[l] = load_a<UT>(p, ctx, z, (kt + 2) * BK, ra[l]); kb[l] = load_b(W, p.K, n0, p.Cout, (kt + 2) * BK, p.K, rb[l]); }
+    if (!(EXP & 1) && kt + 2 < nk) { ka[l] = load_a<UT>(p, ctx, z, (kt + 2) * BK, ra[l]); kb[l] = load_b(bctx, (kt + 2) * BK, p.K, rb[l]); }
     __builtin_amdgcn_sched_barrier(0);     // nothing that needs tile kt+1's registers may move above the MFMAs
     mma_tile(smem + bo, smem + bo + 16384, wm, wn, fr, fg, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) {
-      if (kt + 2 < nk) wait_loads<8>(ra[sset], rb[sset]); else wait_loads<0>(ra[sset], rb[sset]);    // tile kt+2 stays in flight
+    if (!(EXP & 2) && kt + 1 < nk) {
+      if (EXP & 1) wait_loads<0>(ra[sset], rb[sset]);
+      else if (kt + 2 < nk) wait_loads<8>(ra[sset], rb[sset]); else wait_loads<0>(ra[sset], rb[sset]);    // tile kt+2 stays in flight
       store_tile(smem + (bo ^ 32768), ra[sset], ka[sset]); store_tile(smem + (bo ^ 32768) + 16384, rb[sset], kb[sset]);
     }
-    __syncthreads();
+    if (!(EXP & 4)) __syncthreads();
   };
 #pragma unroll 1
   for (int kt = 0; kt < nk; kt += 2) {
@@ -303,6 +322,7 @@ __global__ __launch_bounds__(NT) void vq_argmin_kernel(const VqArgs p) {
     for (int e = 0; e < 16; ++e) { bv[i][e] = INFINITY; bi[i][e] = 0; }
 
   const int nk = (p.D + BK - 1) / BK;
+  const RowCtx xctx = make_b_ctx(p.x, p.D, m0, p.M);
   for (int n0 = 0; n0 < p.NE; n0 += BN) {
     f32x16 acc[2][2];
 #pragma unroll
@@ -312,14 +332,15 @@ __global__ __launch_bounds__(NT) void vq_argmin_kernel(const VqArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     f32x4 ra[4], rb[4];
-    uint32_t ka = load_b(p.x, p.D, m0, p.M, 0, p.D, ra), kb = load_b(p.et, p.D, n0, p.NE, 0, p.D, rb);
+    const RowCtx ectx = make_b_ctx(p.et, p.D, n0, p.NE);
+    uint32_t ka = load_b(xctx, 0, p.D, ra), kb = load_b(ectx, 0, p.D, rb);
     __syncthreads();
     wait_loads<0>(ra, rb);
     store_tile(smem, ra, ka); store_tile(smem + 16384, rb, kb);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
-      if (kt + 1 < nk) { ka = load_b(p.x, p.D, m0, p.M, (kt + 1) * BK, p.D, ra); kb = load_b(p.et, p.D, n0, p.NE, (kt + 1) * BK, p.D, rb); }
+      if (kt + 1 < nk) { ka = load_b(xctx, (kt + 1) * BK, p.D, ra); kb = load_b(ectx, (kt + 1) * BK, p.D, rb); }
       mma_tile(smem + cur * 32768, smem + cur * 32768 + 16384, wm, wn, fr, fg, acc);
       if (kt + 1 < nk) { wait_loads<0>(ra, rb); store_tile(smem + (cur ^ 1) * 32768, ra, ka); store_tile(smem + (cur ^ 1) * 32768 + 16384, rb, kb); }
       __syncthreads();
@@ -442,10 +463,18 @@ extern "C" int cogv_conv2d_nhwc_f32(const cogv_conv_desc* d, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     attr = true;
   }
-  if ((long long)a.B * a.IH * a.IW >= (1ll << 31)) return COGV_ERR_ARG;
+  if ((long long)a.IH * a.IW * a.Cin >= (1ll << 31) || (long long)a.IW * a.Cin >= (1 << 23) || a.IH >= 32768 || a.IW >= 32768) return COGV_ERR_ARG;
   const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
   const long long blocks = 8ll * ((mtiles + 7) / 8) * ntiles * nz;
   if (blocks > 0x7fffffffll) return COGV_ERR_ARG;
+  static const int probe = [] { const char* e = getenv("COGV_CONV_EXP"); return e ? atoi(e) : 0; }();
+  if (probe && a.Cin % BK == 0) {
+    void (*k)(const ConvArgs) = probe == 1 ? conv_kernel<true, 1> : probe == 2 ? conv_kernel<true, 2> : probe == 3 ? conv_kernel<true, 3>
+                              : probe == 4 ? conv_kernel<true, 4> : probe == 6 ? conv_kernel<true, 6> : conv_kernel<true, 7>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NT), 65536, reinterpret_cast<hipStream_t>(stream), a);
+    return cogv_check_launch();
+  }
   if (a.Cin % BK == 0) hipLaunchKernelGGL(conv_kernel<true>, dim3((unsigned)blocks), dim3(NT), 65536, reinterpret_cast<hipStream_t>(stream), a);
   else hipLaunchKernelGGL(conv_kernel<false>, dim3((unsigned)blocks), dim3(NT), 65536, reinterpret_cast<hipStream_t>(stream), a);
   return cogv_check_launch();
