@@ -221,8 +221,10 @@ def run_gpt(args, dtype_name, world, rank, mp):
     model = GPT2Model(L, vocab, h, heads, args.dropout, args.dropout, args.dropout, ROW, 0, args.checkpoint_activations)
     n_params = sum(p.numel() for p in model.parameters())          # per rank (a shard when mp > 1)
     model = FP16_Module(model.cuda(), dtype=dtype, keep_half_outputs=True)
+    ddp = None
     if dp_world > 1:
-        model = PyTorchDistributedDataParallel(model, process_group=mpu.get_data_parallel_group())
+        model = ddp = PyTorchDistributedDataParallel(model, process_group=mpu.get_data_parallel_group(),
+                                                     shard_optimizer=args.shard_optimizer)
     inner = model
     while hasattr(inner, "module"):
         inner = inner.module
@@ -235,6 +237,8 @@ def run_gpt(args, dtype_name, world, rank, mp):
                          dynamic_loss_args={"init_scale": 2 ** 16 if dtype == torch.float16 else 1.0,
                                             "scale_window": 1000, "min_scale": 1, "delayed_shift": 2})
     assert opt._arena is not None
+    if ddp is not None:
+        opt.attach_data_parallel(ddp)
     model.train()
     log(f"[bench] {args.config}: {n_params / 1e6:.1f}M params per rank, built in {time.perf_counter() - t0:.1f}s, "
         f"rank {rank}/{world} (mp {mp} x dp {dp_world}), micro-batch {args.batch}, dtype {dtype_name}, "
@@ -263,7 +267,8 @@ def run_gpt(args, dtype_name, world, rank, mp):
                                f"1089 random token ids -> 1088 model positions, vocab {vocab}, full train step "
                                f"(fwd+CE+nan guard+bwd+grad all-reduce+clip+AdamW)",
                    "global_batch": dp_world * args.batch, "seq_len": ROW, "model_positions": ROW - 1,
-                   "parallelism": f"dp{dp_world}" + (f"-mp{mp}" if mp > 1 else ""), "dropout": args.dropout,
+                   "parallelism": f"dp{dp_world}" + (f"-mp{mp}" if mp > 1 else "") + ("-sharded-optimizer" if (ddp is not None and ddp.shard is not None) else ""),
+                   "dropout": args.dropout,
                    "activation_recompute": bool(args.checkpoint_activations), "loss": final_loss,
                    "loss_scale": opt.loss_scale, "skipped_last_step": int(skipped),
                    "logits_rel_l2_vs_fp32_reference": LOGITS_REL_L2[dtype_name]},
@@ -292,7 +297,7 @@ def run_gpt(args, dtype_name, world, rank, mp):
             out["roofline"]["traffic_source"] = os.path.relpath(tpath, ROOT)
             out["roofline"]["algorithmic_bytes_per_launch"] = algo
     # release this model's HBM (a second dtype leg may follow in the same process)
-    del step, batch, opt, model, inner, groups
+    del step, batch, opt, model, inner, groups, ddp
     import gc
     gc.collect()
     torch.cuda.empty_cache()
@@ -361,6 +366,9 @@ def main():
                     help="default: bf16 as the headline value, plus an fp16 leg in the same line when N=1")
     ap.add_argument("--model-parallel", type=int, default=1,
                     help="model-parallel size (BASELINE configs[2]: 2); ranks r, r+1 form a group (mpu/initialize.py)")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="data-parallel exchange as reduce-scatter + owned-slice AdamW + all-gather (ZeRO stage 1 shape, "
+                         "scripts/ds_config_zero.json) instead of the bucketed all-reduce")
     ap.add_argument("--dropout", type=float, default=0.1, help="reference default (arguments.py:30,40)")
     ap.add_argument("--checkpoint-activations", action="store_true",
                     help="recompute each layer in backward (the reference's scripts do; 288 GB HBM makes it unnecessary)")

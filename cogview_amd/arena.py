@@ -48,17 +48,34 @@ class ParamArena:
         last = idx[-1]
         return self.offsets[idx[0]], self.offsets[last] + (self.params[last].numel() + ALIGN - 1) // ALIGN * ALIGN
 
-    def chunk_table(self, group_of, norm_of):
+    def chunk_table(self, group_of, norm_of, owned=None):
         """Device chunk table for cogv_grad_stats / cogv_adamw_step.
-        group_of(param) -> hyper-parameter group index; norm_of(param) -> bool (counted in the global norm)."""
+        group_of(param) -> hyper-parameter group index; norm_of(param) -> bool (counted in the global norm).
+        owned: optional sorted list of disjoint element ranges [(s, e)] (multiples of 8): only the parts of the parameters
+        inside them are listed (a data-parallel rank's share when the optimizer is sharded)."""
         starts, lens, groups, norms = [], [], [], []
+        oi = 0
         for p, off in zip(self.params, self.offsets):
             g, n = group_of(p), norm_of(p)
-            for c0 in range(0, p.numel(), CHUNK):
-                starts.append(off + c0)
-                lens.append(min(CHUNK, p.numel() - c0))
-                groups.append(g)
-                norms.append(1 if n else 0)
+            spans = [(off, off + p.numel())]
+            if owned is not None:
+                spans = []
+                while oi < len(owned) and owned[oi][1] <= off:
+                    oi += 1
+                j = oi
+                while j < len(owned) and owned[j][0] < off + p.numel():
+                    a, b = max(owned[j][0], off), min(owned[j][1], off + p.numel())
+                    if b > a:
+                        spans.append((a, b))
+                    j += 1
+            for a, b in spans:
+                for c0 in range(a, b, CHUNK):
+                    starts.append(c0)
+                    lens.append(min(CHUNK, b - c0))
+                    groups.append(g)
+                    norms.append(1 if n else 0)
+        if not starts:                       # a rank may own nothing of a tiny model: one empty chunk keeps the kernels happy
+            starts, lens, groups, norms = [0], [0], [0], [0]
         dev = self.data.device
         return (torch.tensor(starts, dtype=torch.int64, device=dev), torch.tensor(lens, dtype=torch.int32, device=dev),
                 torch.tensor(groups, dtype=torch.uint8, device=dev), torch.tensor(norms, dtype=torch.uint8, device=dev))

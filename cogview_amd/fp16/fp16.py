@@ -128,9 +128,9 @@ class FP16_Optimizer(object):
             self.fp32_from_fp32_groups.append(fp32_params)
         if fused:
             mp_rank0 = (not mpu.model_parallel_is_initialized()) or mpu.get_model_parallel_rank() == 0
-            self._tables = arena.chunk_table(
-                lambda p: group_of[id(p)],
-                lambda p: bool(getattr(p, 'model_parallel', False)) or mp_rank0)      # mpu/grads.py:61
+            self._group_of = lambda p: group_of[id(p)]
+            self._norm_of = lambda p: bool(getattr(p, 'model_parallel', False)) or mp_rank0      # mpu/grads.py:61
+            self._tables = arena.chunk_table(self._group_of, self._norm_of)
         else:
             self.optimizer.load_state_dict(self.optimizer.state_dict())
         if dynamic_loss_scale:
@@ -143,7 +143,7 @@ class FP16_Optimizer(object):
         self.overflow = False
         self.first_closure_call_this_step = True
         self.clip_grad_norm = clip_grad_norm
-        self._clip, self._stats_valid, self._ddp = 0.0, False, None
+        self._clip, self._stats_valid, self._ddp, self._shard = 0.0, False, None, None
 
     # ---------------------------------------------------------------------------------------------- misc
     def maybe_print(self, msg):
@@ -151,8 +151,15 @@ class FP16_Optimizer(object):
             print(msg)
 
     def attach_data_parallel(self, ddp):
-        """Let update_master_grads() finish the overlapped gradient all-reduce first."""
+        """Let update_master_grads() finish the overlapped gradient exchange first.  With a sharded exchange
+        (DistributedDataParallel(shard_optimizer=True)) the statistics and AdamW passes are restricted to this rank's
+        slices of the flat buffers and step() all-gathers the updated parameters."""
         self._ddp = ddp
+        shard = getattr(ddp, 'shard', None)
+        if shard is not None:
+            assert self._arena is not None and self._arena is ddp.arena, "sharding needs the fused flat optimizer path"
+            self._shard = shard
+            self._tables = self._arena.chunk_table(self._group_of, self._norm_of, owned=shard.owned())
 
     def __getstate__(self):
         raise RuntimeError("FP16_Optimizer should be serialized using state_dict().")
@@ -184,6 +191,8 @@ class FP16_Optimizer(object):
     def _compute_stats(self):
         self._stats.zero_()
         ops.grad_stats(self._arena.grad, self._tables[0], self._tables[1], self._tables[3], self._stats)
+        if self._shard is not None:          # every rank saw its own slices: sum of squares and overflow count add up
+            torch.distributed.all_reduce(self._stats, group=self._shard.group)
         if mpu.model_parallel_is_initialized() and mpu.get_model_parallel_world_size() > 1:
             g = mpu.get_model_parallel_group()
             st = self._stats.clone()
@@ -246,6 +255,9 @@ class FP16_Optimizer(object):
         return self.clip_grad_norm(fp32_params, max_norm, norm_type)
 
     def state_dict(self):
+        if self._shard is not None:          # refresh the slices other ranks own: the saved state is the full, reference-layout one
+            for flat in (self._master_flat, self._m_flat, self._v_flat):
+                self._shard.gather_state(flat)
         if self._arena is not None:
             for g in self.optimizer.param_groups:     # where the generic path / apex FusedAdam keep the step
                 g['step'] = self._step_count
@@ -312,6 +324,8 @@ class FP16_Optimizer(object):
                            bias_correction=bool(groups[0].get('bias_correction', True)),
                            adam_w_mode=bool(getattr(self.optimizer, 'adam_w_mode', 1)))
             self._stats_valid = False
+            if self._shard is not None:
+                self._shard.gather_params()
             return None
         retval = self._step_with_closure(closure) if closure is not None else self.optimizer.step()
         self._master_params_to_model_params()

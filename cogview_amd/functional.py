@@ -36,6 +36,19 @@ def _mp_allreduce(t):
     return t
 
 
+def _mp_allreduce_start(t):
+    """Start the model-parallel sum of `t` (in place) without blocking the compute stream: RCCL runs it on its own
+    stream behind everything enqueued so far; returns a handle for _mp_allreduce_finish (None when not model parallel)."""
+    if mp_world_size_or_1() > 1:
+        return torch.distributed.all_reduce(t, group=get_model_parallel_group(), async_op=True)
+    return None
+
+
+def _mp_allreduce_finish(work):
+    if work is not None:
+        work.wait()          # nccl: the compute stream waits for the collective; gloo (tests): the host waits
+
+
 def _drop(p, training, attention=False):
     """None or (p, seed, stream_id) drawn from the RNG tracker."""
     if not training or p <= 0.0:
@@ -505,11 +518,21 @@ def _layer_backward(layer, kp, dout, sep):
                                dbeta=G(ln4.bias), colsum=G(b2), accumulate=True).view(rows, h)
     # The four weight gradients dW = dY^T X are deferred to a grouped launch (flush_weight_grads): together their
     # 256x256 tiles fill whole rounds of the 256 CUs (each alone needs split-K slabs or idles half a round).
-    wgrads = _WGRADS.problems
+    # Model parallel: the two column-parallel dgrads (dc, da) are partial sums that must be all-reduced before the
+    # LayerNorm backward that consumes them; the weight gradients of the GEMMs already back-propagated are independent
+    # of that exchange, so they are launched while it runs (the reference's autograd serialises them, mpu/mappings.py:
+    # 79-93 inside F.linear's backward).  Without model parallelism they stay deferred to the grouped launch.
+    mp = mp_world_size_or_1()
+    wgrads = _WGRADS.problems if mp == 1 else []
     du = ops.gemm(d_mo, W2, trans_b=True, mul_aux=kp.u, colsum_out=G(b1))       # dgrad x stored gelu' + bias grad of h->4h
     wgrads.append((d_mo, kp.g, G(W2)))
-    dc = _mp_allreduce(ops.gemm(du, W1, trans_b=True))
+    dc = ops.gemm(du, W1, trans_b=True)
     wgrads.append((du, kp.c.view(rows, h), G(W1)))
+    if mp > 1:
+        work = _mp_allreduce_start(dc)
+        ops.gemm_grouped(wgrads, trans_a=True, trans_b=True, accumulate=True)     # overlaps the exchange of dc
+        wgrads = []
+        _mp_allreduce_finish(work)
     # y feeds LN2 and the second residual:  dy = dout + LN2'(dc)
     dy = ops.sandwich_ln_bwd(dc.view(b, s, h), kp.y, ln2.weight, *kp.st2, add_in=dout, dgamma=G(ln2.weight),
                              dbeta=G(ln2.bias), accumulate=True)
@@ -527,8 +550,12 @@ def _layer_backward(layer, kp, dout, sep):
                       dq=dqkv[:, :, 0:hp].view(b, s, npp, 64), dk=dqkv[:, :, hp:2 * hp].view(b, s, npp, 64),
                       dv=dqkv[:, :, 2 * hp:].view(b, s, npp, 64), colsum_out=G(bq))
     dqkv2 = dqkv.view(rows, 3 * hp)
-    da = _mp_allreduce(ops.gemm(dqkv2, Wq, trans_b=True))
+    da = ops.gemm(dqkv2, Wq, trans_b=True)
     wgrads.append((dqkv2, kp.a.view(rows, h), G(Wq)))
+    if mp > 1:
+        work = _mp_allreduce_start(da)
+        ops.gemm_grouped(wgrads, trans_a=True, trans_b=True, accumulate=True)     # overlaps the exchange of da
+        _mp_allreduce_finish(work)
     dx = ops.sandwich_ln_bwd(da.view(b, s, h), kp.x, ln1.weight, *kp.st1, add_in=dy, dgamma=G(ln1.weight),
                              dbeta=G(ln1.bias), accumulate=True)
     return dx

@@ -292,6 +292,7 @@ class GPT2ParallelTransformer(torch.nn.Module):
         self.final_layernorm = LayerNorm(hidden_size, eps=layernorm_epsilon)
         self.rmask = None
         self.on_layer_backward_done = None      # set by the data-parallel wrapper to overlap the all-reduce
+        self.on_layer_forward_start = None      # set by the data-parallel wrapper: parameters of layer i must have arrived
 
     def embed(self, input_ids, position_ids, word_embeddings):
         """word + position embedding + embedding dropout in ONE kernel (mpu/layers.py:117-133 and
@@ -347,6 +348,8 @@ class GPT2ParallelTransformer(torch.nn.Module):
             mem_layers = []
         for i, layer in enumerate(self.layers):
             mem_i = mems[i] if mems else None
+            if self.on_layer_forward_start is not None:
+                self.on_layer_forward_start(i)
             if kv_mode:
                 slot = KVCacheSlot(mem_i, self.max_memory_length)
                 hidden_states = layer(hidden_states, sep, mem=slot)

@@ -177,6 +177,50 @@ def w_sharding_rule(rank, world):
     assert col.bias.model_parallel and not hasattr(row.bias, "model_parallel")
 
 
+def w_shard_plan(rank, world):
+    """ShardPlan (reduce-scatter / all-gather exchange): the ranks' owned slices tile the arena exactly once, the
+    restricted chunk table lists exactly the owned elements, and reduce_region leaves the MEAN gradient in the owner's
+    slice (gloo, CPU tensors: the collectives' host logic; the stream / kernel side is covered on the GPU)."""
+    from types import SimpleNamespace
+    from cogview_amd import mpu
+    from cogview_amd.arena import ParamArena
+    from cogview_amd.model.distributed import ShardPlan
+    mpu.initialize_model_parallel(1)
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(n)) for n in (1000, 70000, 300, 4096, 131072 + 5, 640)]
+    arena = ParamArena(params, torch.float32, torch.device("cpu"))
+    cut1, cut2 = arena.offsets[2], arena.offsets[4]
+    ddp = SimpleNamespace(world=world, data_parallel_group=mpu.get_data_parallel_group(), arena=arena,
+                          _buckets=[(1, (cut2, arena.total)), (0, (cut1, cut2))])
+    ddp._allreduce_mean = lambda g: (g.div_(world), dist.all_reduce(g, group=ddp.data_parallel_group))
+    plan = ShardPlan(ddp)
+    assert plan.regions == [(0, cut1), (cut1, cut2), (cut2, arena.total)]
+    cover = torch.zeros(arena.total, dtype=torch.int32)
+    for r in range(world):
+        for a, b in plan.owned(r):
+            assert a % 8 == 0 and b > a
+            cover[a:b] += 1
+    assert bool((cover == 1).all()), "owned slices must tile the arena exactly once"
+    own = plan.owned()
+    st, ln, grp, nrm = arena.chunk_table(lambda p: 0, lambda p: True, owned=own)
+    listed = torch.zeros(arena.total, dtype=torch.int32)
+    for a, n in zip(st.tolist(), ln.tolist()):
+        listed[a:a + n] += 1
+    want = torch.zeros(arena.total, dtype=torch.int32)
+    for (p_, off) in zip(arena.params, arena.offsets):
+        for a, b in own:
+            lo, hi = max(a, off), min(b, off + p_.numel())
+            if hi > lo:
+                want[lo:hi] = 1
+    assert torch.equal(listed, want), "restricted chunk table != owned parameter elements"
+    arena.grad.copy_(torch.arange(arena.total, dtype=torch.float32) * (rank + 1))
+    for s_, e_ in plan.regions:
+        plan.reduce_region(s_, e_)
+    mean = torch.arange(arena.total, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+    for a, b in own:
+        assert torch.allclose(arena.grad[a:b], mean[a:b], rtol=1e-6), "owned slice does not hold the mean gradient"
+
+
 def w_checkpoint_mp2_dp2(rank, world):
     """utils.save/load_checkpoint on a 2 x 2 grid: each model-parallel rank's file is written once (by its data-parallel
     rank 0), the tracker by global rank 0, and every rank reloads its own shard."""
@@ -255,6 +299,14 @@ def test_trainer_data_path_world2():
 
 def test_checkpoint_files_world4_mp2():
     _run("w_checkpoint_mp2_dp2", 4)
+
+
+def test_shard_plan_world2():
+    _run("w_shard_plan", 2)
+
+
+def test_shard_plan_world4():
+    _run("w_shard_plan", 4)
 
 
 def test_topology_world4_mp2():
