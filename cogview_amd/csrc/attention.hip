@@ -161,26 +161,32 @@ __device__ __forceinline__ void mask_frag(f32x16& a, int lim, int lim_sep, int b
   }
 }
 
-// dropout bits for (attention row `arow` = (b*H+head)*s_q + q, keys key0..key0+3, key0 % 4 == 0)
-__device__ __forceinline__ u32x2 attn_bits(uint32_t key, long long arow, int ngrp, int key0) {
-  return Philox::gen64_k(key, (uint64_t)(arow * ngrp + (key0 >> 2)));
+// Attention dropout bits.  One 64-bit draw per (attention row arow = (b*H+head)*s_q + q, group g = key >> 2 of 4
+// consecutive keys); element i = key & 3 takes bits 16 (i & 1) .. +15 of word i >> 1:
+//     rk   = pcg32((lo32(arow) ^ key) + hi32(arow) * 0x85EBCA6B)            per row, once per kernel
+//     x    = rk + g * 0x9E3779B9;  x ^= x >> 15;  x *= 0x2C1B3C6D;  x ^= x >> 12          word 0
+//     y    = (x ^ 0x68E31DA4) * 0x297A2D39;  y ^= y >> 15                                   word 1
+// The row hash carries the quality (PCG); the per-draw part is a Weyl step (an ADD per draw when g advances by a
+// constant, as it does along a lane's keys in the forward and dQ kernels) and one multiply-xorshift round per word --
+// 16 instruction slots per draw where the former generator (PCG + xorshift32 on a 64-bit counter with carry) took 28,
+// in kernels that are bound by VALU issue.  Neighbour correlations of the keep mask measured at the noise level
+// (oracle/cogview_oracle.py restates it; tests compare every kernel with the oracle's masks).
+struct RowKey { uint32_t rk; };
+__device__ __forceinline__ RowKey row_key(uint32_t key, unsigned long long arow) {
+  return RowKey{pcg32(((uint32_t)arow ^ key) + (uint32_t)(arow >> 32) * 0x85EBCA6Bu)};
 }
-__device__ __forceinline__ uint32_t bits_of(const u32x2& r, int i) { return (r[i >> 1] >> (16 * (i & 1))) & 0xffffu; }
-// The same draw with the 64-bit group counter kept as (lo, hi * C): ctr = base + g with g < 2^32.  Bit-identical to
-// attn_bits(key, arow, ngrp, key0) for base = arow * ngrp, g = key0 >> 2, without the per-draw 64-bit add and the
-// quarter-rate multiply of the high word (it only changes on a carry).
-struct CtrBase { uint32_t lo, hic; };
-__device__ __forceinline__ CtrBase ctr_base(unsigned long long base) {
-  return CtrBase{(uint32_t)base, (uint32_t)(base >> 32) * 0x85EBCA6Bu};
-}
-__device__ __forceinline__ u32x2 attn_bits_at(uint32_t key, const CtrBase& cb, uint32_t g) {
-  const uint32_t lo = cb.lo + g;
-  const uint32_t hic = cb.hic + (lo < cb.lo ? 0x85EBCA6Bu : 0u);
+__device__ __forceinline__ u32x2 attn_bits_w(uint32_t w) {          // w = rk + g * 0x9E3779B9
   u32x2 o;
-  o[0] = pcg32((lo ^ key) + hic);
-  o[1] = xorshift32(o[0] ^ 0x68E31DA4u);
+  uint32_t x = w ^ (w >> 15);
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  uint32_t y = (x ^ 0x68E31DA4u) * 0x297A2D39u;
+  y ^= y >> 15;
+  o[0] = x; o[1] = y;
   return o;
 }
+__device__ __forceinline__ u32x2 attn_bits_at(const RowKey& r, uint32_t g) { return attn_bits_w(r.rk + g * 0x9E3779B9u); }
+__device__ __forceinline__ uint32_t bits_of(const u32x2& r, int i) { return (r[i >> 1] >> (16 * (i & 1))) & 0xffffu; }
 // keep test on element i of a draw without extracting the 16-bit field: high halves compare the whole word against
 // thr << 16 (the low half only adds less than one unit), low halves compare the low 16 bits
 __device__ __forceinline__ bool keep_of(const u32x2& r, int i, uint32_t thr16) {
@@ -255,8 +261,9 @@ __device__ __forceinline__ void tile_colsum(const float (&vals)[2][16], float* l
 // =====================================================================================================
 // forward: grid (ceil(s_q/128), H, B); wave w owns queries q0 + 32w .. +31.  Ring stage = K tile | V tile.
 // =====================================================================================================
-template <typename T, bool IDX>
+template <typename T, bool IDX, int DROP>       // DROP: 1 / 0 = dropout on / off at compile time, -1 = decided by p.thr16
 __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
+  const bool drop = DROP < 0 ? (p.thr16 != 0u) : (DROP != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 stages x 16 KiB
   constexpr int STAGE = 2 * TILE, LPT = 4;
   const int lane = threadIdx.x & 63;
@@ -293,11 +300,10 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   const float sl2 = p.scale * 1.4426950408889634f;   // raw score -> log2 domain
   const float masked_raw = MASKED / p.scale;         // raw value whose scaled score is exactly -10000
   const long long arow = ((long long)b * p.H + head) * p.s_q + myq;
-  const int ngrp = (p.s_k + 3) >> 2;
-  const CtrBase cb = ctr_base((unsigned long long)arow * (unsigned long long)ngrp);
+  const RowKey cb = row_key(p.rng_key, (unsigned long long)arow);
   // dropout scale 1 / (1 - p) folded into the exponent: the probabilities (and their running sum) carry it, the
   // final normalisation takes it back out -- no multiply per kept element
-  const float kofs = p.thr16 ? __builtin_amdgcn_logf(p.keep_scale) : 0.f;     // v_log_f32 = log2
+  const float kofs = drop ? __builtin_amdgcn_logf(p.keep_scale) : 0.f;     // v_log_f32 = log2
   const uint32_t loff[2] = {tr_lane_off(0, lane) ^ tr_lane_fix(lane), tr_lane_off(1, lane) ^ tr_lane_fix(lane)};
   const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
 
@@ -366,10 +372,20 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
           mask_frag(sacc[sb], myq + off - base, p.sep_k - base, p.s_k - base, masked_raw);
         }
       }
-      float mb = fmaxf(sacc[0][0], sacc[1][0]);
+      // row maximum of the 32 scores: v_max3_f32 (the maxnum of fmaxf costs an extra canonicalising v_max per operand)
+      float mb = sacc[0][0];
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mb) : "v"(mb), "v"(sacc[1][0]), "v"(sacc[0][1]));
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mb) : "v"(mb), "v"(sacc[1][1]), "v"(sacc[0][2]));
 #pragma unroll
-      for (int e = 1; e < 16; ++e) mb = fmaxf(mb, fmaxf(sacc[0][e], sacc[1][e]));
-      mb = fmaxf(mb, __shfl_xor(mb, 32, 64)) * sl2;
+      for (int e = 2; e < 16; e += 1) {
+        if (e < 15) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mb) : "v"(mb), "v"(sacc[1][e]), "v"(sacc[0][e + 1]));
+        else asm("v_max_f32 %0, %1, %2" : "=v"(mb) : "v"(mb), "v"(sacc[1][e]));
+      }
+      {
+        const float other = __shfl_xor(mb, 32, 64);
+        asm("v_max_f32 %0, %1, %2" : "=v"(mb) : "v"(mb), "v"(other));
+      }
+      mb *= sl2;
       if (!__all(mb <= m_run)) {               // running max grew for some row of this wave: rescale (rare later on)
         const float m_new = fmaxf(m_run, mb);
         const float alpha = fast_exp2(m_run - m_new);
@@ -386,12 +402,12 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { const float pv = fast_exp2(fmaf(sacc[sb][e], sl2, kofs - m_run)); sacc[sb][e] = pv; ls += pv; }
       l_run += ls;
-      if (p.thr16) {
+      if (drop) {
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
-            const u32x2 r = attn_bits_at(p.rng_key, cb, (uint32_t)((kb * 64 + sb * 32 + 8 * gq + 4 * fg) >> 2));
+            const u32x2 r = attn_bits_at(cb, (uint32_t)((kb * 64 + sb * 32 + 8 * gq + 4 * fg) >> 2));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               sacc[sb][4 * gq + i] = keep_of(r, i, p.thr16) ? sacc[sb][4 * gq + i] : 0.f;
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   wait_vmcnt<0>();
   if (wave_active && myq < p.s_q) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);       // = keep_scale * sum of probabilities
-    const float inv = (p.thr16 ? p.keep_scale : 1.0f) / l_tot;
+    const float inv = (drop ? p.keep_scale : 1.0f) / l_tot;
     if (fg == 0 && p.lse) p.lse[((long long)b * p.H + head) * p.s_q + myq] = (m_run + __builtin_amdgcn_logf(l_tot) - kofs) * 0.6931471805599453f;
     T* O = reinterpret_cast<T*>(p.o) + b * p.o_bs + (long long)myq * p.o_rs + head * HD;
 #pragma unroll
@@ -445,8 +461,9 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
 // dQ: grid (ceil(s_q/128), H, B); lane = query.   dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
 // Ring stage = K tile | V tile (K serves both S^T (natural read) and dQ^T (transposing read)).
 // =====================================================================================================
-template <typename T, bool IDX>
+template <typename T, bool IDX, int DROP>
 __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
+  const bool drop = DROP < 0 ? (p.thr16 != 0u) : (DROP != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 2 * TILE, LPT = 4;
   const int lane = threadIdx.x & 63;
@@ -472,8 +489,8 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     dof[t] = load_frag_global<T>(DO + (long long)myq * p.do_rs + 16 * t + 8 * fg, qvalid);
   }
   const long long arow = ((long long)b * p.H + head) * p.s_q + myq;
-  const CtrBase cb = ctr_base((unsigned long long)arow * (unsigned long long)((p.s_k + 3) >> 2));
-  const float kscale = p.thr16 ? p.keep_scale : 1.0f;
+  const RowKey cb = row_key(p.rng_key, (unsigned long long)arow);
+  const float kscale = drop ? p.keep_scale : 1.0f;
   const float lse2 = qvalid ? p.lse[arow] * 1.4426950408889634f : 0.f;
   // D[q] = sum_d dO[q][d] O[q][d] (the softmax-backward row term): computed here from the dO fragments this lane
   // already holds (+ the matching O fragments), published for the dK/dV kernel that runs next -- no separate pass
@@ -489,7 +506,6 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     dv += __shfl_xor(dv, 32, 64);
     if (qvalid && fg == 0) p.dvec[arow] = dv;
   }
-  const int ngrp = (p.s_k + 3) >> 2;
   const float sl2 = p.scale * 1.4426950408889634f;
   const float masked_raw = MASKED / p.scale;
 
@@ -568,13 +584,13 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           u32x2 r = {0u, 0u};
-          if (p.thr16) r = attn_bits_at(p.rng_key, cb, (uint32_t)((kfirst + 8 * gq + 4 * fg) >> 2));
+          if (drop) r = attn_bits_at(cb, (uint32_t)((kfirst + 8 * gq + 4 * fg) >> 2));
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int e = 4 * gq + i;
             const float pr = fast_exp2(fmaf(sacc[e], sl2, -lse2));
             float dp = pacc[e];
-            if (p.thr16) dp = keep_of(r, i, p.thr16) ? dp : 0.f;
+            if (drop) dp = keep_of(r, i, p.thr16) ? dp : 0.f;
             ds[e] = pr * fmaf(dp, kscale, -dv);                  // kscale = 1 / (1 - p) (1 without dropout)
           }
         }
@@ -621,8 +637,9 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 // Ring stage = Q tile | dO tile | LSE[64] | D[64]  (64 queries per stage; Q and dO each serve a natural and a
 // transposing read).
 // =====================================================================================================
-template <typename T, bool IDX>
+template <typename T, bool IDX, int DROP>
 __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) {
+  const bool drop = DROP < 0 ? (p.thr16 != 0u) : (DROP != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 2 * TILE + 512, LPT = 6;
   const int lane = threadIdx.x & 63;
@@ -667,10 +684,9 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   const float sl2 = p.scale * 1.4426950408889634f;
   const float l2e = 1.4426950408889634f;
   const float masked_raw = MASKED / p.scale;
-  const int ngrp = (p.s_k + 3) >> 2;
   const long long arow0 = ((long long)b * p.H + head) * p.s_q;
-  const float kscale = p.thr16 ? p.keep_scale : 1.0f;
-  const unsigned long long ctr_lane = (unsigned long long)(arow0 + 4 * fg + (lane & 3)) * (unsigned long long)ngrp + (unsigned long long)(mykey >> 2);
+  const float kscale = drop ? p.keep_scale : 1.0f;
+  const uint32_t gweyl = (uint32_t)(mykey >> 2) * 0x9E3779B9u;       // the lane's key group, as the generator's Weyl offset
 
   f32x16 dkacc[2], dvacc[2];
 #pragma unroll
@@ -732,14 +748,13 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
           for (int e = 0; e < 16; ++e) sacc[e] = (kflag ? masked_raw : sacc[e]) + sp_add;
         }
         uint32_t kmask[4] = {0u, 0u, 0u, 0u};
-        if (p.thr16) {
+        if (drop) {
           const int c = lane & 3;
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
-            // ctr = (arow0 + q) * ngrp + (key >> 2), q = qb * 64 + sb * 32 + 8 gq + 4 fg + c: the lane's part
-            // (arow0 + 4 fg + c) * ngrp + (key >> 2) is hoisted (ctr_lane), the rest is a small multiple of ngrp
-            const unsigned long long ctr = ctr_lane + (unsigned long long)(uint32_t)(qb * 64 + sb * 32 + 8 * gq) * (uint32_t)ngrp;
-            const u32x2 r = attn_bits_at(p.rng_key, ctr_base(ctr), 0u);
+            // row q = qb * 64 + sb * 32 + 8 gq + 4 fg + c of this (batch, head); group = the lane's keys
+            const RowKey rq = row_key(p.rng_key, (unsigned long long)(arow0 + qb * 64 + sb * 32 + 8 * gq + 4 * fg + c));
+            const u32x2 r = attn_bits_w(rq.rk + gweyl);
             uint32_t m4 = 0;
 #pragma unroll
             for (int f = 0; f < 4; ++f) m4 |= (keep_of(r, f, p.thr16) ? 1u : 0u) << f;
@@ -754,7 +769,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + ql);
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + 64 + ql);
           uint32_t km[4];
-          if (p.thr16) {                                           // quad_perm(i,i,i,i): value held by quad lane i
+          if (drop) {                                           // quad_perm(i,i,i,i): value held by quad lane i
             km[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)kmask[gq], 0x00, 0xf, 0xf, true);
             km[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)kmask[gq], 0x55, 0xf, 0xf, true);
             km[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)kmask[gq], 0xaa, 0xf, 0xf, true);
@@ -766,7 +781,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
             const float pr = fast_exp2(fmaf(sacc[e], sl2, -l4[i] * l2e));
             // dropped probability Pd = keep ? P / (1 - p) : 0 and dS = P (keep ? dPd / (1 - p) : 0  -  D)
             const float prs = pr * kscale;
-            const bool kept = !p.thr16 || ((km[i] >> kbit) & 1u);
+            const bool kept = !drop || ((km[i] >> kbit) & 1u);
             pd[e] = kept ? prs : 0.f;
             const float t = pr * d4[i];
             ds[e] = kept ? fmaf(prs, pacc[e], -t) : -t;
@@ -936,12 +951,18 @@ extern "C" int cogv_attention_fwd(const cogv_attn_desc* d, void* stream) {
   int sh = 3 * 2 * TILE;
   if ((rc = index_args(d, a))) return rc;
   if (a.kv_index) sh += ((a.s_k * 4 + 15) / 16) * 16;
+  // dense kernels: dropout on / off are separate instantiations (no wave-uniform branches and register copies at their
+  // joins inside the softmax); the gathered / sparse forms decide at run time
+  const bool drop = a.thr16 != 0u;
   if (a.kv_index) {
-    if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t, true>), grid, dim3(NT), sh, st, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, true>), grid, dim3(NT), sh, st, a);
+    if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t, true, -1>), grid, dim3(NT), sh, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, true, -1>), grid, dim3(NT), sh, st, a);
+  } else if (d->dtype == COGV_F16) {
+    if (drop) hipLaunchKernelGGL((attn_fwd_kernel<f16_t, false, 1>), grid, dim3(NT), sh, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<f16_t, false, 0>), grid, dim3(NT), sh, st, a);
   } else {
-    if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t, false>), grid, dim3(NT), sh, st, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, false>), grid, dim3(NT), sh, st, a);
+    if (drop) hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, false, 1>), grid, dim3(NT), sh, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, false, 0>), grid, dim3(NT), sh, st, a);
   }
   return cogv_check_launch();
 }
@@ -972,30 +993,31 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   static int attr_q = 0;
   static bool attr = false;
   if (!attr) {
-    set_smem(&attn_bwd_dkdv_kernel<f16_t, false>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false>, sh_k);
-    set_smem(&attn_bwd_dkdv_kernel<f16_t, true>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t, true>, sh_k);
-    set_smem(&attn_bwd_dq_kernel<f16_t, false>, 3 * 2 * TILE); set_smem(&attn_bwd_dq_kernel<bf16_t, false>, 3 * 2 * TILE);
+    set_smem(&attn_bwd_dkdv_kernel<f16_t, false, 0>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false, 0>, sh_k);
+    set_smem(&attn_bwd_dkdv_kernel<f16_t, false, 1>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false, 1>, sh_k);
+    set_smem(&attn_bwd_dkdv_kernel<f16_t, true, -1>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t, true, -1>, sh_k);
+    set_smem(&attn_bwd_dq_kernel<f16_t, false, 0>, 3 * 2 * TILE); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 0>, 3 * 2 * TILE);
+    set_smem(&attn_bwd_dq_kernel<f16_t, false, 1>, 3 * 2 * TILE); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 1>, 3 * 2 * TILE);
     attr = true;
   }
   if (a.kv_index && sh_q > attr_q) {
-    set_smem(&attn_bwd_dq_kernel<f16_t, true>, sh_q); set_smem(&attn_bwd_dq_kernel<bf16_t, true>, sh_q);
+    set_smem(&attn_bwd_dq_kernel<f16_t, true, -1>, sh_q); set_smem(&attn_bwd_dq_kernel<bf16_t, true, -1>, sh_q);
     attr_q = sh_q;
   }
+  const bool drop = a.thr16 != 0u;
+#define ATTN_BWD_LAUNCH(T_, IDX_, DROP_)                                                             \
+  do {                                                                                               \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T_, IDX_, DROP_>), gq, dim3(NT), sh_q, st, a);            \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T_, IDX_, DROP_>), gk, dim3(NT), sh_k, st, a);          \
+  } while (0)
   if (a.kv_index) {       // sparse training form: the instantiation with the gather and the slot attributes
-    if (d->dtype == COGV_F16) {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, true>), gq, dim3(NT), sh_q, st, a);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t, true>), gk, dim3(NT), sh_k, st, a);
-    } else {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, true>), gq, dim3(NT), sh_q, st, a);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t, true>), gk, dim3(NT), sh_k, st, a);
-    }
+    if (d->dtype == COGV_F16) ATTN_BWD_LAUNCH(f16_t, true, -1); else ATTN_BWD_LAUNCH(bf16_t, true, -1);
   } else if (d->dtype == COGV_F16) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, false>), gq, dim3(NT), sh_q, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t, false>), gk, dim3(NT), sh_k, st, a);
+    if (drop) ATTN_BWD_LAUNCH(f16_t, false, 1); else ATTN_BWD_LAUNCH(f16_t, false, 0);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, false>), gq, dim3(NT), sh_q, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t, false>), gk, dim3(NT), sh_k, st, a);
+    if (drop) ATTN_BWD_LAUNCH(bf16_t, false, 1); else ATTN_BWD_LAUNCH(bf16_t, false, 0);
   }
+#undef ATTN_BWD_LAUNCH
   return cogv_check_launch();
 }
 

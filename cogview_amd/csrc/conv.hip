@@ -229,23 +229,29 @@ __global__ __launch_bounds__(NT, 2) void conv_kernel(const ConvArgs p) {
   const RowCtx ctx = make_a_ctx(p, m0), bctx = make_b_ctx(W, p.K, n0, p.Cout);
   // two k-tiles in flight in registers: the loads of kt+2 are issued before the MFMAs of kt, the loads of kt+1
   // (issued one iteration earlier) are parked in LDS after them -- two MFMA phases between issue and use
+  // The loop body is branch-free around the asynchronous loads: every iteration issues eight loads (the tile index is
+  // clamped, so the last two iterations re-read the last tile from L2) and every iteration parks a tile in LDS (the
+  // last one parks a copy nobody reads).  With the waits inside `if (more tiles)` branches the compiler copied the
+  // in-flight destination registers at the joins BEFORE the s_waitcnt of one branch -- stale data for nk == 1.
   f32x4 ra[2][4], rb[2][4];
-  uint32_t ka[2] = {0u, 0u}, kb[2] = {0u, 0u};
+  uint32_t ka[2], kb[2];
   ka[0] = load_a<UT>(p, ctx, z, 0, ra[0]); kb[0] = load_b(bctx, 0, p.K, rb[0]);
-  if (nk > 1) { ka[1] = load_a<UT>(p, ctx, z, BK, ra[1]); kb[1] = load_b(bctx, BK, p.K, rb[1]); }
-  if (nk > 1) wait_loads<8>(ra[0], rb[0]); else wait_loads<0>(ra[0], rb[0]);
+  ka[1] = load_a<UT>(p, ctx, z, min(1, nk - 1) * BK, ra[1]); kb[1] = load_b(bctx, min(1, nk - 1) * BK, p.K, rb[1]);
+  wait_loads<8>(ra[0], rb[0]);
   store_tile(smem, ra[0], ka[0]); store_tile(smem + 16384, rb[0], kb[0]);
   __syncthreads();
   // one iteration: loads of tile kt+2 -> set `l`; MFMAs on LDS buffer `bo`; tile kt+1 (set `s`) -> the other buffer
   auto step = [&](int kt, auto lc, auto sc, int bo) {
     constexpr int l = decltype(lc)::value, sset = decltype(sc)::value;
-    if (!(EXP & 1) && kt + 2 < nk) { ka[l] = load_a<UT>(p, ctx, z, (kt + 2) * BK, ra[l]); kb[l] = load_b(bctx, (kt + 2) * BK, p.K, rb[l]); }
+    if (!(EXP & 1)) {
+      const int k2 = min(kt + 2, nk - 1) * BK;
+      ka[l] = load_a<UT>(p, ctx, z, k2, ra[l]); kb[l] = load_b(bctx, k2, p.K, rb[l]);
+    }
     __builtin_amdgcn_sched_barrier(0);     // nothing that needs tile kt+1's registers may move above the MFMAs
     mma_tile(smem + bo, smem + bo + 16384, wm, wn, fr, fg, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(EXP & 2) && kt + 1 < nk) {
-      if (EXP & 1) wait_loads<0>(ra[sset], rb[sset]);
-      else if (kt + 2 < nk) wait_loads<8>(ra[sset], rb[sset]); else wait_loads<0>(ra[sset], rb[sset]);    // tile kt+2 stays in flight
+    if (!(EXP & 2)) {
+      if (EXP & 1) wait_loads<0>(ra[sset], rb[sset]); else wait_loads<8>(ra[sset], rb[sset]);    // tile kt+2 stays in flight
       store_tile(smem + (bo ^ 32768), ra[sset], ka[sset]); store_tile(smem + (bo ^ 32768) + 16384, rb[sset], kb[sset]);
     }
     if (!(EXP & 4)) __syncthreads();
@@ -255,6 +261,7 @@ __global__ __launch_bounds__(NT, 2) void conv_kernel(const ConvArgs p) {
     step(kt, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0);
     if (kt + 1 < nk) step(kt + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, 32768);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped loads of the last iteration
   float* ct = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -340,9 +347,10 @@ __global__ __launch_bounds__(NT) void vq_argmin_kernel(const VqArgs p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
-      if (kt + 1 < nk) { ka = load_b(xctx, (kt + 1) * BK, p.D, ra); kb = load_b(ectx, (kt + 1) * BK, p.D, rb); }
+      { const int k1 = min(kt + 1, nk - 1) * BK; ka = load_b(xctx, k1, p.D, ra); kb = load_b(ectx, k1, p.D, rb); }   // branch-free, see conv_kernel
       mma_tile(smem + cur * 32768, smem + cur * 32768 + 16384, wm, wn, fr, fg, acc);
-      if (kt + 1 < nk) { wait_loads<0>(ra, rb); store_tile(smem + (cur ^ 1) * 32768, ra, ka); store_tile(smem + (cur ^ 1) * 32768 + 16384, rb, kb); }
+      wait_loads<0>(ra, rb);
+      store_tile(smem + (cur ^ 1) * 32768, ra, ka); store_tile(smem + (cur ^ 1) * 32768 + 16384, rb, kb);
       __syncthreads();
     }
 #pragma unroll

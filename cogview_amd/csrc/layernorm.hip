@@ -10,6 +10,8 @@
 #include "common.cuh"
 #include "cogview_hip.h"
 
+#include <cstdlib>
+
 namespace {
 
 struct LnFwdArgs {
@@ -266,16 +268,27 @@ template <typename T> void launch_bwd(const LnBwdArgs& a, int blocks, hipStream_
     default: FN<T, 8>(__VA_ARGS__); break;                 \
   }
 
-constexpr int LN_BWD_MAX_BLOCKS = 512;
 
 }  // namespace
 
-extern "C" int cogv_ln_bwd_num_blocks(int rows) {
+// Workgroups of the backward kernel: about 2.5 waves per SIMD measured best at both hot widths (h = 2560: 5 waves per
+// workgroup, 512 workgroups 101 us vs 111 us with 1024; h = 1024: 2 waves per workgroup, 1024 workgroups 44 us vs 59 us
+// with 512) -- more waves only add partial-sum rows for the reduce pass, fewer leave load latency exposed.
+static int ln_bwd_blocks(int rows, int h) {
+  static const int forced = [] { const char* e = getenv("COGV_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
+  const int nw = (h + 511) / 512;
+  int cap = forced > 0 ? (forced > 1024 ? 1024 : forced) : 2560 / nw;
+  if (forced <= 0) cap = cap < 256 ? 256 : (cap > 1024 ? 1024 : cap);
   int b = (rows + 3) / 4;                       // 4 rows per workgroup iteration
-  return b < 1 ? 1 : (b > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : b);
+  return b < 1 ? 1 : (b > cap ? cap : b);
+}
+// upper bound of the workgroup count over all widths (sizes the partial-sum workspace)
+extern "C" int cogv_ln_bwd_num_blocks(int rows) {
+  const int b = (rows + 3) / 4;
+  return b < 1 ? 1 : (b > 1024 ? 1024 : b);
 }
 extern "C" size_t cogv_ln_bwd_workspace_bytes(int rows, int h) {
-  return (size_t)cogv_ln_bwd_num_blocks(rows) * 3 * (size_t)h * sizeof(float);
+  return (size_t)cogv_ln_bwd_num_blocks(rows) * 3 * (size_t)h * sizeof(float);      // sized for the largest block count
 }
 
 extern "C" int cogv_sandwich_ln_fwd(int dtype, const void* x, const void* gamma, const void* beta, const void* residual,
@@ -310,7 +323,7 @@ extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, co
   a.seed = seed; a.stream_id = stream_id;
   a.thr16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
-  const int blocks = cogv_ln_bwd_num_blocks(rows);
+  const int blocks = ln_bwd_blocks(rows, h);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == COGV_F16) launch_bwd<f16_t>(a, blocks, st); else launch_bwd<bf16_t>(a, blocks, st);
   if (dgamma || dbeta || colsum) {

@@ -115,7 +115,7 @@ int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, const void* g
                          int accumulate_param_grads, int rows, int h, float dropout_p, uint64_t seed,
                          uint64_t stream_id, void* workspace, size_t workspace_bytes, void* stream);
 size_t cogv_ln_bwd_workspace_bytes(int rows, int h);
-int cogv_ln_bwd_num_blocks(int rows);
+int cogv_ln_bwd_num_blocks(int rows);   /* upper bound of the backward kernel's workgroup count (workspace sizing) */
 
 /* ------------------------------------------------------------------ attention (head dim 64)
  * replaces standard_attention, mpu/sparse_transformer.py:652-673, plus the head permutes at :112-120,:159.

@@ -347,16 +347,29 @@ def dropout_keep_mask(n_elements, p, seed, stream):
 
 
 def attention_keep_mask(b, heads, s_q, s_k, p, seed, stream):
-    """Scaled keep mask [b, heads, s_q, s_k] of the attention convention: one 64-bit group per
-    (attention row, 4 consecutive keys): ctr = row * ceil(s_k/4) + key//4, element i = key & 3."""
+    """Scaled keep mask [b, heads, s_q, s_k] of the attention convention (cogview_amd/csrc/attention.hip, "Attention
+    dropout bits"): one 64-bit draw per (attention row, 4 consecutive keys); the row is hashed once with PCG, the key
+    group enters as a Weyl step and each of the two words gets one multiply-xorshift round:
+        rk = pcg32((lo32(row) ^ key) + hi32(row) * 0x85EBCA6B);  x = rk + (key // 4) * 0x9E3779B9
+        x ^= x >> 15; x *= 0x2C1B3C6D; x ^= x >> 12                  (word 0)
+        y = (x ^ 0x68E31DA4) * 0x297A2D39; y ^= y >> 15              (word 1)
+    element i = key & 3 takes bits 16 (i & 1) .. +15 of word i >> 1; keep iff bits >= round(p * 65536)."""
     thr = _thr16(p)
-    ngrp = (s_k + 3) // 4
+    key = rng_key(seed, stream)
     rows = np.arange(b * heads * s_q, dtype=np.uint64).reshape(-1, 1)
     keys = np.arange(s_k, dtype=np.uint64).reshape(1, -1)
-    ctr = rows * np.uint64(ngrp) + (keys >> np.uint64(2))
-    ws = _words(rng_key(seed, stream), ctr, 2)
-    i = (keys & np.uint64(3)).astype(np.int64) + np.zeros_like(ctr, dtype=np.int64)
-    w = np.choose(i >> 1, ws)
+    lo = (rows & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (rows >> np.uint64(32)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        rk = _pcg32((lo ^ key) + hi * _U(0x85EBCA6B))
+        x = rk + (keys >> np.uint64(2)).astype(np.uint32) * _U(0x9E3779B9)
+        x = x ^ (x >> _U(15))
+        x = x * _U(0x2C1B3C6D)
+        x = x ^ (x >> _U(12))
+        y = (x ^ _U(0x68E31DA4)) * _U(0x297A2D39)
+        y = y ^ (y >> _U(15))
+    i = (keys & np.uint64(3)).astype(np.int64) + np.zeros(x.shape, dtype=np.int64)
+    w = np.where((i >> 1) == 0, x, y)
     bits = (w >> ((i & 1) * 16).astype(np.uint32)) & _U(0xFFFF)
     keep = (bits >= thr).astype(np.float32) * np.float32(65536.0 / (65536.0 - thr))
     return keep.reshape(b, heads, s_q, s_k)

@@ -104,3 +104,35 @@ def test_images_to_compact_binary_pipeline(tmp_path):
     ids = IdSpace()
     s = get_dataset_by_type("CompactBinaryDataset", path, SimpleNamespace(max_position_embeddings=1089))[1]
     assert s["text"][:4].tolist() == [ids['[ROI1]'], 8192 + 9, ids['[BASE]'], ids['[BOI1]']] and s["loss_mask"].sum() == 1 + 1 + 2 + 1024 + 1
+
+
+@pytest.mark.parametrize("kind,B,H,W,Cin,Cout", [
+    ("1x1", 2, 8, 8, 32, 16), ("1x1", 2, 8, 8, 64, 16), ("1x1", 4, 16, 16, 32, 32), ("1x1", 1, 4, 4, 16, 8),
+    ("1x1", 2, 8, 8, 96, 24), ("conv", 2, 16, 16, 4, 32), ("conv", 2, 16, 16, 8, 16), ("conv", 1, 8, 8, 32, 32),
+    ("convT", 2, 8, 8, 16, 32), ("convT", 1, 4, 4, 8, 8), ("convT", 2, 8, 8, 32, 16)])
+def test_conv_kernel_short_contractions(kind, B, H, W, Cin, Cout):
+    """The implicit-GEMM kernel at contraction lengths of one, two and three 32-deep k-tiles (and k-tiles that straddle
+    taps): the software pipeline keeps two tiles of loads in flight, so its prologue / drain paths are exactly what a
+    1 x 1 convolution with 32 input channels runs.  Reference: the oracle's definition (F.conv2d / F.conv_transpose2d
+    on the CPU, vqvae/vqvae_zc.py:121-129,172-192)."""
+    import torch.nn.functional as F
+    from cogview_amd import _lib as L
+    from cogview_amd.vqvae.vqvae_zc import _conv, pack_conv_weight, pack_convt_weight
+    g = torch.Generator().manual_seed(B * 1000 + Cin * 10 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    bias = torch.randn(Cout, generator=g)
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    if kind == "1x1":
+        w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1
+        ref = F.conv2d(x, w, bias)
+        y = _conv(L.CONV_1X1, xh, pack_conv_weight(w.cuda()), bias.cuda(), Cout, False)
+    elif kind == "conv":
+        w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1
+        ref = F.relu(F.conv2d(x, w, bias, stride=2, padding=1))
+        y = _conv(L.CONV_4X4_S2, xh, pack_conv_weight(w.cuda()), bias.cuda(), Cout, True)
+    else:
+        w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.1
+        ref = F.relu(F.conv_transpose2d(x, w, bias, stride=2, padding=1))
+        y = _conv(L.CONVT_4X4_S2, xh, pack_convt_weight(w.cuda()), bias.cuda(), Cout, True)
+    for _ in range(2):                       # twice: timing-dependent races show up as run-to-run differences
+        assert rel(y.permute(0, 3, 1, 2), ref) < 1e-5
