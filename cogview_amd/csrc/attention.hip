@@ -41,7 +41,7 @@ constexpr int TILE = 8192;      // one 64 x 64 16-bit tile
 struct AttnArgs {
   const void* q; const void* k; const void* v; void* o;        // forward
   const void* dout; void* dq; void* dk; void* dv;              // backward
-  float* lse; float* dvec;                                     // [b][H][s_q]
+  float* lse; float* dvec;                                     // [b][H][s_q]; dvec: [2][b][H][s_q] (D, dropout row keys)
   float* colsum_ws;                                            // optional [B * nblk][3 * H * 64]: sums of dq | dk | dv
   const int* kv_index; long long kv_index_bs;                  // optional: key slot j reads K/V row kv_index[b][j] & 0x7fffffff
   // sparse TRAINING form in slot space (sp_w > 0): one index row per query block g = q / sp_w (kv_index_gs apart);
@@ -504,7 +504,12 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
       for (int e = 0; e < 8; ++e) dv = fmaf((float)dof[t][e], (float)of[e], dv);
     }
     dv += __shfl_xor(dv, 32, 64);
-    if (qvalid && fg == 0) p.dvec[arow] = dv;
+    if (qvalid && fg == 0) {
+      p.dvec[arow] = dv;
+      // second plane of the workspace: the row's dropout key, so the dK/dV kernel (lane = key, 16 query rows per lane)
+      // reads it instead of re-hashing the row for every draw
+      reinterpret_cast<uint32_t*>(p.dvec)[(long long)p.B * p.H * p.s_q + arow] = cb.rk;
+    }
   }
   const float sl2 = p.scale * 1.4426950408889634f;
   const float masked_raw = MASKED / p.scale;
@@ -641,7 +646,7 @@ template <typename T, bool IDX, int DROP>
 __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) {
   const bool drop = DROP < 0 ? (p.thr16 != 0u) : (DROP != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = 2 * TILE + 512, LPT = 6;
+  constexpr int STAGE = 2 * TILE + 768, LPT = 7;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 31, fg = lane >> 5;
@@ -660,6 +665,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   const T* DO = reinterpret_cast<const T*>(p.dout) + b * p.do_bs + head * HD;
   const float* LSE = p.lse + ((long long)b * p.H + head) * p.s_q;
   const float* DV = p.dvec + ((long long)b * p.H + head) * p.s_q;
+  const float* RK = DV + (long long)p.B * p.H * p.s_q;            // row keys of the dropout generator (written by the dQ kernel)
   const int mykey = k0w + fr;
   const bool kvalid = mykey < p.s_k;
   const bool wave_active = k0w < p.s_k;
@@ -702,6 +708,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
     dma_tile<T>(DO, p.do_rs, qb * 64, p.s_q, base + TILE, wave, lane);
     dma_stat(LSE, qb * 64, p.s_q, base + 2 * TILE, lane);
     dma_stat(DV, qb * 64, p.s_q, base + 2 * TILE + 256, lane);
+    dma_stat(RK, qb * 64, p.s_q, base + 2 * TILE + 512, lane);
   };
   if (qb0 < nqb) { issue(qb0, 0); issue(min(qb0 + 1, nqb - 1), 1); }
   int st = 0;
@@ -752,9 +759,10 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
           const int c = lane & 3;
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
-            // row q = qb * 64 + sb * 32 + 8 gq + 4 fg + c of this (batch, head); group = the lane's keys
-            const RowKey rq = row_key(p.rng_key, (unsigned long long)(arow0 + qb * 64 + sb * 32 + 8 * gq + 4 * fg + c));
-            const u32x2 r = attn_bits_w(rq.rk + gweyl);
+            // row q = qb * 64 + sb * 32 + 8 gq + 4 fg + c of this (batch, head): its key comes from the stage's third
+            // statistics row; group = the lane's keys
+            const uint32_t rkq = reinterpret_cast<const uint32_t*>(stat)[128 + sb * 32 + 8 * gq + 4 * fg + c];
+            const u32x2 r = attn_bits_w(rkq + gweyl);
             uint32_t m4 = 0;
 #pragma unroll
             for (int f = 0; f < 4; ++f) m4 |= (keep_of(r, f, p.thr16) ? 1u : 0u) << f;
@@ -779,12 +787,13 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
           for (int i = 0; i < 4; ++i) {
             const int e = 4 * gq + i;
             const float pr = fast_exp2(fmaf(sacc[e], sl2, -l4[i] * l2e));
-            // dropped probability Pd = keep ? P / (1 - p) : 0 and dS = P (keep ? dPd / (1 - p) : 0  -  D)
-            const float prs = pr * kscale;
-            const bool kept = !drop || ((km[i] >> kbit) & 1u);
-            pd[e] = kept ? prs : 0.f;
-            const float t = pr * d4[i];
-            ds[e] = kept ? fmaf(prs, pacc[e], -t) : -t;
+            // dropped probability Pd = keep ? P / (1 - p) : 0 and dS = Pd dPd - P D.  The keep bit becomes the
+            // multiplier 1/(1-p) or 0 by sign-extending it over the float's bit pattern (v_bfe_i32 + v_and): two
+            // instructions where compare + two selects (on Pd and dS) took five
+            float keepf = kscale;
+            if (drop) keepf = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)km[i], (uint32_t)kbit, 1u) & __float_as_uint(kscale));
+            pd[e] = pr * keepf;
+            ds[e] = fmaf(pd[e], pacc[e], -(pr * d4[i]));
           }
         }
         if (!kvalid) {
@@ -988,7 +997,7 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   // the plane stride and grid z runs over B * (s_q / sparse_window) planes
   const int planes = a.sp_w > 0 ? a.B * (a.s_q / a.sp_w) : a.B;
   dim3 gq((a.s_q + 127) / 128, a.H, a.B), gk((a.s_k + 127) / 128, a.H, planes);
-  const int sh_q = 3 * 2 * TILE + (a.kv_index ? ((a.s_k * 4 + 15) / 16) * 16 : 0), sh_k = 3 * (2 * TILE + 512);
+  const int sh_q = 3 * 2 * TILE + (a.kv_index ? ((a.s_k * 4 + 15) / 16) * 16 : 0), sh_k = 3 * (2 * TILE + 768);
   if (sh_q > 160 * 1024) return COGV_ERR_UNSUPPORTED;
   static int attr_q = 0;
   static bool attr = false;

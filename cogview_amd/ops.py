@@ -425,7 +425,7 @@ def sparse_attention_bwd(dout, q, k, v, o, lse, kv_index, sparse, pivot_inv, tim
     dq = torch.empty((b, s, H, 64), dtype=q.dtype, device=q.device)
     dks = torch.empty((b * G, n_slots, H, 64), dtype=q.dtype, device=q.device)
     dvs = torch.empty_like(dks)
-    dvec = torch.empty((b, H, s), dtype=torch.float32, device=q.device)
+    dvec = torch.empty((2, b, H, s), dtype=torch.float32, device=q.device)
     d = _attn_desc(q, k, v, o, 0, dropout)
     _sparse_desc(d, kv_index, sparse, b, s)
     d.lse, d.dvec = lse.data_ptr(), dvec.data_ptr()
@@ -455,7 +455,7 @@ def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, 
         dk = torch.empty((b, k.shape[1], H, 64), dtype=q.dtype, device=q.device)
     if dv is None:
         dv = torch.empty((b, k.shape[1], H, 64), dtype=q.dtype, device=q.device)
-    dvec = torch.empty((b, H, s_q), dtype=torch.float32, device=q.device)
+    dvec = torch.empty((2, b, H, s_q), dtype=torch.float32, device=q.device)
     d = _attn_desc(q, k, v, o, sep, dropout)
     d.lse, d.dvec = lse.data_ptr(), dvec.data_ptr()
     d.dout, d.dq, d.dk, d.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()

@@ -121,7 +121,8 @@ int cogv_ln_bwd_num_blocks(int rows);   /* upper bound of the backward kernel's 
  * replaces standard_attention, mpu/sparse_transformer.py:652-673, plus the head permutes at :112-120,:159.
  * Tensor element (b, row, head, d) lives at base + b*bs + row*rs + head*64 + d.
  * Mask: key j visible to query i iff j <= i + (s_k - s_q) or j < sep + (s_k - s_q) (sep = 0: causal);
- * masked scores are exactly -10000 as in the reference.  lse/dvec: [B][H][s_q] fp32.
+ * masked scores are exactly -10000 as in the reference.  lse: [B][H][s_q] fp32; dvec: backward workspace
+ * [2][B][H][s_q] 4-byte words (softmax-backward row term D, then the per-row dropout keys), written by the dQ kernel.
  */
 typedef struct cogv_attn_desc {
   int dtype; int B, H, s_q, s_k, head_dim; int sep;
