@@ -55,6 +55,23 @@ struct AttnArgs {
   uint32_t thr16; float keep_scale; uint32_t rng_key;
 };
 
+// Workgroup -> (block along the sequence, head, batch / plane).  The grid is ONE-dimensional and XCD-aware: hardware deals
+// consecutive workgroup ids to the 8 XCDs round-robin and each XCD has its own L2, so with a plain (blocks, H, B) grid the
+// sequence blocks of one (batch, head) -- which all read the same K / V (forward, dQ) or Q / dO (dK/dV) tiles -- sat on
+// 8 different XCDs and every tile was fetched through the fabric up to 8 times.  Here XCD x owns the (batch, head) units
+// u = x (mod 8) and walks the sequence blocks of one unit consecutively (heaviest block of the causal triangle first).
+struct BlockId { int bx, head, z; bool ok; };
+__device__ __forceinline__ BlockId xcd_block_id(int nx, int H, int Z, bool heavy_last) {
+  const int L = blockIdx.x, x = L & 7, j = L >> 3;
+  const int ul = j / nx, k = j - ul * nx;
+  const int u = ul * 8 + x;
+  BlockId id;
+  id.ok = u < H * Z;
+  id.z = u / H; id.head = u - id.z * H;
+  id.bx = heavy_last ? nx - 1 - k : k;
+  return id;
+}
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
@@ -269,8 +286,11 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 31, fg = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * 128, q0w = q0 + wave * 32;
+  const int nblk_x = (p.s_q + 127) >> 7;
+  const BlockId bid = xcd_block_id(nblk_x, p.H, p.B, true);
+  if (!bid.ok) return;
+  const int b = bid.z, head = bid.head;
+  const int q0 = bid.bx * 128, q0w = q0 + wave * 32;
   // IDX (compile time): gathered keys / the sparse training form; the dense instantiation carries none of that code
   const bool spw = IDX && p.sp_w > 0;               // sparse training form (slot space)
   const int gblk = spw ? q0 / p.sp_w : 0;
@@ -469,8 +489,11 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 31, fg = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * 128, q0w = q0 + wave * 32;
+  const int nblk_x = (p.s_q + 127) >> 7;
+  const BlockId bid = xcd_block_id(nblk_x, p.H, p.B, true);
+  if (!bid.ok) return;
+  const int b = bid.z, head = bid.head;
+  const int q0 = bid.bx * 128, q0w = q0 + wave * 32;
   const bool spw = IDX && p.sp_w > 0;               // sparse training form (slot space), see attn_fwd_kernel
   const int gblk = spw ? q0 / p.sp_w : 0;
   const int off = spw ? (p.s_k - p.sp_w - gblk * p.sp_w) : (p.s_k - p.s_q);
@@ -631,7 +654,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   }
   if (p.colsum_ws) {     // bias gradient of the QKV projection, q section
     __syncthreads();     // every wave is done with the ring
-    float* dst = p.colsum_ws + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)(3 * p.H * HD) + head * HD;
+    float* dst = p.colsum_ws + ((size_t)b * nblk_x + bid.bx) * (size_t)(3 * p.H * HD) + head * HD;
     tile_colsum(rq, reinterpret_cast<float*>(smem), dst, lane, wave);
   }
 }
@@ -654,9 +677,12 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   // dK / dV go to slot-space buffers [z][slot] which cogv_sparse_slot_reduce folds back onto the keys
   const bool spw = IDX && p.sp_w > 0;
   const int nblk = spw ? p.s_q / p.sp_w : 1;
-  const int zb = blockIdx.z, head = blockIdx.y;
+  const int nblk_x = (p.s_k + 127) >> 7;
+  const BlockId bid = xcd_block_id(nblk_x, p.H, p.B * nblk, false);       // key block 0 has the most queries: first
+  if (!bid.ok) return;
+  const int zb = bid.z, head = bid.head;
   const int b = spw ? zb / nblk : zb, gblk = spw ? zb - b * nblk : 0;
-  const int k0 = blockIdx.x * 128, k0w = k0 + wave * 32;
+  const int k0 = bid.bx * 128, k0w = k0 + wave * 32;
   const int off = spw ? (p.s_k - p.sp_w - gblk * p.sp_w) : (p.s_k - p.s_q);
   const int qlo = gblk * p.sp_w, qhi = spw ? qlo + p.sp_w : p.s_q;
   const T* Q = reinterpret_cast<const T*>(p.q) + b * p.q_bs + head * HD;
@@ -850,7 +876,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   }
   if (p.colsum_ws) {     // bias gradient of the QKV projection, k and v sections
     __syncthreads();
-    float* dst = p.colsum_ws + ((size_t)zb * gridDim.x + blockIdx.x) * (size_t)(3 * p.H * HD) + (size_t)p.H * HD + head * HD;
+    float* dst = p.colsum_ws + ((size_t)zb * nblk_x + bid.bx) * (size_t)(3 * p.H * HD) + (size_t)p.H * HD + head * HD;
     tile_colsum(rk, reinterpret_cast<float*>(smem), dst, lane, wave);
     tile_colsum(rv, reinterpret_cast<float*>(smem), dst + (size_t)p.H * HD, lane, wave);
   }
@@ -956,7 +982,8 @@ extern "C" int cogv_attention_fwd(const cogv_attn_desc* d, void* stream) {
   if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs) & 7) return COGV_ERR_ARG;
   if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs) & 7) return COGV_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid((a.s_q + 127) / 128, a.H, a.B);
+  // one-dimensional XCD-aware grid (xcd_block_id): 8 x ceil(units / 8) x blocks, units = H * B
+  dim3 grid(8u * (unsigned)((a.H * a.B + 7) / 8) * (unsigned)((a.s_q + 127) / 128));
   int sh = 3 * 2 * TILE;
   if ((rc = index_args(d, a))) return rc;
   if (a.kv_index) sh += ((a.s_k * 4 + 15) / 16) * 16;
@@ -996,7 +1023,8 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   // sparse training form: dK / dV are slot-space buffers, one [s_k] plane per (batch, query block): dk_bs / dv_bs is
   // the plane stride and grid z runs over B * (s_q / sparse_window) planes
   const int planes = a.sp_w > 0 ? a.B * (a.s_q / a.sp_w) : a.B;
-  dim3 gq((a.s_q + 127) / 128, a.H, a.B), gk((a.s_k + 127) / 128, a.H, planes);
+  dim3 gq(8u * (unsigned)((a.H * a.B + 7) / 8) * (unsigned)((a.s_q + 127) / 128));
+  dim3 gk(8u * (unsigned)((a.H * planes + 7) / 8) * (unsigned)((a.s_k + 127) / 128));
   const int sh_q = 3 * 2 * TILE + (a.kv_index ? ((a.s_k * 4 + 15) / 16) * 16 : 0), sh_k = 3 * (2 * TILE + 768);
   if (sh_q > 160 * 1024) return COGV_ERR_UNSUPPORTED;
   static int attr_q = 0;
