@@ -56,6 +56,18 @@ class AttnDesc(C.Structure):
     ]
 
 
+class AttnDecodeDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("capacity", C.c_int), ("head_dim", C.c_int),
+        ("scale", C.c_float),
+        ("qkv", C.c_void_p), ("qkv_bs", C.c_longlong),
+        ("cache", C.c_void_p), ("cache_bs", C.c_longlong), ("cache_rs", C.c_int),
+        ("out", C.c_void_p), ("out_bs", C.c_longlong),
+        ("pos", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 class AdamDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int),
@@ -101,6 +113,8 @@ SIGNATURES = {
     "cogv_ln_bwd_num_blocks": (_i, [_i]),
     "cogv_attention_fwd": (_i, [C.POINTER(AttnDesc), _vp]),
     "cogv_attention_bwd": (_i, [C.POINTER(AttnDesc), _vp]),
+    "cogv_attention_decode": (_i, [C.POINTER(AttnDecodeDesc), _vp]),
+    "cogv_attention_decode_workspace_bytes": (_sz, [_i, _i, _i]),
     "cogv_sparse_slot_reduce": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cogv_embedding_fwd": (_i, [_i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _f, _u64, _u64, _vp]),
     "cogv_embedding_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _i, _f, _u64, _u64, _vp]),

@@ -882,6 +882,103 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   }
 }
 
+// =====================================================================================================
+// Decode step: ONE query token per batch row against a fixed-capacity key/value cache (generation/sampling.py:139-148,
+// one model call per generated token).  The 128-query tile kernels above spend a whole workgroup per (batch, head) on
+// one row (40 workgroups on 256 CUs, 34 us per layer at 1152 slots); this kernel splits the KEYS: grid (capacity / 128,
+// H, B), 8 lanes per key (16 bytes of the 128-byte row each: coalesced), a partial (max, sum, output) per split; a
+// second small launch combines the partials in split order (deterministic).  The new token's key / value come straight from the QKV GEMM's
+// output row and are written into the cache slot *pos by the split that owns it: the cat + index_copy_ launches of the
+// generic cache append disappear.  Valid slots are [0, *pos] (device data: no launch parameter depends on the length).
+struct DecodeArgs {
+  const void* qkv; void* cache; void* out; const long long* pos; float* ws; int* tickets;
+  long long qkv_bs, cache_bs, out_bs; int cache_rs;
+  int B, H, cap, nsplit; float scale_l2e;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs p) {
+  __shared__ float red_o[32][64];
+  __shared__ float red_m[4], red_l[32];
+  const int t = threadIdx.x, dch = t & 7, kg = t >> 3, lane = t & 63, wave = t >> 6;
+  const int split = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int hp = p.H * HD;
+  const long long pos = *p.pos;
+  const T* qrow = reinterpret_cast<const T*>(p.qkv) + b * p.qkv_bs + head * HD + dch * 8;
+  float q8[8], kn[8], vn[8];
+  unpack8<T>(*reinterpret_cast<const u32x4*>(qrow), q8);
+  const u32x4 knew = *reinterpret_cast<const u32x4*>(qrow + hp), vnew = *reinterpret_cast<const u32x4*>(qrow + 2 * hp);
+  T* crow = reinterpret_cast<T*>(p.cache) + b * p.cache_bs + head * HD + dch * 8;
+  float sc[4]; u32x4 v8[4];
+  float m_loc = -INFINITY;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const long long key = (long long)split * 128 + ps * 32 + kg;
+    const bool valid = key <= pos && key < p.cap;
+    u32x4 k8 = knew; v8[ps] = vnew;
+    if (valid && key != pos) {
+      k8 = *reinterpret_cast<const u32x4*>(crow + key * p.cache_rs);
+      v8[ps] = *reinterpret_cast<const u32x4*>(crow + key * p.cache_rs + hp);
+    } else if (valid) {                      // the new token's own slot: store it for the steps to come
+      *reinterpret_cast<u32x4*>(crow + key * p.cache_rs) = knew;
+      *reinterpret_cast<u32x4*>(crow + key * p.cache_rs + hp) = vnew;
+    }
+    float kf[8]; unpack8<T>(k8, kf);
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d = fmaf(q8[e], kf[e], d);
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);     // the key's 8 lanes
+    sc[ps] = valid ? d * p.scale_l2e : -INFINITY;
+    m_loc = fmaxf(m_loc, sc[ps]);
+  }
+  m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 8, 64)); m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 16, 64)); m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));
+  if (lane == 0) red_m[wave] = m_loc;
+  __syncthreads();
+  const float m = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+  float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, l = 0.f;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const float pr = (sc[ps] == -INFINITY) ? 0.f : fast_exp2(sc[ps] - m);
+    float vf[8]; unpack8<T>(v8[ps], vf);
+    l += pr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = fmaf(pr, vf[e], o8[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red_o[kg][dch * 8 + e] = o8[e];
+  if (dch == 0) red_l[kg] = l;
+  __syncthreads();
+  float* part = p.ws + (((size_t)b * p.H + head) * p.nsplit + split) * 66;
+  if (t < 64) {
+    float o = 0.f;
+#pragma unroll 8
+    for (int g = 0; g < 32; ++g) o += red_o[g][t];
+    part[2 + t] = o;
+    if (t == 0) {
+      float ls = 0.f;
+      for (int g = 0; g < 32; ++g) ls += red_l[g];
+      part[0] = m; part[1] = ls;
+    }
+  }
+}
+// second launch of a decode step: combine the splits' partial (max, sum, output) in split order.  (A device-scope
+// release fence + arrival ticket inside the first kernel costs an L2 write-back per workgroup on this part -- measured
+// 50 us per layer; the kernel boundary publishes the partials for free.)
+template <typename T>
+__global__ __launch_bounds__(64) void attn_decode_combine_kernel(const DecodeArgs p) {
+  const int t = threadIdx.x, head = blockIdx.x, b = blockIdx.y;
+  const float* base = p.ws + ((size_t)b * p.H + head) * p.nsplit * 66;
+  float M = -INFINITY;
+  for (int i = 0; i < p.nsplit; ++i) M = fmaxf(M, base[i * 66]);
+  float L = 0.f, O = 0.f;
+  for (int i = 0; i < p.nsplit; ++i) {
+    const float mi = base[i * 66];
+    const float w = (mi == -INFINITY) ? 0.f : fast_exp2(mi - M);
+    L = fmaf(base[i * 66 + 1], w, L);
+    O = fmaf(base[i * 66 + 2 + t], w, O);
+  }
+  reinterpret_cast<T*>(p.out)[b * p.out_bs + head * HD + t] = HT<T>::from_f(O / L);
+}
+
 // Sparse training form: fold the slot-space gradients [B][G][n_slots][H*64] back onto the keys.  Key r is a window
 // slot of the blocks g = r/w ... r/w + times - 1 (slot n_piv + r - (g - times + 1) w) and, when it is pivot j
 // (pivot_inv[b][r] = j, else -1), slot j of every block whose window starts after it (g >= r/w + times; the blocks
@@ -1055,6 +1152,37 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
     if (drop) ATTN_BWD_LAUNCH(bf16_t, false, 1); else ATTN_BWD_LAUNCH(bf16_t, false, 0);
   }
 #undef ATTN_BWD_LAUNCH
+  return cogv_check_launch();
+}
+
+extern "C" size_t cogv_attention_decode_workspace_bytes(int B, int H, int capacity) {
+  if (B <= 0 || H <= 0 || capacity <= 0) return 0;
+  const size_t nsplit = (size_t)(capacity + 127) / 128;
+  return (size_t)B * H * nsplit * 66 * sizeof(float);
+}
+
+extern "C" int cogv_attention_decode(const cogv_attn_decode_desc* d, void* stream) {
+  if (!d || (d->dtype != COGV_F16 && d->dtype != COGV_BF16)) return COGV_ERR_UNSUPPORTED;
+  if (d->B <= 0 || d->H <= 0 || d->capacity <= 0 || d->head_dim != HD) return COGV_ERR_ARG;
+  if (!d->qkv || !d->cache || !d->out || !d->pos || !d->workspace) return COGV_ERR_ARG;
+  if (!aligned16(d->qkv) || !aligned16(d->cache) || ((d->qkv_bs | d->cache_bs | d->cache_rs) & 7)) return COGV_ERR_ARG;
+  if (d->workspace_bytes < cogv_attention_decode_workspace_bytes(d->B, d->H, d->capacity) || ((uintptr_t)d->workspace & 15)) return COGV_ERR_ARG;
+  DecodeArgs a;
+  a.qkv = d->qkv; a.cache = d->cache; a.out = d->out; a.pos = d->pos;
+  a.tickets = nullptr;
+  a.ws = reinterpret_cast<float*>(d->workspace);
+  a.qkv_bs = d->qkv_bs; a.cache_bs = d->cache_bs; a.out_bs = d->out_bs; a.cache_rs = d->cache_rs;
+  a.B = d->B; a.H = d->H; a.cap = d->capacity; a.nsplit = (d->capacity + 127) / 128;
+  a.scale_l2e = d->scale * 1.4426950408889634f;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(a.nsplit, a.H, a.B);
+  if (d->dtype == COGV_F16) {
+    hipLaunchKernelGGL((attn_decode_kernel<f16_t>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_decode_combine_kernel<f16_t>), dim3(a.H, a.B), dim3(64), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_decode_combine_kernel<bf16_t>), dim3(a.H, a.B), dim3(64), 0, st, a);
+  }
   return cogv_check_launch();
 }
 

@@ -450,6 +450,10 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
     v = qkv[:, :, 2 * hp:].view(b, s, npp, 64)
     if kv_slot is None:
         att, lse = ops.attention_fwd(q, k, v, sep=sep, dropout=d_attn)
+    elif s == 1 and getattr(kv_slot, "pos_index", None) is not None:
+        # captured decode step (StaticKVSlot): keys split over workgroups, cache append fused, length read on the device
+        att, lse = ops.attention_decode(qkv, kv_slot.cache, kv_slot.pos_index, npp).view(b, 1, npp, 64), None
+        kv_slot.out = kv_slot.cache
     else:
         _, kc, vc = kv_slot.append(qkv[:, :, hp:2 * hp], qkv[:, :, 2 * hp:])
         kc, vc = kc.view(b, kc.shape[1], npp, 64), vc.view(b, vc.shape[1], npp, 64)

@@ -402,6 +402,37 @@ def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None):
     return o, lse
 
 
+_DECODE_WS = {}
+
+
+def attention_decode(qkv, cache, pos_index, heads):
+    """One decode step's attention (cogv_attention_decode): qkv [b, 1, 3 * heads * 64] (q | k | v of the new token),
+    cache [b, capacity, 2 * heads * 64] (keys | values), pos_index: device int64 scalar = slot of the new token (slots
+    [0, pos] are attended; the new key / value are written into slot pos by the kernel).  Returns out [b, 1, heads * 64].
+    The workspace (partial results of the key splits) is kept per (device, shape): fixed addresses, so the call is
+    replayable inside a captured graph."""
+    _need_gpu(qkv, cache, pos_index)
+    b, cap = cache.shape[0], cache.shape[1]
+    hp = heads * 64
+    assert qkv.shape[0] == b and qkv.shape[-1] == 3 * hp and qkv.numel() == b * 3 * hp and cache.shape[2] == 2 * hp
+    assert qkv.stride(-1) == 1 and cache.stride(2) == 1 and pos_index.dtype == torch.int64
+    lib = L.lib()
+    key = (qkv.device.index, b, heads, cap)
+    ws = _DECODE_WS.get(key)
+    if ws is None:
+        ws = _DECODE_WS[key] = torch.zeros(lib.cogv_attention_decode_workspace_bytes(b, heads, cap), dtype=torch.uint8, device=qkv.device)
+    out = torch.empty((b, 1, hp), dtype=qkv.dtype, device=qkv.device)
+    d = L.AttnDecodeDesc()
+    d.dtype, d.B, d.H, d.capacity, d.head_dim, d.scale = dt_code(qkv), b, heads, cap, 64, 0.125
+    d.qkv, d.qkv_bs = qkv.data_ptr(), qkv.stride(0)
+    d.cache, d.cache_bs, d.cache_rs = cache.data_ptr(), cache.stride(0), cache.stride(1)
+    d.out, d.out_bs = out.data_ptr(), out.stride(0)
+    d.pos = pos_index.data_ptr()
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(lib.cogv_attention_decode(C.byref(d), _stream()), "cogv_attention_decode")
+    return out
+
+
 def _sparse_desc(d, kv_index, sparse, b, s_q):
     """Sparse training form in slot space: kv_index [b, s_q // w, n_slots] int32 (bit 31 = masked slot),
     sparse = (w, n_pivots, pivot_bias)."""

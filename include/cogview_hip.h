@@ -153,6 +153,25 @@ typedef struct cogv_attn_desc {
 } cogv_attn_desc;
 int cogv_attention_fwd(const cogv_attn_desc* d, void* stream);
 int cogv_attention_bwd(const cogv_attn_desc* d, void* stream);
+/* Decode step (generation/sampling.py:139-148: one model call per generated token; mems mpu/sparse_transformer.py:526-546):
+ * ONE query token per batch row against a fixed-capacity key/value cache.  qkv: the QKV projection of the new token,
+ * [B][3 * H * 64] = q | k | v (qkv_bs elements between batch rows); cache: [B][capacity][2 * H * 64] keys | values
+ * (cache_bs / cache_rs: batch / slot strides in elements).  *pos (device int64) = slot of the new token = number of
+ * slots already valid: the kernel attends slots [0, *pos] -- the new token's key / value are taken from qkv and WRITTEN
+ * into slot *pos -- so no launch parameter depends on the length (HIP-graph replay).  out: [B][H * 64] (out_bs elements
+ * between rows).  Keys are split over workgroups (capacity / 128 per head); a second launch combines the partial softmax
+ * results in split order.  workspace: cogv_attention_decode_workspace_bytes() bytes (partials; no initialisation needed). */
+typedef struct cogv_attn_decode_desc {
+  int dtype; int B, H, capacity, head_dim;
+  float scale;                       /* 1/sqrt(head_dim) */
+  const void* qkv; long long qkv_bs;
+  void* cache; long long cache_bs; int cache_rs;
+  void* out; long long out_bs;
+  const long long* pos;
+  void* workspace; size_t workspace_bytes;
+} cogv_attn_decode_desc;
+size_t cogv_attention_decode_workspace_bytes(int B, int H, int capacity);
+int cogv_attention_decode(const cogv_attn_decode_desc* d, void* stream);
 /* Sparse training form, backward: cogv_attention_bwd with sparse_window > 0 writes dq as usual, but dk / dv are
  * SLOT-SPACE buffers [B * s_q / sparse_window][s_k slots][H][64] (dk_bs / dv_bs = the stride of one (batch, query block)
  * plane) -- the gradient of each gathered copy of a key, the same quantity the reference's autograd holds for pivot_k

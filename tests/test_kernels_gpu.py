@@ -596,3 +596,30 @@ def test_sparse_attention_training_form_dropout_adjoint(ops):
     # the dropout-free gradient differs (sanity: the identity above is not trivially true)
     _, _, dv0 = ops.sparse_attention_bwd(dout, q, k, v, o0, lse, tab, sp, inv, times)
     assert rel(dv0, dv) > 0.1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,H,cap,pos", [(1, 2, 128, 0), (2, 3, 300, 127), (2, 3, 300, 128), (1, 40, 1152, 1024), (3, 2, 256, 255)])
+def test_attention_decode_step(ops, dtype, b, H, cap, pos):
+    """cogv_attention_decode: one query token against a fixed-capacity cache (keys split over workgroups, last arriver
+    combines, cache append fused) == the oracle's standard_attention (mpu/sparse_transformer.py:652-673) of that query
+    over slots [0, pos] with the new token's key / value in slot pos; the cache afterwards holds them; a second launch
+    (re-armed tickets, as in a graph replay) gives the same bits."""
+    g = torch.Generator().manual_seed(cap + pos)
+    hp = H * 64
+    cache = rnd((b, cap, 2 * hp), dtype, g)
+    qkv = rnd((b, 1, 3 * hp), dtype, g)
+    cache_d, qkv_d = dev(cache.clone()), dev(qkv)
+    pos_d = torch.tensor([pos], dtype=torch.int64, device="cuda")
+    out = ops.attention_decode(qkv_d, cache_d, pos_d, H)
+    want_cache = cache.clone()
+    want_cache[:, pos, :hp] = qkv[:, 0, hp:2 * hp]
+    want_cache[:, pos, hp:] = qkv[:, 0, 2 * hp:]
+    assert torch.equal(cache_d.cpu(), want_cache), "the new key / value must land in slot pos and nothing else may change"
+    q = qkv[:, :, :hp].float().view(b, 1, H, 64).permute(0, 2, 1, 3)
+    k = want_cache[:, :pos + 1, :hp].float().view(b, pos + 1, H, 64).permute(0, 2, 1, 3)
+    v = want_cache[:, :pos + 1, hp:].float().view(b, pos + 1, H, 64).permute(0, 2, 1, 3)
+    ref = O.standard_attention(q, k, v, torch.ones(1, 1, 1, pos + 1)).permute(0, 2, 1, 3).reshape(b, 1, hp)
+    assert rel(out, ref) < TOL[dtype]
+    again = ops.attention_decode(qkv_d, cache_d, pos_d, H)
+    assert torch.equal(out, again)
