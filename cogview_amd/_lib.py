@@ -56,6 +56,15 @@ class AttnDesc(C.Structure):
     ]
 
 
+class LnPrologue(C.Structure):
+    _fields_ = [
+        ("z", C.c_void_p), ("z_absmax", C.c_void_p),
+        ("gamma_post", C.c_void_p), ("beta_post", C.c_void_p), ("residual", C.c_void_p), ("t_out", C.c_void_p),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("eps", C.c_float),
+    ]
+
+
 class AttnDecodeDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("capacity", C.c_int), ("head_dim", C.c_int),
@@ -113,6 +122,7 @@ SIGNATURES = {
     "cogv_ln_bwd_num_blocks": (_i, [_i]),
     "cogv_attention_fwd": (_i, [C.POINTER(AttnDesc), _vp]),
     "cogv_attention_bwd": (_i, [C.POINTER(AttnDesc), _vp]),
+    "cogv_gemv_ln": (_i, [C.POINTER(GemmDesc), C.POINTER(LnPrologue), _vp]),
     "cogv_attention_decode": (_i, [C.POINTER(AttnDecodeDesc), _vp]),
     "cogv_attention_decode_workspace_bytes": (_sz, [_i, _i, _i]),
     "cogv_sparse_slot_reduce": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),

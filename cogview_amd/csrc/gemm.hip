@@ -1576,6 +1576,246 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Matrix-vector kernel with the layer's LayerNorms as its PROLOGUE (decode steps, M <= 8 rows, K = hidden size <= 4096).
+// A decode step of one token spends more time in its four per-layer Sandwich-LN launches (7 us each: launch latency plus a
+// dependent chain on one row) than the LayerNorms cost in bytes, so the chain
+//     z --[post-LN gamma_p, beta_p, Sandwich scale |z|max]--> + residual --> t --[pre-LN gamma, beta, Sandwich scale |t|max]--> x_in
+//     y = epilogue(x_in . W^T + b)
+// (mpu/sparse_transformer.py:314-342: t = x + LN3(attn) feeding LN2, or t = y + LN4(mlp) feeding the next layer's LN1 /
+// the final LayerNorm) runs inside EVERY workgroup of the GEMV that consumes x_in: the vectors are M x K 16-bit values, a
+// few KB, and recomputing them 320-1280 times is cheaper than one more launch.  Workgroup 0 also stores t (the
+// residual stream) once.  Rounding points are those of ln_fwd_kernel (LayerNorm output rounded to the storage type
+// before the residual add, t rounded, x_in rounded).  |t|max is taken over all M rows, as x.abs().max() does.
+struct GemvLnArgs {
+  GemmArgs g;                                   // B, bias, C, M, N, K, ldb, ldc, flags, absmax (of the output)
+  const void* z; const float* z_absmax;         // [M][K] input; its abs-max (device scalar) -- required with a post-LN
+  const void* gamma_p; const void* beta_p;      // post-LN affine (nullptr: no post-LN, t = z)
+  const void* res; void* t_out;                 // residual [M][K] (with the post-LN); t_out [M][K] written by workgroup 0 (may be null)
+  const void* gamma; const void* beta;          // pre-LN affine
+  float eps;
+};
+template <typename T, int MT>        // MT: compile-time bound of the row count (1, 2, 4, 8): registers follow the real batch
+__global__ __launch_bounds__(256) void gemv_ln_kernel(const GemvLnArgs q) {
+  extern __shared__ __attribute__((aligned(16))) char xs_raw[];           // x_in [M][K] as T
+  __shared__ float part[4][MT][8];
+  __shared__ float red[8];
+  __shared__ uint32_t redm[16];
+  __shared__ float s_amax;
+  const GemmArgs& p = q.g;
+  T* xs = reinterpret_cast<T*>(xs_raw);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = p.K, nvec = K >> 3;                // K % 512 == 0: every thread owns whole 8-element vectors v = tid, tid + 256
+  const float inv_k = 1.0f / (float)K;
+  const bool has_post = q.gamma_p != nullptr;
+  const int v0 = threadIdx.x, v1 = threadIdx.x + 256;
+  const bool ok1 = v1 < nvec;                      // v0 < nvec always (K >= 2048 is not required: guard below)
+  const bool ok0 = v0 < nvec;
+  // ---- everything that does not depend on the prologue is requested first: this wave's first weight chunk (the HBM
+  //      stream: its latency now overlaps the LayerNorm arithmetic), the input rows, the residual and the four affine vectors
+  const int n0 = blockIdx.x * 8;
+  const T* B = reinterpret_cast<const T*>(p.B) + (size_t)n0 * p.ldb;
+  const int nchunk = K >> 9;
+  u32x4 w[8];
+  {
+    const int k = (min(wave, nchunk - 1) << 9) + lane * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const u32x4*>(B + (size_t)j * p.ldb + k);
+  }
+  const T* Z = reinterpret_cast<const T*>(q.z);
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 zr[MT][2], rr[MT][2], gpr[2], bpr[2], gnr[2], bnr[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int v = u ? v1 : v0; const bool ok = u ? ok1 : ok0;
+    gnr[u] = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(q.gamma) + v * 8) : zero4;
+    bnr[u] = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(q.beta) + v * 8) : zero4;
+    gpr[u] = (ok && has_post) ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(q.gamma_p) + v * 8) : zero4;
+    bpr[u] = (ok && has_post) ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(q.beta_p) + v * 8) : zero4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      zr[m][u] = (ok && m < p.M) ? *reinterpret_cast<const u32x4*>(Z + (size_t)m * K + v * 8) : zero4;
+      rr[m][u] = (ok && has_post && m < p.M) ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(q.res) + (size_t)m * K + v * 8) : zero4;
+    }
+  }
+  const float zamax = q.z_absmax ? *q.z_absmax : 0.f;
+  // sums over the workgroup of up to 2 * MT values at once (one LDS round for all rows)
+  auto block_sums = [&](float (&a)[MT]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = wave_sum_uniform(a[m]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) part[wave][m][0] = a[m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = (part[0][m][0] + part[1][m][0]) + (part[2][m][0] + part[3][m][0]);
+  };
+  float tv[MT][2][8];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) unpack8<T>(zr[m][u], tv[m][u]);
+  if (has_post) {                 // t = residual + LN_post(z), rounded where ln_fwd_kernel rounds
+    const float c = zamax * 0.125f;
+    const float eps_p = q.eps * c * c;
+    float s[MT], qq[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      s[m] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[m] += tv[m][u][i];            // vectors past K are zero
+    }
+    block_sums(s);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float mean = s[m] * inv_k;
+      qq[m] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (u ? ok1 : ok0)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const float d = tv[m][u][i] - mean; qq[m] += d * d; }
+    }
+    block_sums(qq);
+    float gp[2][8], bp[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { unpack8<T>(gpr[u], gp[u]); unpack8<T>(bpr[u], bp[u]); }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float mean = s[m] * inv_k, rstd = 1.0f / sqrtf(qq[m] * inv_k + eps_p);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float r[8], o[8];
+        unpack8<T>(rr[m][u], r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (tv[m][u][i] - mean) * rstd * gp[u][i] + bp[u][i];
+        u32x4 lo = pack8<T>(o); unpack8<T>(lo, o);          // LayerNorm output rounded before the residual add
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += r[i];
+        const u32x4 ov = pack8<T>(o);
+        unpack8<T>(ov, tv[m][u]);
+        if (!(u ? ok1 : ok0)) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) tv[m][u][i] = 0.f;
+        } else if (blockIdx.x == 0 && q.t_out && m < p.M)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(q.t_out) + (size_t)m * K + (u ? v1 : v0) * 8) = ov;
+      }
+    }
+  }
+  // pre-LN: Sandwich scale = max |t| over all rows (x.abs().max(), mpu/sparse_transformer.py:40-44) -- the published
+  // abs-max when t is the plain input, else taken here -- then mean / variance per row
+  float amax;
+  if (!has_post && q.z_absmax) {
+    amax = zamax;
+  } else {
+    uint32_t amax_pk = 0u;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) amax_pk = absmax_pk8(amax_pk, pack8<T>(tv[m][u]));     // rows >= M and vectors past K are zero
+    __syncthreads();
+    const float a = absmax_pk_block<T>(amax_pk, redm);
+    if (threadIdx.x == 0) s_amax = a;
+    __syncthreads();
+    amax = s_amax;
+  }
+  {
+    const float c = amax * 0.125f;
+    const float eps_n = q.eps * c * c;
+    float s[MT], qq[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      s[m] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[m] += tv[m][u][i];
+    }
+    block_sums(s);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float mean = s[m] * inv_k;
+      qq[m] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (u ? ok1 : ok0)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const float d = tv[m][u][i] - mean; qq[m] += d * d; }
+    }
+    block_sums(qq);
+    float gn[2][8], bn[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { unpack8<T>(gnr[u], gn[u]); unpack8<T>(bnr[u], bn[u]); }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float mean = s[m] * inv_k, rstd = 1.0f / sqrtf(qq[m] * inv_k + eps_n);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u ? ok1 : ok0) {
+          float o[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (tv[m][u][i] - mean) * rstd * gn[u][i] + bn[u][i];
+          *reinterpret_cast<u32x4*>(xs + (size_t)m * K + (u ? v1 : v0) * 8) = pack8<T>(o);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the matrix-vector product proper (as gemv_kernel, x_in read from LDS; the first chunk is already in registers)
+  float acc[MT][8];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[m][j] = 0.f;
+  for (int c = wave; c < nchunk; c += 4) {
+    const int k = (c << 9) + lane * 8;
+    if (c != wave) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const u32x4*>(B + (size_t)j * p.ldb + k);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float x[8];
+      unpack8<T>(*reinterpret_cast<const u32x4*>(xs + (size_t)m * K + k), x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float wf[8];
+        unpack8<T>(w[j], wf);
+        float t = acc[m][j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t = fmaf(x[e], wf[e], t);
+        acc[m][j] = t;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float t = wave_sum_uniform(acc[m][j]);
+      if (lane == 0) part[wave][m][j] = t;
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t am = 0u;
+    for (int m = 0; m < p.M; ++m) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[0][m][j] + part[1][m][j] + part[2][m][j] + part[3][m][j];
+      am = absmax_pk(am, epilogue8<T>(p, m, n0, v));
+    }
+    if (p.flags & COGV_EPI_ABSMAX) {
+      const uint32_t wv = max(am & 0xffffu, am >> 16);
+      atomic_max_nonneg(p.absmax, bits_to_f<T>((uint16_t)wv));
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   __shared__ float red[16];
@@ -1872,6 +2112,37 @@ extern "C" int cogv_gemm(const cogv_gemm_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == COGV_F16) return launch_gemm<f16_t>(d, a, st);
   return launch_gemm<bf16_t>(d, a, st);
+}
+
+// y = epilogue(LN_pre([res + LN_post(z)]) . B^T): the decode step's GEMV with its LayerNorms as prologue (gemv_ln_kernel).
+extern "C" int cogv_gemv_ln(const cogv_gemm_desc* d, const cogv_ln_prologue* ln, void* stream) {
+  if (!d || !ln) return COGV_ERR_ARG;
+  GemvLnArgs a;
+  const int rc = build_gemm_args(d, a.g);
+  if (rc != COGV_OK) return rc;
+  if (d->trans_a || d->trans_b || a.g.M > GEMV_MAX_M || (a.g.K & 511) || a.g.K > 4096 || (a.g.N & 7) || (a.g.ldb & 7)) return COGV_ERR_UNSUPPORTED;
+  if (d->flags & (COGV_EPI_COLSUM | COGV_EPI_ACCUM | COGV_EPI_DGELU | COGV_EPI_MULAUX | COGV_EPI_DROPOUT) || d->out_f32 || d->splitk > 1) return COGV_ERR_UNSUPPORTED;
+  if (!ln->z || !ln->gamma || !ln->beta) return COGV_ERR_ARG;
+  if (ln->gamma_post && (!ln->beta_post || !ln->residual || !ln->z_absmax)) return COGV_ERR_ARG;
+  if (((uintptr_t)ln->z | (uintptr_t)ln->gamma | (uintptr_t)ln->beta | (uintptr_t)ln->gamma_post | (uintptr_t)ln->beta_post |
+       (uintptr_t)ln->residual | (uintptr_t)ln->t_out) & 15) return COGV_ERR_ARG;
+  a.z = ln->z; a.z_absmax = ln->z_absmax; a.gamma_p = ln->gamma_post; a.beta_p = ln->beta_post; a.res = ln->residual;
+  a.t_out = ln->t_out; a.gamma = ln->gamma; a.beta = ln->beta; a.eps = ln->eps;
+  a.g.splitk = 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int mt = a.g.M <= 1 ? 1 : a.g.M <= 2 ? 2 : a.g.M <= 4 ? 4 : 8;
+  const int shmem = mt * a.g.K * 2;                 // rows [M, mt) are written as zeros-normalised junk nobody reads
+  const dim3 grid(a.g.N / 8), block(256);
+#define GEMV_LN_LAUNCH(T_, MT_)                                                                                          \
+  do {                                                                                                                   \
+    static bool attr = false;                                                                                            \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_ln_kernel<T_, MT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; } \
+    hipLaunchKernelGGL((gemv_ln_kernel<T_, MT_>), grid, block, shmem, st, a);                                             \
+  } while (0)
+  if (d->dtype == COGV_F16) { if (mt == 1) GEMV_LN_LAUNCH(f16_t, 1); else if (mt == 2) GEMV_LN_LAUNCH(f16_t, 2); else if (mt == 4) GEMV_LN_LAUNCH(f16_t, 4); else GEMV_LN_LAUNCH(f16_t, 8); }
+  else { if (mt == 1) GEMV_LN_LAUNCH(bf16_t, 1); else if (mt == 2) GEMV_LN_LAUNCH(bf16_t, 2); else if (mt == 4) GEMV_LN_LAUNCH(bf16_t, 4); else GEMV_LN_LAUNCH(bf16_t, 8); }
+#undef GEMV_LN_LAUNCH
+  return cogv_check_launch();
 }
 
 // Several GEMMs of the same dtype and layout in one persistent launch of the generation-3 kernel (see GroupArgs).

@@ -626,6 +626,49 @@ class _TransformerLayer(torch.autograd.Function):
         return dx, None, None, None, None, None, None
 
 
+def decode_chain_supported(tr, batch):
+    """The fused decode chain (decode_chain) covers the dense, single-partition model in a 16-bit type at one token per
+    row: what a captured decode step runs."""
+    h = tr.layers[0].input_layernorm.weight.shape[0]
+    return (mp_world_size_or_1() == 1 and batch <= 8 and h % 512 == 0 and h <= 4096
+            and tr.layers[0].input_layernorm.weight.dtype in (torch.float16, torch.bfloat16))
+
+
+def decode_chain(tr, h0, absmax0, slots, emb_weight):
+    """One decode step through all layers with FIVE launches per layer (+1 combine): QKV GEMV with [previous layer's
+    LN4 + residual, LN1] as prologue | decode attention (cache append fused) | dense GEMV | h->4h GEMV with [LN3 +
+    residual, LN2] as prologue and GeLU epilogue | 4h->h GEMV; the last LN4 + residual and the final LayerNorm are the
+    prologue of the tied-logits GEMV.  Same arithmetic and rounding points as the layer-by-layer path
+    (mpu/sparse_transformer.py:314-342, 612; model/gpt2_modeling.py:115-118).  h0 [b, 1, h]; slots: StaticKVSlot per
+    layer.  Returns logits [b, 1, V]."""
+    b, s, h = h0.shape
+    assert s == 1
+    dev = h0.device
+    z, z_absmax, post, res = h0.view(b, h), absmax0, None, None
+    for layer, slot in zip(tr.layers, slots):
+        att_m, mlp_m = layer.attention, layer.mlp
+        eps = layer.input_layernorm.eps
+        npp = att_m.num_attention_heads_per_partition
+        hp = npp * 64
+        qkv, x = ops.gemv_ln(z, att_m.query_key_value.weight, att_m.query_key_value.bias, layer.input_layernorm.weight,
+                             layer.input_layernorm.bias, eps, z_absmax, post, res, want_t=post is not None)
+        if x is None:
+            x = z
+        att = ops.attention_decode(qkv.view(b, 1, 3 * hp), slot.cache, slot.pos_index, npp)
+        slot.out = slot.cache
+        slot_ao = ops.new_absmax_slot(dev)
+        ao = ops.gemm(att.view(b, hp), att_m.dense.weight, bias=att_m.dense.bias, absmax=slot_ao)
+        g, y = ops.gemv_ln(ao, mlp_m.dense_h_to_4h.weight, mlp_m.dense_h_to_4h.bias, layer.post_attention_layernorm.weight,
+                           layer.post_attention_layernorm.bias, eps, slot_ao,
+                           (layer.third_layernorm.weight, layer.third_layernorm.bias), x, want_t=True, gelu=True)
+        slot_mo = ops.new_absmax_slot(dev)
+        mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias, absmax=slot_mo)
+        z, z_absmax, post, res = mo, slot_mo, (layer.fourth_layernorm.weight, layer.fourth_layernorm.bias), y
+    fl = tr.final_layernorm
+    logits, _ = ops.gemv_ln(z, emb_weight, None, fl.weight, fl.bias, fl.eps, z_absmax, post, res)
+    return logits.view(b, 1, emb_weight.shape[0])
+
+
 def transformer_layer_kv(layer, x, absmax_x, sep, kv_slot):
     """The fused layer chain for incremental decoding (no gradient): 9 kernels + the cache append instead of the ~20 of
     the op-by-op composition."""

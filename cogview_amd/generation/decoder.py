@@ -38,6 +38,7 @@ class GraphDecoder:
         self.slots = [StaticKVSlot(c, self.pos_index, self.table) for c in self.caches]
         self.slab = torch.zeros(8 * len(tr.layers) + 16, dtype=torch.float32, device=dev)
         self.graph, self.logits = None, None
+        self.fused = True            # False: layer-by-layer path (every LayerNorm its own launch) -- kept for comparison
 
     # ------------------------------------------------------------------ one decode step, eager (also what gets captured)
     def _step(self):
@@ -45,6 +46,10 @@ class GraphDecoder:
         self.slab.zero_()
         with ops.scalar_slab(self.slab):
             h = tr.embed(self.tok, self.pos, self.gpt.word_embeddings)
+            if self.fused and F_.decode_chain_supported(tr, self.batch):
+                # five launches per layer: the LayerNorms ride as prologues of the GEMVs, the cache append inside the
+                # decode attention kernel (functional.decode_chain)
+                return F_.decode_chain(tr, h, h._cogv_absmax, self.slots, self.gpt.word_embeddings.weight)
             for layer, slot in zip(tr.layers, self.slots):
                 h = layer(h, 0, mem=slot)
             out = tr.final_layernorm(h)

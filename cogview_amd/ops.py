@@ -258,6 +258,47 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
     return out
 
 
+def gemv_ln(z, w, bias, gamma, beta, eps, z_absmax=None, post=None, residual=None, want_t=False, gelu=False, absmax=None):
+    """Decode-step GEMV with its LayerNorms as prologue (cogv_gemv_ln): z [M, K] (M <= 8), w [N, K].
+        t = residual + SandwichLN(z; post = (gamma_p, beta_p), scale z_absmax)   (post given)   else   t = z
+        out = epilogue(SandwichLN(t; gamma, beta) . w^T + bias)
+    Returns (out [M, N], t [M, K] or None)."""
+    _need_gpu(z, w)
+    assert z.dim() == 2 and w.dim() == 2 and z.is_contiguous() and w.stride(1) == 1 and z.shape[1] == w.shape[1]
+    M, K = z.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=z.dtype, device=z.device)
+    d = L.GemmDesc()
+    d.dtype = dt_code(z)
+    d.M, d.N, d.K = M, N, K
+    d.A, d.lda = z.data_ptr(), K
+    d.B, d.ldb = w.data_ptr(), w.stride(0)
+    d.C, d.ldc = out.data_ptr(), N
+    flags = 0
+    if bias is not None:
+        flags |= L.EPI_BIAS
+        d.bias = bias.data_ptr()
+    if gelu:
+        flags |= L.EPI_GELU
+    if absmax is not None:
+        flags |= L.EPI_ABSMAX
+        d.absmax = absmax.data_ptr()
+    d.flags, d.splitk = flags, 1
+    ln = L.LnPrologue()
+    ln.z = z.data_ptr()
+    ln.z_absmax = None if z_absmax is None else z_absmax.data_ptr()
+    t = None
+    if post is not None:
+        assert residual is not None and residual.is_contiguous() and residual.shape == z.shape and z_absmax is not None
+        ln.gamma_post, ln.beta_post, ln.residual = post[0].data_ptr(), post[1].data_ptr(), residual.data_ptr()
+        if want_t:
+            t = torch.empty_like(z)
+            ln.t_out = t.data_ptr()
+    ln.gamma, ln.beta, ln.eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
+    L.check(L.lib().cogv_gemv_ln(C.byref(d), C.byref(ln), _stream()), "cogv_gemv_ln")
+    return out, t
+
+
 def gemm_grouped(problems, trans_a=True, trans_b=True, accumulate=True):
     """Up to 16 GEMMs of one layout in ONE persistent launch (cogv_gemm_grouped): `problems` is a list of
     (a, b, out).  Used for the weight gradients of one or several transformer layers, which fill the 256 CUs together.

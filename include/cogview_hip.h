@@ -99,6 +99,22 @@ int cogv_gemm_grouped(const cogv_gemm_desc* descs, int count, void* stream);
  * counters in 4 KiB of device memory per GPU that it allocates itself on the first GEMM call (its only allocation). */
 int cogv_gemm_pick_splitk_tiles(int tiles_256x256, int K);
 
+/* Decode-step matrix-vector product with the layer's LayerNorms as prologue (M <= 8 rows, K = hidden size <= 4096,
+ * K % 512 == 0; trans_a = trans_b = 0; epilogue flags BIAS | GELU | ABSMAX only; d->A is ignored):
+ *     t    = gamma_post ? residual + LN_{eps (|z|max/8)^2}(z) * gamma_post + beta_post : z        (t_out, if given, receives t)
+ *     x_in = LN_{eps (|t|max/8)^2}(t) * gamma + beta ;   C = epilogue(x_in . B^T)
+ * i.e. mpu/sparse_transformer.py:326-341 -- `x + LN3(attn)` feeding `LN2`, or `y + LN4(mlp)` feeding the next layer's
+ * `LN1` / the final LayerNorm -- fused into the GEMV that consumes it (every workgroup recomputes the few-KB vectors;
+ * four Sandwich-LN launches per layer disappear from a decode step).  |t|max is taken over all M rows.  z_absmax: device
+ * scalar with max|z| (required with a post-LN; for a plain input it is used as |t|max when given). */
+typedef struct cogv_ln_prologue {
+  const void* z; const float* z_absmax;
+  const void* gamma_post; const void* beta_post; const void* residual; void* t_out;
+  const void* gamma; const void* beta;
+  float eps;
+} cogv_ln_prologue;
+int cogv_gemv_ln(const cogv_gemm_desc* d, const cogv_ln_prologue* ln, void* stream);
+
 /* ------------------------------------------------------------------ Sandwich-LN
  * y = [residual +] LayerNorm_{eps*(amax/8)^2}(x) * gamma + beta ; amax = *absmax_in (NULL: plain LN).
  * replaces mpu/sparse_transformer.py:40-44 (LayerNorm = FusedLayerNorm(x / (x.abs().max()/8))) and the

@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_symbol():
 
 def test_struct_layouts_match_header_field_order():
     src = open(os.path.join(ROOT, "include", "cogview_hip.h")).read()
-    for cname, cls in (("cogv_gemm_desc", _lib.GemmDesc), ("cogv_attn_desc", _lib.AttnDesc), ("cogv_adam_desc", _lib.AdamDesc), ("cogv_attn_decode_desc", _lib.AttnDecodeDesc),
+    for cname, cls in (("cogv_gemm_desc", _lib.GemmDesc), ("cogv_attn_desc", _lib.AttnDesc), ("cogv_adam_desc", _lib.AdamDesc), ("cogv_attn_decode_desc", _lib.AttnDecodeDesc), ("cogv_ln_prologue", _lib.LnPrologue),
                        ("cogv_conv_desc", _lib.ConvDesc)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)

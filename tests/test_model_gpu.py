@@ -685,6 +685,45 @@ def test_graph_decoder_matches_eager_incremental_decoding(golden_dir):
         assert e < 3e-3 and dec.length == S_, (captured, e, per)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_decode_chain_matches_layer_by_layer_and_full_sequence(dtype):
+    """The five-launches-per-layer decode chain (LayerNorms as GEMV prologues: cogv_gemv_ln; decode attention with the
+    cache append fused: cogv_attention_decode; final LayerNorm inside the logits GEMV) at a width it supports (h = 512),
+    batch 2: same logits as the layer-by-layer decode path and as the full-sequence forward, eager and captured."""
+    from cogview_amd import functional as F_
+    from cogview_amd.fp16 import FP16_Module
+    from cogview_amd.generation import GraphDecoder
+    from cogview_amd.model import GPT2Model
+    L_, V_, H_, NH_, S_, B_ = 3, 1024, 512, 8, 40, 2
+    torch.manual_seed(11)
+    m = GPT2Model(L_, V_, H_, NH_, 0.0, 0.0, 0.0, S_ + 1, 64, False)
+    for n, p in m.named_parameters():                      # non-trivial LayerNorm affine / biases
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    model = FP16_Module(m.cuda(), dtype=dtype, keep_half_outputs=True).eval()
+    assert F_.decode_chain_supported(model.module.transformer, B_)
+    tokens = torch.randint(0, V_, (B_, S_), generator=torch.Generator().manual_seed(3)).cuda()
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    with torch.no_grad():
+        full, *_ = model(tokens, pos, 0, None, None, 0)
+    pre = S_ - 8
+    tol = 3e-3 if dtype == torch.float16 else 3e-2
+    res = {}
+    for fused, captured in ((False, False), (True, False), (True, True)):
+        dec = GraphDecoder(model, batch=B_, capacity=128)
+        dec.fused = fused
+        dec.prefill(tokens[:, :pre], pos[:, :pre])
+        if captured:
+            dec.capture()
+        outs = [dec.step(tokens[:, t:t + 1], pos[:, t:t + 1]).clone() for t in range(pre, S_)]
+        res[(fused, captured)] = torch.cat(outs, 1)
+        e = rel(res[(fused, captured)], full[:, pre:])
+        print(f"[{dtype}] fused={fused} captured={captured}: decode logits vs full sequence rel-L2 {e:.2e}")
+        assert e < tol, (fused, captured, e)
+    assert rel(res[(True, False)], res[(False, False)]) < tol
+    assert torch.equal(res[(True, True)], res[(True, False)]), "graph replay must reproduce the eager fused step bit for bit"
+
+
 # ------------------------------------------------------------------------------------------------ sharded optimizer (2 ranks, one GPU)
 def _dp2_shard_worker(rank, world, port, golden_dir, ret):
     """Two data-parallel ranks, two optimizer steps, once with the all-reduce exchange and once with the reduce-scatter /
