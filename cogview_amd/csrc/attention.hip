@@ -965,17 +965,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs p) {
 // 50 us per layer; the kernel boundary publishes the partials for free.)
 template <typename T>
 __global__ __launch_bounds__(64) void attn_decode_combine_kernel(const DecodeArgs p) {
+  __shared__ float wgt[64];
   const int t = threadIdx.x, head = blockIdx.x, b = blockIdx.y;
   const float* base = p.ws + ((size_t)b * p.H + head) * p.nsplit * 66;
-  float M = -INFINITY;
-  for (int i = 0; i < p.nsplit; ++i) M = fmaxf(M, base[i * 66]);
-  float L = 0.f, O = 0.f;
-  for (int i = 0; i < p.nsplit; ++i) {
-    const float mi = base[i * 66];
-    const float w = (mi == -INFINITY) ? 0.f : fast_exp2(mi - M);
-    L = fmaf(base[i * 66 + 1], w, L);
-    O = fmaf(base[i * 66 + 2 + t], w, O);
-  }
+  // lane i holds split i's (max, sum): one independent load each instead of a chain of dependent ones (nsplit <= 32)
+  const float mi = t < p.nsplit ? base[t * 66] : -INFINITY;
+  const float li = t < p.nsplit ? base[t * 66 + 1] : 0.f;
+  float M = mi;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+  const float w = (mi == -INFINITY) ? 0.f : fast_exp2(mi - M);
+  float L = li * w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) L += __shfl_xor(L, o, 64);
+  wgt[t] = w;
+  __syncthreads();
+  float O = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < p.nsplit; ++i) O = fmaf(base[i * 66 + 2 + t], wgt[i], O);
   reinterpret_cast<T*>(p.out)[b * p.out_bs + head * HD + t] = HT<T>::from_f(O / L);
 }
 
@@ -1163,7 +1170,7 @@ extern "C" size_t cogv_attention_decode_workspace_bytes(int B, int H, int capaci
 
 extern "C" int cogv_attention_decode(const cogv_attn_decode_desc* d, void* stream) {
   if (!d || (d->dtype != COGV_F16 && d->dtype != COGV_BF16)) return COGV_ERR_UNSUPPORTED;
-  if (d->B <= 0 || d->H <= 0 || d->capacity <= 0 || d->head_dim != HD) return COGV_ERR_ARG;
+  if (d->B <= 0 || d->H <= 0 || d->capacity <= 0 || d->capacity > 4096 || d->head_dim != HD) return COGV_ERR_ARG;
   if (!d->qkv || !d->cache || !d->out || !d->pos || !d->workspace) return COGV_ERR_ARG;
   if (!aligned16(d->qkv) || !aligned16(d->cache) || ((d->qkv_bs | d->cache_bs | d->cache_rs) & 7)) return COGV_ERR_ARG;
   if (d->workspace_bytes < cogv_attention_decode_workspace_bytes(d->B, d->H, d->capacity) || ((uintptr_t)d->workspace & 15)) return COGV_ERR_ARG;
