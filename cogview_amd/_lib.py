@@ -97,6 +97,7 @@ class ConvDesc(C.Structure):
         ("kind", C.c_int), ("B", C.c_int), ("IH", C.c_int), ("IW", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
         ("relu", C.c_int),
         ("in", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+        ("rgb_w", C.c_void_p), ("rgb_partial", C.c_void_p),
     ]
 
 
@@ -143,6 +144,7 @@ SIGNATURES = {
     "cogv_cast_flat": (_i, [_i, _vp, _vp, _sz, _vp]),
     "cogv_cast_flat_back": (_i, [_i, _vp, _vp, _sz, _vp]),
     "cogv_conv2d_nhwc_f32": (_i, [C.POINTER(ConvDesc), _vp]),
+    "cogv_rgb_finalize_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
     "cogv_vq_argmin_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "cogv_nchw3_to_nhwc4_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "cogv_embed_code_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),

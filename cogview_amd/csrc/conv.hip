@@ -36,6 +36,8 @@ struct ConvArgs {
   int in_mul, out_mul;
   int ntaps;
   int kind;                 // COGV_CONV_*: tap offsets are arithmetic (tap_offset), no table in memory
+  const float* rgb_w;       // optional fused 1x1 -> 3 projection of the (bias + ReLU) output: weights [3][Cout] ...
+  float* rgb_part;          // ... partial sums [Cout / 128][B * OH * OW][4] instead of the output tensor
   long long w_parity_stride;
   int relu_out;
   int nz;                   // parities (4 for the transposed convolution, else 1)
@@ -276,6 +278,8 @@ __global__ __launch_bounds__(NT, 2) void conv_kernel(const ConvArgs p) {
   for (int pass = 0; pass < 8; ++pass) {
     const int row = pass * 16 + (threadIdx.x >> 4);
     const int m = m0 + row, n = n0 + cchunk;
+    float rgb[3] = {0.f, 0.f, 0.f};
+    size_t pix = 0;
     if (m < p.M && n < p.Cout) {
       f32x4 x0 = ld4(ct + row * BN + cchunk), x1 = ld4(ct + row * BN + cchunk + 4);
       if (p.bias) { const f32x4 b0 = ld4(p.bias + n), b1 = ld4(p.bias + n + 4); x0 += b0; x1 += b1; }
@@ -287,9 +291,33 @@ __global__ __launch_bounds__(NT, 2) void conv_kernel(const ConvArgs p) {
       const int rem = m - b * (p.GH * p.GW);
       const int y = rem / p.GW, x = rem - y * p.GW;
       const int oy = y * p.out_mul + (z >> 1), ox = x * p.out_mul + (z & 1);   // z = 0 unless transposed
-      float* o = p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.Cout + n;
-      *reinterpret_cast<f32x4*>(o) = x0;
-      *reinterpret_cast<f32x4*>(o + 4) = x1;
+      if (!p.rgb_part) {
+        float* o = p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.Cout + n;
+        *reinterpret_cast<f32x4*>(o) = x0;
+        *reinterpret_cast<f32x4*>(o + 4) = x1;
+      } else {
+        // fused final 1x1 convolution (vqvae/vqvae_zc.py:190): this tile's 128 channels of the three output sums; the
+        // 134-MB-per-image activation of the last transposed convolution is never written
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const f32x4 w0 = ld4(p.rgb_w + (size_t)c * p.Cout + n), w1 = ld4(p.rgb_w + (size_t)c * p.Cout + n + 4);
+          float r = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { r = fmaf(x0[i], w0[i], r); r = fmaf(x1[i], w1[i], r); }
+          rgb[c] = r;
+        }
+        pix = ((size_t)b * p.OH + oy) * p.OW + ox;
+      }
+    }
+    if (p.rgb_part) {        // the 16 lanes of a row hold its 16 channel groups: fold them, lane 0 of the group stores
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float r = rgb[c];
+        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 8, 64);
+        rgb[c] = r;
+      }
+      if ((threadIdx.x & 15) == 0 && m < p.M)
+        *reinterpret_cast<f32x4*>(p.rgb_part + ((size_t)(n0 / BN) * ((size_t)p.B * p.OH * p.OW) + pix) * 4) = f32x4{rgb[0], rgb[1], rgb[2], 0.f};
     }
   }
 }
@@ -439,15 +467,30 @@ __global__ __launch_bounds__(256) void conv1x1_to3_kernel(const float* in, const
   }
 }
 
+// out[b][c][pix] = (sum over channel tiles of the fused-projection partial sums + bias[c]) * scale[c] + shift[c]
+__global__ __launch_bounds__(256) void rgb_finalize_kernel(const float* part, int ntiles, const float* bias, float* out, size_t npix,
+                                                           int HW, float s0, float s1, float s2, float t0, float t1, float t2) {
+  for (size_t px = (size_t)blockIdx.x * blockDim.x + threadIdx.x; px < npix; px += (size_t)gridDim.x * blockDim.x) {
+    f32x4 a = ld4(part + px * 4);
+    for (int t = 1; t < ntiles; ++t) a += ld4(part + ((size_t)t * npix + px) * 4);
+    const size_t b = px / HW, r = px % HW;
+    out[(b * 3 + 0) * HW + r] = (a[0] + bias[0]) * s0 + t0;
+    out[(b * 3 + 1) * HW + r] = (a[1] + bias[1]) * s1 + t1;
+    out[(b * 3 + 2) * HW + r] = (a[2] + bias[2]) * s2 + t2;
+  }
+}
+
 }  // namespace
 
 extern "C" int cogv_conv2d_nhwc_f32(const cogv_conv_desc* d, void* stream) {
-  if (!d || !d->in || !d->w || !d->out) return COGV_ERR_ARG;
+  if (!d || !d->in || !d->w || (!d->out && !d->rgb_partial)) return COGV_ERR_ARG;
+  if (d->rgb_partial && (!d->rgb_w || !d->relu || (d->Cout % 128) || (((uintptr_t)d->rgb_w | (uintptr_t)d->rgb_partial) & 15))) return COGV_ERR_ARG;
   if (d->Cin <= 0 || (d->Cin & 3) || (d->Cout & 7) || d->B <= 0) return COGV_ERR_ARG;
   if (((uintptr_t)d->in | (uintptr_t)d->w | (uintptr_t)d->out | (uintptr_t)d->bias) & 15) return COGV_ERR_ARG;
   ConvArgs a;
   a.in = (const float*)d->in; a.w = (const float*)d->w; a.bias = (const float*)d->bias; a.out = (float*)d->out;
   a.B = d->B; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin; a.Cout = d->Cout; a.relu_out = d->relu;
+  a.rgb_w = (const float*)d->rgb_w; a.rgb_part = (float*)d->rgb_partial;
   int nz = 1;
   a.kind = d->kind;
   if (d->kind == COGV_CONV_4X4_S2) {
@@ -485,6 +528,18 @@ extern "C" int cogv_conv2d_nhwc_f32(const cogv_conv_desc* d, void* stream) {
   }
   if (a.Cin % BK == 0) hipLaunchKernelGGL(conv_kernel<true>, dim3((unsigned)blocks), dim3(NT), 65536, reinterpret_cast<hipStream_t>(stream), a);
   else hipLaunchKernelGGL(conv_kernel<false>, dim3((unsigned)blocks), dim3(NT), 65536, reinterpret_cast<hipStream_t>(stream), a);
+  return cogv_check_launch();
+}
+
+extern "C" int cogv_rgb_finalize_f32(const float* partial, int ntiles, const float* bias, float* out, int B, int H, int W,
+                                     const float* scale3_host, const float* shift3_host, void* stream) {
+  if (!partial || !bias || !out || ntiles <= 0 || B <= 0 || H <= 0 || W <= 0 || ((uintptr_t)partial & 15)) return COGV_ERR_ARG;
+  const float s[3] = {scale3_host ? scale3_host[0] : 1.f, scale3_host ? scale3_host[1] : 1.f, scale3_host ? scale3_host[2] : 1.f};
+  const float t[3] = {shift3_host ? shift3_host[0] : 0.f, shift3_host ? shift3_host[1] : 0.f, shift3_host ? shift3_host[2] : 0.f};
+  const size_t npix = (size_t)B * H * W;
+  size_t blocks = (npix + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(rgb_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial, ntiles,
+                     bias, out, npix, H * W, s[0], s[1], s[2], t[0], t[1], t[2]);
   return cogv_check_launch();
 }
 

@@ -25,8 +25,10 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _conv(kind, x, w, bias, cout, relu):
-    """x NHWC fp32 contiguous -> NHWC fp32."""
+def _conv(kind, x, w, bias, cout, relu, rgb=None):
+    """x NHWC fp32 contiguous -> NHWC fp32.  rgb = (w_rgb [3, cout], bias_rgb [3], scale, shift): the decoder's final
+    1x1 convolution (and the de-normalisation of api.code2img) fused into this layer's epilogue -- the layer's own
+    output tensor is never written; returns the NCHW image [b, 3, oh, ow]."""
     if not x.is_cuda:
         raise L.CogviewHipError("cogview_amd.vqvae runs only on an MI355X (HIP) device; there is no CPU fallback")
     b, ih, iw, cin = x.shape
@@ -36,17 +38,31 @@ def _conv(kind, x, w, bias, cout, relu):
         oh, ow = ih * 2, iw * 2
     else:
         oh, ow = ih, iw
-    out = torch.empty((b, oh, ow, cout), dtype=torch.float32, device=x.device)
     d = L.ConvDesc()
     d.kind, d.B, d.IH, d.IW, d.Cin, d.Cout, d.relu = kind, b, ih, iw, cin, cout, int(relu)
     setattr(d, "in", x.data_ptr())
-    d.w, d.bias, d.out = w.data_ptr(), bias.data_ptr(), out.data_ptr()
+    d.w, d.bias = w.data_ptr(), bias.data_ptr()
+    if rgb is None:
+        out = torch.empty((b, oh, ow, cout), dtype=torch.float32, device=x.device)
+        d.out = out.data_ptr()
+    else:
+        ntiles = cout // 128
+        out = torch.empty((ntiles, b * oh * ow, 4), dtype=torch.float32, device=x.device)
+        d.rgb_w, d.rgb_partial = rgb[0].data_ptr(), out.data_ptr()
     par = 4 if kind == L.CONVT_4X4_S2 else 1
     taps = {L.CONV_4X4_S2: 16, L.CONV_1X1: 1, L.CONVT_4X4_S2: 4}[kind]
     npix_out = b * oh * ow
     with ops.timed_launch("conv", 2.0 * npix_out * cout * taps * cin, 4.0 * (x.numel() + w.numel() + out.numel()),
                           f"kind{kind} {b}x{ih}x{iw}x{cin}->{cout}"):
         L.check(L.lib().cogv_conv2d_nhwc_f32(C.byref(d), _stream()), "cogv_conv2d_nhwc_f32")
+    if rgb is not None:
+        img = torch.empty((b, 3, oh, ow), dtype=torch.float32, device=x.device)
+        sc = (C.c_float * 3)(*rgb[2]) if rgb[2] is not None else None
+        sh = (C.c_float * 3)(*rgb[3]) if rgb[3] is not None else None
+        with ops.timed_launch("rgb_finalize", 0.0, 4.0 * (out.numel() + img.numel()), f"{b}x{oh}x{ow}"):
+            L.check(L.lib().cogv_rgb_finalize_f32(_p(out), cout // 128, _p(rgb[1]), _p(img), b, oh, ow, sc, sh, _stream()),
+                    "cogv_rgb_finalize_f32")
+        return img
     return out
 
 
@@ -183,6 +199,9 @@ class Decoder(_ConvStack):
         (w1, b1), (w2, b2), (w3, b3), (w4, b4) = self._weights([pack_convt_weight] * 3 + [lambda w: w.detach().float().reshape(3, -1).contiguous()])
         y = _conv(L.CONVT_4X4_S2, q_nhwc.contiguous(), w1, b1, self.channel, True)
         y = _conv(L.CONVT_4X4_S2, y, w2, b2, self.channel, True)
+        if self.channel % 128 == 0:
+            # production width: the last transposed convolution projects straight to RGB in its epilogue
+            return _conv(L.CONVT_4X4_S2, y, w3, b3, self.channel, True, rgb=(w4, b4, scale, shift))
         y = _conv(L.CONVT_4X4_S2, y, w3, b3, self.channel, True)
         b, h, w, c = y.shape
         out = torch.empty((b, 3, h, w), dtype=torch.float32, device=y.device)

@@ -284,8 +284,15 @@ int cogv_cast_flat_back(int dtype, const float* src_f32, void* dst_half, size_t 
 typedef struct cogv_conv_desc {
   int kind; int B, IH, IW, Cin, Cout; int relu;     /* relu: applied to the output */
   const void* in; const void* w; const void* bias; void* out;
+  /* optional: the decoder's final 1x1 convolution to RGB (vqvae/vqvae_zc.py:190) fused into this layer's epilogue.
+   * rgb_w = its weights [3][Cout] (fp32); rgb_partial receives [Cout / 128][B * OH * OW][4] fp32 partial sums INSTEAD
+   * of the output tensor (out may be NULL; relu must be set; Cout % 128 == 0); finish with cogv_rgb_finalize_f32. */
+  const void* rgb_w; void* rgb_partial;
 } cogv_conv_desc;
 int cogv_conv2d_nhwc_f32(const cogv_conv_desc* d, void* stream);
+/* out NCHW [B,3,H,W] = (sum over the ntiles partial planes + bias[c]) * scale[c] + shift[c] (scale/shift: 3 HOST floats or NULL) */
+int cogv_rgb_finalize_f32(const float* partial, int ntiles, const float* bias, float* out, int B, int H, int W,
+                          const float* scale3_host, const float* shift3_host, void* stream);
 /* ids[m] = argmin_j (|x_m|^2 - 2 x_m.E_j) + |E_j|^2, first minimum on ties; embed_t = E^T [n_embed][D], embed_sq = |E_j|^2 */
 int cogv_vq_argmin_f32(const float* x, const float* embed_t, const float* embed_sq, int64_t* ids, int M, int D,
                        int n_embed, void* stream);

@@ -136,3 +136,26 @@ def test_conv_kernel_short_contractions(kind, B, H, W, Cin, Cout):
         y = _conv(L.CONVT_4X4_S2, xh, pack_convt_weight(w.cuda()), bias.cuda(), Cout, True)
     for _ in range(2):                       # twice: timing-dependent races show up as run-to-run differences
         assert rel(y.permute(0, 3, 1, 2), ref) < 1e-5
+
+
+def test_fused_rgb_projection_of_the_last_transposed_conv():
+    """COGV conv descriptor with rgb_w / rgb_partial: the last transposed convolution's (bias + ReLU) output projected to
+    RGB in its epilogue (per-channel-tile partial sums + cogv_rgb_finalize_f32) == conv1x1(relu(convT(x))) of the oracle
+    (vqvae/vqvae_zc.py:186-190) with the de-normalisation of vqvae/api.py:43; the 512-channel activation is never written."""
+    import torch.nn.functional as F
+    from cogview_amd import _lib as L
+    from cogview_amd.vqvae.vqvae_zc import _conv, pack_convt_weight
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 2, 8, 8, 64, 256
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g) * 0.1
+    w4 = torch.randn(3, Cout, 1, 1, generator=g) * 0.1
+    b4 = torch.randn(3, generator=g)
+    scale, shift = (0.30379, 0.32279, 0.32800), (0.79093, 0.76271, 0.75340)
+    ref = F.conv2d(F.relu(F.conv_transpose2d(x, w, bias, stride=2, padding=1)), w4, b4)
+    ref = ref * torch.tensor(scale).view(1, 3, 1, 1) + torch.tensor(shift).view(1, 3, 1, 1)
+    img = _conv(L.CONVT_4X4_S2, x.permute(0, 2, 3, 1).contiguous().cuda(), pack_convt_weight(w.cuda()), bias.cuda(), Cout, True,
+                rgb=(w4.reshape(3, Cout).contiguous().cuda(), b4.cuda(), scale, shift))
+    assert img.shape == (B, 3, 2 * H, 2 * W)
+    assert rel(img, ref) < 1e-5
