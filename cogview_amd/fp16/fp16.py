@@ -254,10 +254,16 @@ class FP16_Optimizer(object):
         fp32_params = [p for g in self.optimizer.param_groups for p in g['params']]
         return self.clip_grad_norm(fp32_params, max_norm, norm_type)
 
-    def state_dict(self):
-        if self._shard is not None:          # refresh the slices other ranks own: the saved state is the full, reference-layout one
+    def consolidate_state(self):
+        """COLLECTIVE over the data-parallel group (every rank must call it): with a sharded exchange each rank updates
+        only its slices of the fp32 master / moment buffers; this refreshes the slices the other ranks own, after which
+        state_dict() is the full, reference-layout state on every rank.  A no-op otherwise.  utils.save_checkpoint calls
+        it on all ranks before data-parallel rank 0 writes the file."""
+        if self._shard is not None:
             for flat in (self._master_flat, self._m_flat, self._v_flat):
                 self._shard.gather_state(flat)
+
+    def state_dict(self):
         if self._arena is not None:
             for g in self.optimizer.param_groups:     # where the generic path / apex FusedAdam keep the step
                 g['step'] = self._step_count

@@ -220,7 +220,8 @@ class ShardPlan:
 
     The fp32 master / moment buffers stay allocated full-size (16 B per parameter = 63 GB at 4B: a rounding error in 288
     GB of HBM3E, and it keeps `state_dict()` in the reference's layout); each rank simply never reads or writes the
-    slices it does not own, and `FP16_Optimizer.state_dict()` refreshes them with one all-gather before saving."""
+    slices it does not own, and `FP16_Optimizer.consolidate_state()` (a collective, called by `utils.save_checkpoint` on
+    every rank) refreshes them with one all-gather per buffer before saving."""
 
     ALIGN = 128
 

@@ -69,6 +69,8 @@ def save_checkpoint(iteration, model, optimizer, lr_scheduler, args):
     if getattr(args, 'deepspeed', False):
         raise NotImplementedError("the DeepSpeed engine is not reproduced; checkpoints are written in the same layout")
     model = _unwrap(model)
+    if optimizer is not None and not getattr(args, 'no_save_optim', False) and hasattr(optimizer, 'consolidate_state'):
+        optimizer.consolidate_state()        # collective: sharded optimizer state -> full state on every rank
     if _dp_rank() == 0:
         name = get_checkpoint_name(args.save, iteration)
         print('global rank {} is saving checkpoint at iteration {:7d} to {}'.format(_global_rank(), iteration, name))

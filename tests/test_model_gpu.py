@@ -778,7 +778,8 @@ def _dp2_shard_worker(rank, world, port, golden_dir, ret):
             parts = [torch.empty_like(flat) for _ in range(world)]
             dist.all_gather(parts, flat)
             assert torch.equal(parts[0], parts[1]), f"replicas diverged (shard_optimizer={shard})"
-            sd = opt.state_dict()                                          # gathers the slices the other rank owns
+            opt.consolidate_state()                                        # collective: gathers the slices the other rank owns
+            sd = opt.state_dict()
             master = opt._master_flat.detach().cpu()
             mparts = [torch.empty_like(master) for _ in range(world)]
             dist.all_gather(mparts, master)
