@@ -467,12 +467,14 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
     if mp == 1:
         ao = ops.gemm(att.view(rows, hp), att_m.dense.weight, bias=att_m.dense.bias, dropout=d_ao, absmax=slot_ao)
     else:
-        ao = ops.gemm(att.view(rows, hp), att_m.dense.weight, bias=att_m.dense.bias if rank == 0 else None)
+        # model parallel: hidden dropout is linear per element and its mask depends only on (seed, stream, element index)
+        # of the DEFAULT state, which is the same on every rank of a model-parallel group -- so bias (once) + dropout
+        # ride in each rank's GEMM epilogue and the all-reduce sums already-dropped partials:
+        # mask*(A + B + bias) = mask*(A + bias) + mask*B.  What must follow the reduce is only the abs-max of the sum
+        # (a read-only pass; the reference's order is dropout(all_reduce(.) + bias), mpu/layers.py:312-326)
+        ao = ops.gemm(att.view(rows, hp), att_m.dense.weight, bias=att_m.dense.bias if rank == 0 else None, dropout=d_ao)
         _mp_allreduce(ao)
-        if d_ao is not None:
-            ao = ops.dropout(ao, *d_ao, absmax_out=slot_ao)
-        else:
-            ops.absmax(ao, slot_ao)
+        ops.absmax(ao, slot_ao)
     slot_y = ops.new_absmax_slot(dev)
     y, m3, r3 = ops.sandwich_ln_fwd(ao.view(b, s, h), layer.third_layernorm.weight, layer.third_layernorm.bias, eps,
                                     slot_ao, residual=x, absmax_out=slot_y, save_stats=keep is not None)
@@ -486,12 +488,9 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
     if mp == 1:
         mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias, dropout=d_mo, absmax=slot_mo)
     else:
-        mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias if rank == 0 else None)
+        mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias if rank == 0 else None, dropout=d_mo)
         _mp_allreduce(mo)
-        if d_mo is not None:
-            mo = ops.dropout(mo, *d_mo, absmax_out=slot_mo)
-        else:
-            ops.absmax(mo, slot_mo)
+        ops.absmax(mo, slot_mo)
     slot_out = ops.new_absmax_slot(dev)
     out, m4, r4 = ops.sandwich_ln_fwd(mo.view(b, s, h), layer.fourth_layernorm.weight, layer.fourth_layernorm.bias,
                                       eps, slot_mo, residual=y, absmax_out=slot_out, save_stats=keep is not None)

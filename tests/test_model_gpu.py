@@ -396,8 +396,13 @@ def _tp_build_and_run(dtype=torch.float16):
     from cogview_amd.model import GPT2Model
     c = _TP_CFG
     torch.manual_seed(4321)
-    m = GPT2Model(c["L"], c["V"], c["H"], c["NH"], 0.0, 0.0, 0.0, c["S"] + 1, 0, False)
+    mpu.model_parallel_cuda_manual_seed(4321)      # the default dropout state is the same on every model-parallel rank
+    # hidden (output) dropout ON: its masks are identical across the model-parallel group, so the sharded model must
+    # still reproduce the unsharded one (the row-parallel layers drop their partial sums BEFORE the all-reduce);
+    # attention dropout stays off (its streams differ per rank by design, mpu/random.py:198-233)
+    m = GPT2Model(c["L"], c["V"], c["H"], c["NH"], 0.0, 0.0, 0.1, c["S"] + 1, 0, False)
     model = FP16_Module(m.cuda(), dtype=dtype, keep_half_outputs=True)
+    model.train()
     g = torch.Generator().manual_seed(11)
     tokens = torch.randint(0, c["V"], (c["B"], c["S"]), generator=g).cuda()
     labels = torch.randint(0, c["V"], (c["B"], c["S"]), generator=g).cuda()
