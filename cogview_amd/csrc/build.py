@@ -52,7 +52,8 @@ def _deps_mtime():
 
 # Kernels that issue LDS reads through inline asm and wait for them in a LATER statement: a compiler spill of
 # the destination register between the two would store garbage.  They must be spill-free.
-NO_SPILL_KERNELS = ("attn_fwd_kernel", "attn_bwd_dq_kernel", "gemm_glds_kernel", "gemm_pp64_kernel", "gemm_w4_kernel")
+NO_SPILL_KERNELS = ("attn_fwd_kernel", "attn_bwd_dq_kernel", "gemm_glds_kernel", "gemm_pp64_kernel", "gemm_w4_kernel",
+                    "conv_kernel", "vq_argmin_kernel")
 
 
 def _scratch_in_mfma_loops(src, extra=()):
@@ -106,6 +107,75 @@ def _scratch_in_mfma_loops(src, extra=()):
     return bad
 
 
+def asm_load_hazards(src, kernels=("conv_kernel", "vq_argmin_kernel"), extra=()):
+    """Kernels that issue global loads through inline asm (untracked by the compiler) and wait for them with a counted
+    s_waitcnt in a later asm statement: return [(kernel, line, text)] for every instruction that READS a destination
+    register of such a load while the load may still be in flight (a register copy the compiler placed in front of the
+    wait -- seen once at a control-flow join -- silently feeds stale data).  Linear scan in layout order: the asm loads
+    of a kernel are tracked oldest first, `s_waitcnt vmcnt(N)` retires all but the N youngest, labels do not reset
+    the state (conservative)."""
+    import re, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        r = subprocess.run([_hipcc()] + FLAGS + list(extra) + ["--cuda-device-only", "-S", src, "-o", asm], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
+        lines = open(asm).read().splitlines()
+
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+
+    out, func, in_asm, flight = [], None, False, []
+    for i, ln in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            func, flight = (m.group(1) if any(k in m.group(1) for k in kernels) else None), []
+            if func and re.search(r"ELi[1-9]\d*EEEv", func):      # timing probes (COGV_CONV_EXP): wrong results by design
+                func = None
+            continue
+        if func is None:
+            continue
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith((";", ".")) or t.endswith(":"):
+            continue
+        op, _, rest = t.partition(" ")
+        toks = [x.strip() for x in rest.split(",")]
+        if in_asm and op.startswith("global_load"):
+            flight.append(regs(toks[0]))
+            continue
+        m = re.match(r"s_waitcnt\s+vmcnt\((\d+)\)", t)
+        if m:
+            n = int(m.group(1))
+            flight = flight[len(flight) - n:] if n < len(flight) else flight
+            if n == 0:
+                flight = []
+            continue
+        if op.startswith("s_waitcnt") and "vmcnt" in t:
+            flight = []
+            continue
+        if not flight or op.startswith(("s_", "ds_write")) and not op.startswith("ds_"):
+            pass
+        pending = set().union(*flight) if flight else set()
+        if pending:
+            srcs = set()
+            for tok in toks[1:] if not op.startswith(("ds_write", "global_store", "buffer_store")) else toks:
+                srcs |= regs(tok)
+            hit = srcs & pending
+            if hit:
+                out.append((func, i + 1, t))
+    return out
+
+
 def _check_no_spill(src, log, extra=()):
     import re
     name, spilling = None, []
@@ -128,6 +198,11 @@ def _compile(src, obj, extra=()):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if os.path.basename(src) == "conv.hip":
+        hz = asm_load_hazards(src, extra=extra)
+        if hz:
+            raise RuntimeError(f"{src}: a register of an in-flight asm load is read before its s_waitcnt:\n" +
+                               "\n".join(f"  {k} line {n}: {t}" for k, n, t in hz[:10]))
     _check_no_spill(src, r.stderr, extra)
     return obj
 

@@ -68,6 +68,15 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ void ld4_async(f32x4& dst, const float* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
 }
+// all asynchronous loads retired; the operands tie BOTH register sets to the wait, so that the compiler cannot reuse
+// a register an in-flight load still targets (found by build.py's asm_load_hazards: the epilogue's address arithmetic
+// had been scheduled into those registers in front of a bare s_waitcnt)
+__device__ __forceinline__ void drain_loads(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4], f32x4 (&d)[4]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                 "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+               : : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_loads(f32x4 (&a)[4], f32x4 (&b)[4]) {
   asm volatile("s_waitcnt vmcnt(%8)"
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(NT, 2) void conv_kernel(const ConvArgs p) {
     step(kt, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0);
     if (kt + 1 < nk) step(kt + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, 32768);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped loads of the last iteration
+  drain_loads(ra[0], rb[0], ra[1], rb[1]);               // the clamped loads of the last iteration
   float* ct = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
