@@ -107,20 +107,17 @@ def _scratch_in_mfma_loops(src, extra=()):
     return bad
 
 
-def asm_load_hazards(src, kernels=("conv_kernel", "vq_argmin_kernel"), extra=()):
-    """Kernels that issue global loads through inline asm (untracked by the compiler) and wait for them with a counted
-    s_waitcnt in a later asm statement: return [(kernel, line, text)] for every instruction that READS a destination
-    register of such a load while the load may still be in flight (a register copy the compiler placed in front of the
-    wait -- seen once at a control-flow join -- silently feeds stale data).  Linear scan in layout order: the asm loads
-    of a kernel are tracked oldest first, `s_waitcnt vmcnt(N)` retires all but the N youngest, labels do not reset
-    the state (conservative)."""
-    import re, tempfile
-    with tempfile.TemporaryDirectory() as td:
-        asm = os.path.join(td, "k.s")
-        r = subprocess.run([_hipcc()] + FLAGS + list(extra) + ["--cuda-device-only", "-S", src, "-o", asm], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
-        lines = open(asm).read().splitlines()
+def scan_asm_hazards(lines):
+    """Static check of a unit's device assembly for the one thing the compiler cannot know about the hand-issued
+    asynchronous operations of these kernels: loads issued inside inline asm (global_load_* into registers, ds_read_*)
+    whose result is awaited by a LATER `s_waitcnt` (asm, counted).  Returns [(kernel, line, text)] for every instruction
+    that reads a destination register of such a load while it may still be in flight -- e.g. a register copy the
+    compiler placed in front of the wait at a control-flow join, or an epilogue that reuses the registers before a bare
+    wait: both silently compute on stale data (the first shipped for an hour in round 2 and only failed when other tests
+    had warmed the clocks).  Linear scan in layout order per kernel: asm loads are tracked oldest first per counter
+    (vmcnt / lgkmcnt); `s_waitcnt <cnt>(N)` retires all but the N youngest; labels do not reset the state.
+    Timing-probe instantiations (COGV_CONV_EXP: wrong results by design) are skipped."""
+    import re
 
     def regs(tok):
         m = re.match(r"v\[(\d+):(\d+)\]", tok)
@@ -129,12 +126,13 @@ def asm_load_hazards(src, kernels=("conv_kernel", "vq_argmin_kernel"), extra=())
         m = re.match(r"v(\d+)$", tok)
         return {int(m.group(1))} if m else set()
 
-    out, func, in_asm, flight = [], None, False, []
+    out, func, in_asm = [], None, False
+    flight = {"vmcnt": [], "lgkmcnt": []}
     for i, ln in enumerate(lines):
         m = re.match(r"^(_Z\w+):", ln)
         if m:
-            func, flight = (m.group(1) if any(k in m.group(1) for k in kernels) else None), []
-            if func and re.search(r"ELi[1-9]\d*EEEv", func):      # timing probes (COGV_CONV_EXP): wrong results by design
+            func, flight = m.group(1), {"vmcnt": [], "lgkmcnt": []}
+            if re.search(r"conv_kernelILb[01]ELi[1-9]\d*EEEv", func):
                 func = None
             continue
         if func is None:
@@ -150,30 +148,41 @@ def asm_load_hazards(src, kernels=("conv_kernel", "vq_argmin_kernel"), extra=())
             continue
         op, _, rest = t.partition(" ")
         toks = [x.strip() for x in rest.split(",")]
-        if in_asm and op.startswith("global_load"):
-            flight.append(regs(toks[0]))
+        if in_asm and op.startswith("global_load") and not op.startswith("global_load_lds"):
+            flight["vmcnt"].append(regs(toks[0]))
             continue
-        m = re.match(r"s_waitcnt\s+vmcnt\((\d+)\)", t)
-        if m:
-            n = int(m.group(1))
-            flight = flight[len(flight) - n:] if n < len(flight) else flight
-            if n == 0:
-                flight = []
+        if in_asm and op.startswith("ds_read"):
+            flight["lgkmcnt"].append(regs(toks[0]))
             continue
-        if op.startswith("s_waitcnt") and "vmcnt" in t:
-            flight = []
+        if op.startswith("s_waitcnt"):
+            for cnt in ("vmcnt", "lgkmcnt"):
+                m = re.search(cnt + r"\((\d+)\)", t)
+                if m:
+                    n = int(m.group(1))
+                    flight[cnt] = flight[cnt][len(flight[cnt]) - n:] if 0 < n < len(flight[cnt]) else ([] if n == 0 else flight[cnt])
             continue
-        if not flight or op.startswith(("s_", "ds_write")) and not op.startswith("ds_"):
-            pass
-        pending = set().union(*flight) if flight else set()
+        pending = set()
+        for fl in flight.values():
+            for r in fl:
+                pending |= r
         if pending:
             srcs = set()
-            for tok in toks[1:] if not op.startswith(("ds_write", "global_store", "buffer_store")) else toks:
+            for tok in (toks if op.startswith(("ds_write", "global_store", "buffer_store", "global_atomic")) else toks[1:]):
                 srcs |= regs(tok)
-            hit = srcs & pending
-            if hit:
+            if srcs & pending:
                 out.append((func, i + 1, t))
     return out
+
+
+def asm_load_hazards(src, extra=()):
+    """scan_asm_hazards() of one source compiled on its own (tools / tests)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        r = subprocess.run([_hipcc()] + FLAGS + list(extra) + ["--cuda-device-only", "-S", src, "-o", asm], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
+        return scan_asm_hazards(open(asm).read().splitlines())
 
 
 def _check_no_spill(src, log, extra=()):
@@ -194,15 +203,21 @@ def _check_no_spill(src, log, extra=()):
 
 
 def _compile(src, obj, extra=()):
-    cmd = [_hipcc()] + FLAGS + list(extra) + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-    if os.path.basename(src) == "conv.hip":
-        hz = asm_load_hazards(src, extra=extra)
+    import glob, tempfile
+    # -save-temps=obj leaves the device assembly next to the object (no second compile): it feeds scan_asm_hazards
+    with tempfile.TemporaryDirectory(dir=os.path.dirname(obj)) as td:
+        tobj = os.path.join(td, os.path.basename(obj))
+        cmd = [_hipcc()] + FLAGS + list(extra) + ["-Rpass-analysis=kernel-resource-usage", "-save-temps=obj", "-c", src, "-o", tobj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        hz = []
+        for asm in glob.glob(os.path.join(td, "*amdgcn*.s")):
+            hz += scan_asm_hazards(open(asm).read().splitlines())
         if hz:
             raise RuntimeError(f"{src}: a register of an in-flight asm load is read before its s_waitcnt:\n" +
                                "\n".join(f"  {k} line {n}: {t}" for k, n, t in hz[:10]))
+        os.replace(tobj, obj)
     _check_no_spill(src, r.stderr, extra)
     return obj
 

@@ -61,3 +61,29 @@ def test_product_path_has_no_cpu_fallback():
         for f in fs:
             if f.endswith(".py"):
                 assert "oracle" not in open(os.path.join(dp, f)).read().replace("oracle/", ""), os.path.join(dp, f)
+
+
+def test_build_flags_reads_of_in_flight_asm_loads():
+    """cogview_amd/csrc/build.py::scan_asm_hazards on hand-written assembly: a copy of an asm load's destination in front
+    of its s_waitcnt is reported, the same copy behind the wait is not, counted waits retire the oldest loads only, and
+    LDS reads (lgkmcnt) are tracked separately from global loads (vmcnt)."""
+    from cogview_amd.csrc.build import scan_asm_hazards
+
+    def asm(*body):
+        return ["_ZN4testE:"] + ["\t" + b for b in body] + [".Lfunc_end0:"]
+    load = lambda dst, addr: [";;#ASMSTART", f"global_load_dwordx4 {dst}, {addr}, off", ";;#ASMEND"]
+    wait = lambda n: [";;#ASMSTART", f"s_waitcnt vmcnt({n})", ";;#ASMEND"]
+    bad = asm(*load("v[2:5]", "v[20:21]"), "v_mov_b64_e32 v[30:31], v[4:5]", *wait(0))
+    assert [h[2] for h in scan_asm_hazards(bad)] == ["v_mov_b64_e32 v[30:31], v[4:5]"]
+    good = asm(*load("v[2:5]", "v[20:21]"), *wait(0), "v_mov_b64_e32 v[30:31], v[4:5]")
+    assert scan_asm_hazards(good) == []
+    # two loads, vmcnt(1): the older one is retired, the younger one is still in flight
+    two = asm(*load("v[2:5]", "v[20:21]"), *load("v[6:9]", "v[22:23]"), *wait(1), "v_add_f32_e32 v40, v2, v3", "v_add_f32_e32 v41, v6, v7")
+    assert [h[2] for h in scan_asm_hazards(two)] == ["v_add_f32_e32 v41, v6, v7"]
+    # an LDS read issued through asm is retired by lgkmcnt, not by vmcnt
+    lds = asm(";;#ASMSTART", "ds_read_b64_tr_b16 v[10:11], v50", ";;#ASMEND", "s_waitcnt vmcnt(0)", "v_mov_b32_e32 v60, v10",
+              "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v61, v11")
+    assert [h[2] for h in scan_asm_hazards(lds)] == ["v_mov_b32_e32 v60, v10"]
+    # using an in-flight destination as a STORE source is a read too; writing an unrelated register is fine
+    st = asm(*load("v[2:5]", "v[20:21]"), "ds_write_b128 v70, v[2:5]", "v_mov_b32_e32 v80, v81", *wait(0))
+    assert [h[2] for h in scan_asm_hazards(st)] == ["ds_write_b128 v70, v[2:5]"]
