@@ -623,3 +623,44 @@ def test_attention_decode_step(ops, dtype, b, H, cap, pos):
     assert rel(out, ref) < TOL[dtype]
     again = ops.attention_decode(qkv_d, cache_d, pos_d, H)
     assert torch.equal(out, again)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,N,post,gelu", [(1, 512, 768, False, False), (3, 1024, 512, True, True), (8, 2560, 1024, True, False),
+                                              (2, 4096, 256, True, True), (5, 512, 64, False, True)])
+def test_gemv_with_layernorm_prologue(ops, dtype, M, K, N, post, gelu):
+    """cogv_gemv_ln == the unfused chain of the same library (Sandwich-LN kernels, then the GEMV with the same epilogue)
+    and the oracle's definition (mpu/sparse_transformer.py:326-341): t = residual + LN_post(z), x_in = LN_pre(t),
+    out = [gelu](x_in W^T + b); every row count bucket of the kernel (1, 2, 4, 8 with padding rows), the residual stream
+    written once, the output abs-max slot."""
+    g = torch.Generator().manual_seed(M * 100 + K + N)
+    z, res = rnd((M, K), dtype, g, 3.0), rnd((M, K), dtype, g)
+    w, bias = rnd((N, K), dtype, g, 0.05), rnd((N,), dtype, g)
+    gp, bp = (1.0 + 0.1 * torch.randn(K, generator=g)).to(dtype), (0.1 * torch.randn(K, generator=g)).to(dtype)
+    gn, bn = (1.0 + 0.1 * torch.randn(K, generator=g)).to(dtype), (0.1 * torch.randn(K, generator=g)).to(dtype)
+    eps = 1e-5
+    zd, resd = dev(z), dev(res)
+    zmax = ops.absmax(zd)
+    # unfused chain on the GPU
+    if post:
+        slot_t = ops.new_absmax_slot(zd.device)
+        t_ref, _, _ = ops.sandwich_ln_fwd(zd, dev(gp), dev(bp), eps, zmax, residual=resd, absmax_out=slot_t, save_stats=False)
+    else:
+        t_ref, slot_t = zd, zmax
+    x_ref, _, _ = ops.sandwich_ln_fwd(t_ref, dev(gn), dev(bn), eps, slot_t, save_stats=False)
+    slot_ref = ops.new_absmax_slot(zd.device)
+    out_ref = ops.gemm(x_ref, dev(w), bias=dev(bias), gelu=gelu, absmax=slot_ref)
+    slot = ops.new_absmax_slot(zd.device)
+    out, t = ops.gemv_ln(zd, dev(w), dev(bias), dev(gn), dev(bn), eps, z_absmax=zmax, post=(dev(gp), dev(bp)) if post else None,
+                         residual=resd if post else None, want_t=post, gelu=gelu, absmax=slot)
+    if post:
+        assert torch.equal(t, t_ref), "the residual stream written by workgroup 0 must equal the LayerNorm kernel's"
+    assert rel(out, out_ref.float().cpu()) < 2e-3 if dtype == torch.float16 else rel(out, out_ref.float().cpu()) < 1.5e-2
+    assert abs(slot.item() - slot_ref.item()) <= 2e-2 * max(1.0, slot_ref.item())
+    # oracle definition
+    tf = (res.float() + O.sandwich_layernorm(z.float(), gp.float(), bp.float(), eps).to(dtype).float()).to(dtype).float() if post else z.float()
+    xin = O.sandwich_layernorm(tf, gn.float(), bn.float(), eps).to(dtype).float()
+    ref = O.linear(xin, w.float(), bias.float())
+    if gelu:
+        ref = O.gelu(ref.to(dtype).float())
+    assert rel(out, ref) < TOL[dtype]
