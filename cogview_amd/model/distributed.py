@@ -145,7 +145,9 @@ class DistributedDataParallel(Module):
         # (an optimizer that set .grad = None makes backward allocate loose tensors the exchange would never see)
         esz = self.arena.grad.element_size()
         base = self.arena.grad.data_ptr()
-        for p, off in zip(self.arena.params, self.arena.offsets):
+        self._alias_calls = getattr(self, "_alias_calls", 0) + 1
+        # (772 parameters at 48 layers: checked on the first steps and then every 64th, not 772 pointer reads per step)
+        for p, off in (zip(self.arena.params, self.arena.offsets) if (self._alias_calls <= 2 or self._alias_calls % 64 == 0) else ()):
             if p.grad is not None and p.grad.data_ptr() != base + off * esz:
                 self.arena.grad[off:off + p.numel()].view(p.shape).copy_(p.grad)
                 p.grad = self.arena.grad[off:off + p.numel()].view(p.shape)
