@@ -572,8 +572,8 @@ class _DeferredWeightGrads:
     Measured at 4B: one layer per launch is 1200 tiles = 4.7 rounds of the 256 CUs (6 % lost in the partial last
     round) at 1328 TFLOP/s (generation-4 GEMM; 1207 with generation 3); four layers per launch (18.75 rounds, 1.3 %
     tail) ran at 1267 (1136) TFLOP/s -- a 13 ms uninterrupted GEMM sits at the sustained power limit, while 3 ms
-    launches separated by the lighter LN / attention kernels clock higher.  Hence the default of 1
-    (COGV_WGRAD_GROUP_LAYERS overrides it for experiments)."""
+    launches separated by the lighter LN / attention kernels clock higher.  Hence one layer per launch whenever a layer
+    fills the chip (wgrad_group_layers; COGV_WGRAD_GROUP_LAYERS overrides it for experiments)."""
     __slots__ = ("problems", "callbacks")
 
     def __init__(self):
@@ -581,8 +581,33 @@ class _DeferredWeightGrads:
 
 
 import os as _os
-WGRAD_GROUP_LAYERS = int(_os.environ.get("COGV_WGRAD_GROUP_LAYERS", "1"))
+WGRAD_GROUP_LAYERS = int(_os.environ.get("COGV_WGRAD_GROUP_LAYERS", "0"))       # 0: by tile count (wgrad_group_layers)
 _WGRADS = _DeferredWeightGrads()
+_WGRAD_GROUP_CACHE = {}
+
+
+def wgrad_group_layers(layer):
+    """Layers whose weight gradients share one grouped launch.  A layer's four problems are sum(ceil(out/256) *
+    ceil(in/256)) tiles of 256 x 256: 1200 at the 4B width (4.7 rounds of the 256 CUs: one layer per launch measured
+    best, see _DeferredWeightGrads), 192 at the 336M width -- less than one round, which forces split-K slabs and a
+    reduce pass; four layers together are 768 tiles = 3.0 rounds without either (measured at 336M: weight-gradient
+    launches 1274 -> 1512 TFLOP/s, step 95.8 -> 94.4 ms).  Rule: the smallest group of 1, 2 or 4 layers (16 problems per
+    launch is the kernel's limit) that fills at least 2.5 rounds."""
+    if WGRAD_GROUP_LAYERS > 0:
+        return WGRAD_GROUP_LAYERS
+    w = layer.mlp.dense_h_to_4h.weight
+    key = (w.shape, layer.attention.query_key_value.weight.shape)
+    g = _WGRAD_GROUP_CACHE.get(key)
+    if g is None:
+        tiles = 0
+        for lin in (layer.mlp.dense_h_to_4h, layer.mlp.dense_4h_to_h, layer.attention.dense, layer.attention.query_key_value):
+            o, i = lin.weight.shape
+            tiles += ((o + 255) // 256) * ((i + 255) // 256)
+        g = 1
+        while g < 4 and g * tiles < 640:
+            g *= 2
+        _WGRAD_GROUP_CACHE[key] = g
+    return g
 
 
 def flush_weight_grads():
@@ -620,7 +645,7 @@ class _TransformerLayer(torch.autograd.Function):
         ctx.keep = None
         if ctx.done_cb is not None:
             _WGRADS.callbacks.append((ctx.done_cb, ctx.layer))
-        if getattr(ctx.layer, "_cogv_index", 0) % WGRAD_GROUP_LAYERS == 0:
+        if getattr(ctx.layer, "_cogv_index", 0) % wgrad_group_layers(ctx.layer) == 0:
             flush_weight_grads()
         return dx, None, None, None, None, None, None
 
