@@ -260,8 +260,8 @@ def sparse_attention_inference(q, k, v, pivot_and_window_idx, **kwargs):
     sq keys -- attend the gathered pivot + window keys, causally among themselves.  [b, np, s, hn] tensors, index
     [b, n_pivot_and_window]; inference only (no gradient).  The gather happens inside the attention kernel."""
     if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
-        raise NotImplementedError("sparse_attention_inference is forward-only (SURVEY.md section 8f: the sparse "
-                                  "training path is not implemented yet)")
+        raise NotImplementedError("sparse_attention_inference is the forward-only generation form (mpu/sparse_transformer.py:"
+                                  "727-750); training uses sparse_attention (the slot-space form, with gradients)")
     idx = pivot_and_window_idx.to(torch.int32).contiguous()
     assert int(idx.max()) < k.shape[2] and int(idx.min()) >= 0
     o, _ = ops.attention_fwd(_as_bshd(q), _as_bshd(k), _as_bshd(v), sep=0, dropout=None, kv_index=idx)

@@ -311,3 +311,23 @@ def test_annealing_lr_matches_reference_golden(golden_dir):
             lrs.append(o.param_groups[1]['lr'])
         assert np.array_equal(np.array(lrs), z[style]), style
         assert s.state_dict()['num_iters'] == int(z[style + "_sd_num_iters"]) and s.state_dict()['decay_ratio'] == float(z[style + "_decay_ratio"])
+
+
+def test_weight_gradient_grouping_rule():
+    """functional.wgrad_group_layers: the smallest group of 1, 2 or 4 layers whose 256 x 256 weight-gradient tiles fill at
+    least 2.5 rounds of the 256 CUs -- one layer per launch at the 4B width (1200 tiles), four at the 336M width
+    (192 tiles per layer: 768 = 3.0 rounds), never more than the grouped launch's 16 problems."""
+    import types
+    import torch
+    from cogview_amd import functional as F_
+
+    def fake_layer(h):
+        lin = lambda o, i: types.SimpleNamespace(weight=torch.empty(o, i, device="meta"))
+        return types.SimpleNamespace(mlp=types.SimpleNamespace(dense_h_to_4h=lin(4 * h, h), dense_4h_to_h=lin(h, 4 * h)),
+                                     attention=types.SimpleNamespace(dense=lin(h, h), query_key_value=lin(3 * h, h)))
+    if F_.WGRAD_GROUP_LAYERS == 0:
+        assert F_.wgrad_group_layers(fake_layer(2560)) == 1
+        assert F_.wgrad_group_layers(fake_layer(1024)) == 4
+        assert F_.wgrad_group_layers(fake_layer(2048)) == 1          # 768 tiles per layer
+        assert F_.wgrad_group_layers(fake_layer(1536)) == 2          # 432 tiles per layer
+        assert F_.wgrad_group_layers(fake_layer(256)) == 4           # capped: 4 layers x 4 problems = 16
