@@ -50,61 +50,26 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-# Kernels that issue LDS reads through inline asm and wait for them in a LATER statement: a compiler spill of
-# the destination register between the two would store garbage.  They must be spill-free.
+# Kernels that issue loads through inline asm and wait for them in a LATER statement: a compiler spill of the
+# destination register between the two would store garbage.  They must not spill vector registers at all (a scratch
+# ARRAY -- the generic epilogue's -- is tolerated where no asm load is in flight: scan_asm_hazards checks that).
 NO_SPILL_KERNELS = ("attn_fwd_kernel", "attn_bwd_dq_kernel", "gemm_glds_kernel", "gemm_pp64_kernel", "gemm_w4_kernel",
                     "conv_kernel", "vq_argmin_kernel")
 
 
-def _scratch_in_mfma_loops(src, extra=()):
-    """Compile `src` to device assembly and return the kernels that touch scratch INSIDE an innermost loop
-    containing MFMAs (the k-loop, where the asynchronous asm LDS reads live).  A spill outside it -- e.g. a value
-    parked across the persistent tile loop and reloaded at the top of each item -- cannot sit between an asm read
-    and its wait, so it is tolerated."""
-    import re, tempfile
-    with tempfile.TemporaryDirectory() as td:
-        asm = os.path.join(td, "k.s")
-        r = subprocess.run([_hipcc()] + FLAGS + list(extra) + ["--cuda-device-only", "-S", src, "-o", asm], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
-        lines = open(asm).read().splitlines()
-    bad, func, start = [], None, 0
-    bounds = []
-    for i, ln in enumerate(lines):
-        m = re.match(r"^(_Z\w+):", ln)
+def _check_no_spill(src, log):
+    import re
+    name, spilling = None, []
+    for line in log.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
         if m:
-            if func:
-                bounds.append((func, start, i))
-            func, start = m.group(1), i
-    if func:
-        bounds.append((func, start, len(lines)))
-    for func, a, b in bounds:
-        if not any(k in func for k in NO_SPILL_KERNELS):
-            continue
-        body = lines[a:b]
-        labels = {}
-        for i, ln in enumerate(body):
-            m = re.match(r"^(\.LBB\d+_\d+):", ln)
-            if m:
-                labels[m.group(1)] = i
-        loops = []          # (head, backedge) line intervals
-        for j, ln in enumerate(body):
-            m = re.search(r"\bs_cbranch_\w+\s+(\.LBB\d+_\d+)|\bs_branch\s+(\.LBB\d+_\d+)", ln)
-            if m:
-                tgt = labels.get(m.group(1) or m.group(2))
-                if tgt is not None and tgt < j:
-                    loops.append((tgt, j))
-        mfma = [i for i, ln in enumerate(body) if "v_mfma" in ln]
-        inner = set()
-        for i in mfma:
-            enclosing = [(h, e) for h, e in loops if h < i < e]
-            if enclosing:
-                inner.add(min(enclosing, key=lambda he: he[1] - he[0]))
-        for h, e in inner:
-            if any("scratch_" in ln for ln in body[h:e + 1]):
-                bad.append(func)
-                break
-    return bad
+            name = m.group(1)
+        m = re.search(r"VGPRs Spill: (\d+)", line)
+        if m and name and any(k in name for k in NO_SPILL_KERNELS) and int(m.group(1)) != 0:
+            spilling.append((name, m.group(1)))
+    if spilling:
+        raise RuntimeError(f"{src}: kernel(s) {spilling} issue asynchronous asm loads and spill vector registers: "
+                           f"unsafe, refusing to build")
 
 
 def scan_asm_hazards(lines):
@@ -169,7 +134,9 @@ def scan_asm_hazards(lines):
             srcs = set()
             for tok in (toks if op.startswith(("ds_write", "global_store", "buffer_store", "global_atomic")) else toks[1:]):
                 srcs |= regs(tok)
-            if srcs & pending:
+            # a scratch access while asm loads are in flight is the compiler spilling around them (the k-loops keep
+            # asm reads in flight all the time): refuse it whatever registers it names
+            if srcs & pending or op.startswith("scratch_"):
                 out.append((func, i + 1, t))
     return out
 
@@ -183,23 +150,6 @@ def asm_load_hazards(src, extra=()):
         if r.returncode != 0:
             raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr}")
         return scan_asm_hazards(open(asm).read().splitlines())
-
-
-def _check_no_spill(src, log, extra=()):
-    import re
-    name, spilling = None, []
-    for line in log.splitlines():
-        m = re.search(r"Function Name: (\S+)", line)
-        if m:
-            name = m.group(1)
-        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
-        if m and name and any(k in name for k in NO_SPILL_KERNELS) and int(m.group(1)) != 0:
-            spilling.append((name, m.group(1)))
-    if spilling:
-        bad = _scratch_in_mfma_loops(src, extra)
-        if bad:
-            raise RuntimeError(f"{src}: kernel(s) {bad} use asynchronous asm LDS reads and spill registers inside the "
-                               f"MFMA loop: unsafe, refusing to build")
 
 
 def _compile(src, obj, extra=()):
@@ -218,7 +168,7 @@ def _compile(src, obj, extra=()):
             raise RuntimeError(f"{src}: a register of an in-flight asm load is read before its s_waitcnt:\n" +
                                "\n".join(f"  {k} line {n}: {t}" for k, n, t in hz[:10]))
         os.replace(tobj, obj)
-    _check_no_spill(src, r.stderr, extra)
+    _check_no_spill(src, r.stderr)
     return obj
 
 

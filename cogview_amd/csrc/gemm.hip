@@ -142,6 +142,14 @@ __device__ __forceinline__ typename HT<T>::v8 read_frag(const char* lds, int row
 // ---- fused epilogue on 8 consecutive columns of one row (fp32 in registers)
 //      F >= 0: the flag mask is a compile-time constant and the output is 16-bit (the generation-3 kernel dispatches
 //      the hot combinations to such instances so that one item's epilogue is a few KB of code, not all paths).
+// 16-byte accesses through EXPLICIT global-address-space pointers: the epilogues take their pointers from a descriptor
+// copy pinned in scalar registers (pp64_epilogue), which hides the pointers' origin from address-space inference --
+// a generic pointer would compile to flat_load / flat_store, which also count on the LDS counter
+#define COGV_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ u32x4 gload16(const void* q) { return *(const COGV_GLOBAL u32x4*)q; }
+__device__ __forceinline__ void gstore16(void* q, u32x4 v) { *(COGV_GLOBAL u32x4*)q = v; }
+__device__ __forceinline__ void gstore16(float* q, f32x4 v) { *(COGV_GLOBAL f32x4*)q = v; }
+
 template <typename T, int F = -1>
 //      bias_pre / aux_pre / c_pre: values the caller already loaded (the generation-3 epilogue issues all of a
 //      sub-tile's dGeLU / accumulate reads up front instead of one exposed global-load latency per pass).
@@ -150,7 +158,7 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
   const int flags = F >= 0 ? F : p.flags;
   const bool out_f32 = F >= 0 ? false : (p.out_f32 != 0);
   if (flags & COGV_EPI_BIAS) {
-    u32x4 bv = bias_pre ? *bias_pre : *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
+    u32x4 bv = bias_pre ? *bias_pre : gload16(reinterpret_cast<const T*>(p.bias) + n);
     float b[8]; unpack8<T>(bv, b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += b[i];
@@ -166,21 +174,21 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
       float gd[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) gelu_and_grad_f(v[i], v[i], gd[i]);
-      if (p.aux) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n) = pack8<T>(gd);
+      if (p.aux) gstore16(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n, pack8<T>(gd));
     } else {
-      if (p.aux) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n) = rv;
+      if (p.aux) gstore16(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n, rv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
     }
   }
   if (flags & COGV_EPI_DGELU) {
-    u32x4 uv = aux_pre ? *aux_pre : *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
+    u32x4 uv = aux_pre ? *aux_pre : gload16(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
     float u[8]; unpack8<T>(uv, u);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(u[i]);
   }
   if (flags & COGV_EPI_MULAUX) {
-    u32x4 uv = aux_pre ? *aux_pre : *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
+    u32x4 uv = aux_pre ? *aux_pre : gload16(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
     float u[8]; unpack8<T>(uv, u);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= u[i];
@@ -193,11 +201,11 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
   }
   if (flags & COGV_EPI_ACCUM) {
     if (out_f32) {
-      const float* c = reinterpret_cast<const float*>(p.C) + (size_t)m * p.ldc + n;
+      const COGV_GLOBAL float* c = (const COGV_GLOBAL float*)(reinterpret_cast<const float*>(p.C) + (size_t)m * p.ldc + n);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += c[i];
     } else {
-      u32x4 cv = c_pre ? *c_pre : *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n);
+      u32x4 cv = c_pre ? *c_pre : gload16(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n);
       float c[8]; unpack8<T>(cv, c);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += c[i];
@@ -207,8 +215,8 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
   uint32_t amax_pk = 0u;
   if (out_f32) {
     float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-    *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    gstore16(c, f32x4{v[0], v[1], v[2], v[3]});
+    gstore16(c + 4, f32x4{v[4], v[5], v[6], v[7]});
     if (rounded) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) rounded[i] = v[i];
@@ -216,7 +224,7 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
     if (flags & COGV_EPI_ABSMAX) amax_pk = absmax_pk8(0u, pack8<T>(v));      // fp32 output: max taken on the 16-bit rounding
   } else {
     u32x4 o = pack8<T>(v);
-    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n) = o;
+    gstore16(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n, o);
     if (rounded) unpack8<T>(o, rounded);
     if (flags & COGV_EPI_ABSMAX) amax_pk = absmax_pk8(0u, o);
   }
@@ -738,11 +746,23 @@ void gemm_glds_kernel(const GemmArgs p) {
 //      l & 15, 4 columns at 4 (l >> 4)): transpose 8 rows at a time through the wave's private 2-KiB LDS strip into
 //      "8 lanes x 16 bytes = one 128-byte line per row" order, then epilogue8.  F: compile-time flag mask
 //      (-1: runtime flags / fp32 output, -2: split-K partial slab).
+// pin a wave-uniform value in scalar registers: opaque to the optimiser, so it cannot be rematerialised by re-reading the
+// kernel-argument segment at every use (an s_load + lgkmcnt(0) inside each of the epilogue's 32 passes otherwise)
+template <typename V> __device__ __forceinline__ void pin_s(V& x) { asm volatile("" : "+s"(x)); }
+
 template <typename T, int F>
-__device__ __forceinline__ void pp64_epilogue(const GemmArgs& p, f32x4 (&acc)[8][4], float* strip, int m_base, int n_base,
+__device__ __forceinline__ void pp64_epilogue(const GemmArgs& pg, f32x4 (&acc)[8][4], float* strip, int m_base, int n_base,
                                               int ksplit, int lane, uint32_t& amax_pk, int colsum_row) {
   const int l15 = lane & 15, kb = lane >> 4;
   if ((COGV_EXP & 2048) && acc[0][0][0] != 12345.f) return;      // probe: no strip transposition either
+  // the problem descriptor lives in the kernel-argument segment behind a run-time index: copy what this instance
+  // uses into pinned scalar registers once
+  GemmArgs p = pg;
+  pin_s(p.C); pin_s(p.M); pin_s(p.N); pin_s(p.ldc);
+  if (F < 0 || (F & (COGV_EPI_GELU | COGV_EPI_DGELU | COGV_EPI_MULAUX))) { pin_s(p.aux); pin_s(p.ldaux); }
+  if (F < 0 || (F & COGV_EPI_DROPOUT)) { pin_s(p.seed); pin_s(p.stream_id); pin_s(p.thr16); pin_s(p.keep_scale); }
+  if (F < 0) { pin_s(p.flags); pin_s(p.out_f32); pin_s(p.bias); }
+  if (F == -2) pin_s(p.ws);
   const bool want_cs = (F == -1) ? ((p.flags & COGV_EPI_COLSUM) != 0 && !p.out_f32) : (F >= 0 && (F & COGV_EPI_COLSUM));
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int sr = lane >> 3, sc = lane & 7;           // read side: strip row, 8-column group
@@ -750,52 +770,63 @@ __device__ __forceinline__ void pp64_epilogue(const GemmArgs& p, f32x4 (&acc)[8]
   // the same in every pass), the dGeLU pre-activations / the accumulate target for all 16 passes up front
   constexpr bool PRE_BIAS = F >= 0 && (F & COGV_EPI_BIAS), PRE_AUX = F >= 0 && (F & (COGV_EPI_DGELU | COGV_EPI_MULAUX)), PRE_C = F >= 0 && (F & COGV_EPI_ACCUM);
   u32x4 bias_v = {0u, 0u, 0u, 0u}, aux_v[PRE_AUX ? 16 : 1], c_v[PRE_C ? 16 : 1];
+  const int n = n_base + 8 * sc;
   {
-    const int n = n_base + 8 * sc;
-    if (PRE_BIAS && n < p.N) bias_v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bias) + n);
+    if (PRE_BIAS && n < p.N) bias_v = gload16(reinterpret_cast<const T*>(pg.bias) + n);
     if (PRE_AUX || PRE_C) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int m = m_base + 8 * t + sr;
         const bool ok = m < p.M && n < p.N;
-        if (PRE_AUX) aux_v[t] = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n) : u32x4{0u, 0u, 0u, 0u};
-        if (PRE_C) c_v[t] = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n) : u32x4{0u, 0u, 0u, 0u};
+        if (PRE_AUX) aux_v[t] = ok ? gload16(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n) : u32x4{0u, 0u, 0u, 0u};
+        if (PRE_C) c_v[t] = ok ? gload16(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n) : u32x4{0u, 0u, 0u, 0u};
       }
     }
   }
+  // Pass t moves the 8 rows 16 (t >> 1) + 8 (t & 1) .. +7 through the strip.  The LDS unit executes one wave's
+  // instructions in order, so the writes of pass t + 1 may be issued right behind the reads of pass t: the strip is
+  // software-pipelined one pass deep (reads of t + 1 in flight while pass t runs its element-wise chain and store).
+  auto put = [&](int t) {
+    if ((l15 >> 3) == (t & 1)) {
+      const int r = l15 & 7;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(strip + r * 64 + (((4 * j + kb) ^ r) << 2)) = acc[t >> 1][j];
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto get = [&](f32x4& x0, f32x4& x1) {
+    x0 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc) ^ sr) << 2));
+    x1 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc + 1) ^ sr) << 2));
+    __builtin_amdgcn_wave_barrier();
+  };
+  f32x4 xq[2][2];
+  put(0);
+  get(xq[0][0], xq[0][1]);
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      if ((l15 >> 3) == hh) {
-        const int r = l15 & 7;
+  for (int t = 0; t < 16; ++t) {
+    if (t + 1 < 16) {
+      put(t + 1);
+      get(xq[(t + 1) & 1][0], xq[(t + 1) & 1][1]);
+    }
+    const f32x4 x0 = xq[t & 1][0], x1 = xq[t & 1][1];
+    int m = m_base + 8 * t + sr;
+    if ((COGV_EXP & 64) && x0[0] != 12345.f) continue;      // probe: no epilogue
+    if (COGV_EXP & 128) m &= 255;                           // probe: all tiles store to the same L2-resident rows
+    if (m < p.M && n < p.N) {
+      if (F == -2) {                                        // split-K partial: raw fp32 slab
+        float* w = p.ws + ((size_t)ksplit * p.M + m) * p.N + n;
+        gstore16(w, x0);
+        gstore16(w + 4, x1);
+      } else {
+        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        float rv[8];
+        amax_pk = absmax_pk(amax_pk, epilogue8<T, (F < 0 ? -1 : F)>(p, m, n, v, PRE_BIAS ? &bias_v : nullptr,
+                                                                     PRE_AUX ? &aux_v[t] : nullptr,
+                                                                     PRE_C ? &c_v[t] : nullptr, want_cs ? rv : nullptr));
+        if (want_cs) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4*>(strip + r * 64 + (((4 * j + kb) ^ r) << 2)) = acc[i][j];
-      }
-      __builtin_amdgcn_wave_barrier();
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc) ^ sr) << 2));
-      const f32x4 x1 = *reinterpret_cast<const f32x4*>(strip + sr * 64 + (((2 * sc + 1) ^ sr) << 2));
-      __builtin_amdgcn_wave_barrier();
-      int m = m_base + 16 * i + 8 * hh + sr;
-      const int n = n_base + 8 * sc;
-      if ((COGV_EXP & 64) && x0[0] != 12345.f) continue;      // probe: no epilogue
-      if (COGV_EXP & 128) m &= 255;                           // probe: all tiles store to the same L2-resident rows
-      if (m < p.M && n < p.N) {
-        if (F == -2) {                                        // split-K partial: raw fp32 slab
-          float* w = p.ws + ((size_t)ksplit * p.M + m) * p.N + n;
-          *reinterpret_cast<f32x4*>(w) = x0;
-          *reinterpret_cast<f32x4*>(w + 4) = x1;
-        } else {
-          float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-          float rv[8];
-          amax_pk = absmax_pk(amax_pk, epilogue8<T, (F < 0 ? -1 : F)>(p, m, n, v, PRE_BIAS ? &bias_v : nullptr,
-                                                                       PRE_AUX ? &aux_v[2 * i + hh] : nullptr,
-                                                                       PRE_C ? &c_v[2 * i + hh] : nullptr, want_cs ? rv : nullptr));
-          if (want_cs) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) cs[e] += rv[e];
-          }
+          for (int e = 0; e < 8; ++e) cs[e] += rv[e];
         }
       }
     }
@@ -807,11 +838,10 @@ __device__ __forceinline__ void pp64_epilogue(const GemmArgs& p, f32x4 (&acc)[8]
       t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
       cs[e] = t;
     }
-    const int n = n_base + 8 * sc;
     if (sr == 0 && n < p.N) {
-      float* w = p.colsum_ws + (size_t)colsum_row * p.N + n;
-      *reinterpret_cast<f32x4*>(w) = f32x4{cs[0], cs[1], cs[2], cs[3]};
-      *reinterpret_cast<f32x4*>(w + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+      float* w = pg.colsum_ws + (size_t)colsum_row * p.N + n;
+      gstore16(w, f32x4{cs[0], cs[1], cs[2], cs[3]});
+      gstore16(w + 4, f32x4{cs[4], cs[5], cs[6], cs[7]});
     }
   }
 }
