@@ -115,7 +115,8 @@ struct LnBwdArgs {
 // occupancy at two waves per SIMD and ran at 2 TB/s.  R rows are in flight per iteration (R * 2..3 16-byte
 // loads per lane); the two row statistics go through a double-buffered LDS exchange, one barrier per R rows.
 template <typename T, int R>
-__global__ __launch_bounds__(512) void ln_bwd_kernel(const LnBwdArgs p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 2 ? 4 : 2)))
+void ln_bwd_kernel(const LnBwdArgs p) {
   __shared__ float red[2][R][8][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int col = threadIdx.x * 8;
@@ -253,7 +254,10 @@ template <typename T, int NV> void launch_fwd(const LnFwdArgs& a, int blocks, hi
 }
 template <typename T> void launch_bwd(const LnBwdArgs& a, int blocks, hipStream_t st) {
   const int nw = (a.h + 511) / 512;             // waves per row (h <= 4096 -> <= 8)
-  hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), dim3(blocks), dim3(nw * 64), 0, st, a);
+  // wide rows with the dropout replay: two rows in flight at 128 registers (two workgroups per CU) beat four rows at
+  // 206 (one per CU) -- 112 vs 129 us at h = 2560; without the replay four rows and one workgroup per CU win (109 vs 116)
+  if (nw >= 4 && a.thr16) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(blocks), dim3(nw * 64), 0, st, a);
+  else hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), dim3(blocks), dim3(nw * 64), 0, st, a);
 }
 
 #define NV_SWITCH(FN, T, nv, ...)                          \
@@ -271,14 +275,17 @@ template <typename T> void launch_bwd(const LnBwdArgs& a, int blocks, hipStream_
 
 }  // namespace
 
-// Workgroups of the backward kernel: about 2.5 waves per SIMD measured best at both hot widths (h = 2560: 5 waves per
-// workgroup, 512 workgroups 101 us vs 111 us with 1024; h = 1024: 2 waves per workgroup, 1024 workgroups 44 us vs 59 us
-// with 512) -- more waves only add partial-sum rows for the reduce pass, fewer leave load latency exposed.
-static int ln_bwd_blocks(int rows, int h) {
+// Workgroups of the backward kernel: exactly ONE round of resident workgroups (each loops over its rows) measured best
+// at the wide rows -- h = 2560 (5 waves per workgroup): 256 workgroups of the four-row form (one per CU) 96 / 110 us
+// (plain / residual-gradient add) vs 101 / 115 with 512, and 512 of the two-row form (two per CU) for the dropout-replay
+// variant 112 vs 134 us; a third resident workgroup or a second round is 10-30 % slower.  h = 1024 (2 waves per
+// workgroup): 1024 workgroups 44 us vs 59 with 512, 79 with 256.
+static int ln_bwd_blocks(int rows, int h, bool dropout_replay) {
   static const int forced = [] { const char* e = getenv("COGV_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
   const int nw = (h + 511) / 512;
-  int cap = forced > 0 ? (forced > 1024 ? 1024 : forced) : 2560 / nw;
-  if (forced <= 0) cap = cap < 256 ? 256 : (cap > 1024 ? 1024 : cap);
+  int cap = nw >= 4 ? (dropout_replay ? 512 : 256) : 2560 / nw;
+  if (forced > 0) cap = forced > 1024 ? 1024 : forced;
+  else cap = cap < 256 ? 256 : (cap > 1024 ? 1024 : cap);
   int b = (rows + 3) / 4;                       // 4 rows per workgroup iteration
   return b < 1 ? 1 : (b > cap ? cap : b);
 }
@@ -323,7 +330,7 @@ extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, co
   a.seed = seed; a.stream_id = stream_id;
   a.thr16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
-  const int blocks = ln_bwd_blocks(rows, h);
+  const int blocks = ln_bwd_blocks(rows, h, a.thr16 != 0);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == COGV_F16) launch_bwd<f16_t>(a, blocks, st); else launch_bwd<bf16_t>(a, blocks, st);
   if (dgamma || dbeta || colsum) {
