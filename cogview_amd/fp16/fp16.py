@@ -167,9 +167,19 @@ class FP16_Optimizer(object):
     def __setstate__(self, state):
         raise RuntimeError("FP16_Optimizer should be deserialized using load_state_dict().")
 
-    def zero_grad(self, set_grads_to_None=False):
+    @property
+    def lazy_zero_grad_ok(self):
+        return self._arena is not None
+
+    def finish_lazy_zero_grad(self):
         if self._arena is not None:
-            self._arena.zero_grad()                  # one memset; param.grad stay views of the flat buffer
+            self._arena.finish_lazy()
+
+    def zero_grad(self, set_grads_to_None=False, lazy=False):
+        """lazy (fused flat path only): no memset, the next backward pass overwrites instead of accumulating
+        (arena.ParamArena.zero_grad) -- for callers that run backward immediately, like training.backward_step."""
+        if self._arena is not None:
+            self._arena.zero_grad(lazy=lazy)         # one memset (or none); param.grad stay views of the flat buffer
             self._stats_valid = False
             return
         for group in self.optimizer.param_groups:
@@ -189,6 +199,7 @@ class FP16_Optimizer(object):
 
     # ---------------------------------------------------------------------------------------------- fused pieces
     def _compute_stats(self):
+        self._arena.finish_lazy()
         self._stats.zero_()
         ops.grad_stats(self._arena.grad, self._tables[0], self._tables[1], self._tables[3], self._stats)
         if self._shard is not None:          # every rank saw its own slices: sum of squares and overflow count add up

@@ -30,6 +30,19 @@ def grad_buffer(p):
     return p.grad
 
 
+def grad_accumulate(*params):
+    """The accumulate flag for a kernel that adds into the gradients of `params`: False (overwrite) only when all of them
+    are arena gradients untouched since a lazy zero_grad (arena.ParamArena.take_fresh)."""
+    params = [p for p in params if p is not None]
+    arenas = [getattr(p, "_cogv_arena", (None,))[0] for p in params]
+    if params and all(a is not None and a is arenas[0] for a in arenas):
+        return not arenas[0].take_fresh(params)
+    for p, a in zip(params, arenas):          # mixed / no arena: zero what is untouched, then accumulate
+        if a is not None:
+            a.take_fresh([p])
+    return True
+
+
 def _mp_allreduce(t):
     if mp_world_size_or_1() > 1:
         torch.distributed.all_reduce(t, group=get_model_parallel_group())
@@ -82,9 +95,9 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dy2, weight, trans_b=True).view(ctx.xshape)
         if weight.requires_grad:
-            ops.gemm(dy2, x2, trans_a=True, trans_b=True, out=grad_buffer(weight), accumulate=True)
+            ops.gemm(dy2, x2, trans_a=True, trans_b=True, out=grad_buffer(weight), accumulate=grad_accumulate(weight))
         if ctx.bias is not None and ctx.bias.requires_grad:
-            ops.colsum(dy2, out=grad_buffer(ctx.bias), accumulate=True)
+            ops.colsum(dy2, out=grad_buffer(ctx.bias), accumulate=grad_accumulate(ctx.bias))
         return dx, None, None
 
 
@@ -109,7 +122,8 @@ class _SandwichLN(torch.autograd.Function):
         dyc = dy if dy.is_contiguous() else dy.contiguous()
         dg = grad_buffer(weight) if weight.requires_grad else None
         db = grad_buffer(ctx.bias) if ctx.bias.requires_grad else None
-        dx = ops.sandwich_ln_bwd(dyc, xc, weight, mean, rstd, dgamma=dg, dbeta=db, accumulate=True)
+        dx = ops.sandwich_ln_bwd(dyc, xc, weight, mean, rstd, dgamma=dg, dbeta=db,
+                                 accumulate=grad_accumulate(weight if dg is not None else None, ctx.bias if db is not None else None))
         return dx, None, None, None, None
 
 
@@ -345,6 +359,9 @@ class _Embedding(torch.autograd.Function):
         w, pw = ctx.weight, ctx.pos_weight
         dpos = grad_buffer(pw) if (pw is not None and pw.requires_grad) else None
         dtab = grad_buffer(w) if w.requires_grad else None
+        for q in (pw if dpos is not None else None, w if dtab is not None else None):
+            if q is not None and getattr(q, "_cogv_arena", None) is not None:
+                q._cogv_arena[0].ensure_zeroed(q)         # scatter-add kernel: an untouched gradient is zeroed first
         ops.embedding_bwd(dout, ids, dtab, ctx.vocab_start, pos_ids, dpos, dropout=ctx.drop)
         return None, None, None, None, None, None
 
@@ -411,7 +428,7 @@ class _Logits(torch.autograd.Function):
         d2 = dl.reshape(-1, dl.shape[-1])
         dx = _mp_allreduce(ops.gemm(d2, w, trans_b=True)).view(ctx.xshape)
         if w.requires_grad:
-            ops.gemm(d2, x2, trans_a=True, trans_b=True, out=grad_buffer(w), accumulate=True)
+            ops.gemm(d2, x2, trans_a=True, trans_b=True, out=grad_buffer(w), accumulate=grad_accumulate(w))
         return dx, None
 
 
@@ -518,7 +535,7 @@ def _layer_backward(layer, kp, dout, sep):
 
     # out = y + LN4(mo):  d_mo = mask(LN4'(dout)); bias grad of 4h->h = column sums of d_mo
     d_mo = ops.sandwich_ln_bwd(dout, kp.mo, ln4.weight, *kp.st4, dropout=kp.d_mo, dgamma=G(ln4.weight),
-                               dbeta=G(ln4.bias), colsum=G(b2), accumulate=True).view(rows, h)
+                               dbeta=G(ln4.bias), colsum=G(b2), accumulate=grad_accumulate(ln4.weight, ln4.bias, b2)).view(rows, h)
     # The four weight gradients dW = dY^T X are deferred to a grouped launch (flush_weight_grads): together their
     # 256x256 tiles fill whole rounds of the 256 CUs (each alone needs split-K slabs or idles half a round).
     # Model parallel: the two column-parallel dgrads (dc, da) are partial sums that must be all-reduced before the
@@ -527,23 +544,24 @@ def _layer_backward(layer, kp, dout, sep):
     # 79-93 inside F.linear's backward).  Without model parallelism they stay deferred to the grouped launch.
     mp = mp_world_size_or_1()
     wgrads = _WGRADS.problems if mp == 1 else []
-    du = ops.gemm(d_mo, W2, trans_b=True, mul_aux=kp.u, colsum_out=G(b1))       # dgrad x stored gelu' + bias grad of h->4h
-    wgrads.append((d_mo, kp.g, G(W2)))
+    du = ops.gemm(d_mo, W2, trans_b=True, mul_aux=kp.u, colsum_out=G(b1),       # dgrad x stored gelu' + bias grad of h->4h
+                  colsum_accumulate=grad_accumulate(b1))
+    wgrads.append((d_mo, kp.g, W2))
     dc = ops.gemm(du, W1, trans_b=True)
-    wgrads.append((du, kp.c.view(rows, h), G(W1)))
+    wgrads.append((du, kp.c.view(rows, h), W1))
     if mp > 1:
         work = _mp_allreduce_start(dc)
-        ops.gemm_grouped(wgrads, trans_a=True, trans_b=True, accumulate=True)     # overlaps the exchange of dc
+        _launch_weight_grads(wgrads)                                             # overlaps the exchange of dc
         wgrads = []
         _mp_allreduce_finish(work)
     # y feeds LN2 and the second residual:  dy = dout + LN2'(dc)
     dy = ops.sandwich_ln_bwd(dc.view(b, s, h), kp.y, ln2.weight, *kp.st2, add_in=dout, dgamma=G(ln2.weight),
-                             dbeta=G(ln2.bias), accumulate=True)
+                             dbeta=G(ln2.bias), accumulate=grad_accumulate(ln2.weight, ln2.bias))
     # y = x + LN3(ao):  d_ao = mask(LN3'(dy))
     d_ao = ops.sandwich_ln_bwd(dy, kp.ao, ln3.weight, *kp.st3, dropout=kp.d_ao, dgamma=G(ln3.weight),
-                               dbeta=G(ln3.bias), colsum=G(bo), accumulate=True).view(rows, h)
+                               dbeta=G(ln3.bias), colsum=G(bo), accumulate=grad_accumulate(ln3.weight, ln3.bias, bo)).view(rows, h)
     d_att = ops.gemm(d_ao, Wo, trans_b=True).view(b, s, npp, 64)
-    wgrads.append((d_ao, kp.att.view(rows, hp), G(Wo)))
+    wgrads.append((d_ao, kp.att.view(rows, hp), Wo))
     qkv = kp.qkv
     q = qkv[:, :, 0:hp].view(b, s, npp, 64)
     k = qkv[:, :, hp:2 * hp].view(b, s, npp, 64)
@@ -551,16 +569,16 @@ def _layer_backward(layer, kp, dout, sep):
     dqkv = torch.empty_like(qkv)
     ops.attention_bwd(d_att, q, k, v, kp.att, kp.lse, sep=sep, dropout=kp.d_attn,
                       dq=dqkv[:, :, 0:hp].view(b, s, npp, 64), dk=dqkv[:, :, hp:2 * hp].view(b, s, npp, 64),
-                      dv=dqkv[:, :, 2 * hp:].view(b, s, npp, 64), colsum_out=G(bq))
+                      dv=dqkv[:, :, 2 * hp:].view(b, s, npp, 64), colsum_out=G(bq), colsum_accumulate=grad_accumulate(bq))
     dqkv2 = dqkv.view(rows, 3 * hp)
     da = ops.gemm(dqkv2, Wq, trans_b=True)
-    wgrads.append((dqkv2, kp.a.view(rows, h), G(Wq)))
+    wgrads.append((dqkv2, kp.a.view(rows, h), Wq))
     if mp > 1:
         work = _mp_allreduce_start(da)
-        ops.gemm_grouped(wgrads, trans_a=True, trans_b=True, accumulate=True)     # overlaps the exchange of da
+        _launch_weight_grads(wgrads)                                             # overlaps the exchange of da
         _mp_allreduce_finish(work)
     dx = ops.sandwich_ln_bwd(da.view(b, s, h), kp.x, ln1.weight, *kp.st1, add_in=dy, dgamma=G(ln1.weight),
-                             dbeta=G(ln1.bias), accumulate=True)
+                             dbeta=G(ln1.bias), accumulate=grad_accumulate(ln1.weight, ln1.bias))
     return dx
 
 
@@ -610,11 +628,17 @@ def wgrad_group_layers(layer):
     return g
 
 
+def _launch_weight_grads(probs):
+    """probs: [(dY, X, weight parameter)] -> grouped dW (+)= dY^T X launches of at most 16 problems; whether a problem
+    accumulates or overwrites is decided here, per parameter (grad_accumulate)."""
+    for i in range(0, len(probs), 16):
+        ops.gemm_grouped([(a, b, grad_buffer(w), grad_accumulate(w)) for a, b, w in probs[i:i + 16]], trans_a=True, trans_b=True)
+
+
 def flush_weight_grads():
     probs, cbs = _WGRADS.problems, _WGRADS.callbacks
     _WGRADS.problems, _WGRADS.callbacks = [], []
-    for i in range(0, len(probs), 16):
-        ops.gemm_grouped(probs[i:i + 16], trans_a=True, trans_b=True, accumulate=True)
+    _launch_weight_grads(probs)
     for cb, layer in cbs:
         cb(layer)
 

@@ -130,6 +130,8 @@ class DistributedDataParallel(Module):
             return
         self.needs_reduction = False
         self._layers_done = 0
+        if self.arena is not None:
+            self.arena.finish_lazy()          # gradients no kernel wrote since a lazy zero_grad become real zeros
         if self.world == 1 and not self.force:
             return
         if self.arena is None:

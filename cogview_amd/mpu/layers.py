@@ -136,5 +136,6 @@ class _BiasGradOnly(torch.autograd.Function):
     def backward(ctx, dy):
         from .. import ops
         d2 = dy.reshape(-1, dy.shape[-1])
-        ops.colsum(d2 if d2.is_contiguous() else d2.contiguous(), out=F_.grad_buffer(ctx.bias), accumulate=True)
+        ops.colsum(d2 if d2.is_contiguous() else d2.contiguous(), out=F_.grad_buffer(ctx.bias),
+                   accumulate=F_.grad_accumulate(ctx.bias))
         return dy, None

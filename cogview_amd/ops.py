@@ -301,14 +301,15 @@ def gemv_ln(z, w, bias, gamma, beta, eps, z_absmax=None, post=None, residual=Non
 
 def gemm_grouped(problems, trans_a=True, trans_b=True, accumulate=True):
     """Up to 16 GEMMs of one layout in ONE persistent launch (cogv_gemm_grouped): `problems` is a list of
-    (a, b, out).  Used for the weight gradients of one or several transformer layers, which fill the 256 CUs together.
+    (a, b, out) or (a, b, out, accumulate) -- the flag is per problem, `accumulate` its default.  Used for the weight gradients of one or several transformer layers, which fill the 256 CUs together.
     Falls back to one cogv_gemm per problem when the library reports a shape the grouped kernel does not take."""
     assert 1 <= len(problems) <= 16
     lib = L.lib()
     descs = (L.GemmDesc * len(problems))()
     tiles, kmin, flops, nbytes = 0, None, 0.0, 0.0
     shapes = []
-    for d, (a, b, out) in zip(descs, problems):
+    problems = [(pr[0], pr[1], pr[2], pr[3] if len(pr) > 3 else accumulate) for pr in problems]
+    for d, (a, b, out, acc) in zip(descs, problems):
         _need_gpu(a, b, out)
         assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
         K, M = a.shape if trans_a else a.shape[::-1]
@@ -321,7 +322,7 @@ def gemm_grouped(problems, trans_a=True, trans_b=True, accumulate=True):
         d.B, d.ldb = b.data_ptr(), b.stride(0)
         d.C, d.ldc = out.data_ptr(), out.stride(0)
         d.out_f32 = int(out.dtype == torch.float32)
-        d.flags = L.EPI_ACCUM if accumulate else 0
+        d.flags = L.EPI_ACCUM if acc else 0
         shapes.append((M, N, K))
         tiles += ((M + 255) // 256) * ((N + 255) // 256)
         kmin = K if kmin is None else min(kmin, K)
@@ -329,8 +330,8 @@ def gemm_grouped(problems, trans_a=True, trans_b=True, accumulate=True):
         nbytes += 2.0 * (M * K + N * K + M * N)
     ok = all(M >= 256 and N >= 256 and K % 64 == 0 for M, N, K in shapes)
     if not ok:
-        for a, b, out in problems:
-            gemm(a, b, trans_a=trans_a, trans_b=trans_b, out=out, accumulate=accumulate)
+        for a, b, out, acc in problems:
+            gemm(a, b, trans_a=trans_a, trans_b=trans_b, out=out, accumulate=acc)
         return
     splitk = lib.cogv_gemm_pick_splitk_tiles(tiles, kmin)
     if splitk > 1:

@@ -18,7 +18,24 @@ class FusedAdam(torch.optim.Optimizer):
         self.adam_w_mode = 1 if adam_w_mode else 0
         self.set_grad_none = set_grad_none
 
-    def zero_grad(self, set_to_none=None):
+    def _arenas(self):
+        out = {}
+        for group in self.param_groups:
+            for p in group['params']:
+                e = getattr(p, '_cogv_arena', None)
+                if e is not None:
+                    out[id(e[0])] = e[0]
+        return list(out.values())
+
+    @property
+    def lazy_zero_grad_ok(self):
+        return all(getattr(p, '_cogv_arena', None) is not None for group in self.param_groups for p in group['params'])
+
+    def finish_lazy_zero_grad(self):
+        for a in self._arenas():
+            a.finish_lazy()
+
+    def zero_grad(self, set_to_none=None, lazy=False):
         """Arena-backed parameters keep `param.grad` as a view of the flat gradient buffer (one memset): the
         data-parallel exchange reduces slices of that buffer, so dropping the views would silently stop the gradient
         synchronisation.  Loose parameters follow apex's set_grad_none default."""
@@ -33,7 +50,7 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     loose = True
         for a in arenas.values():
-            a.zero_grad()
+            a.zero_grad(lazy=lazy and not loose)
         if not loose:
             return
         for group in self.param_groups:
@@ -52,6 +69,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self.finish_lazy_zero_grad()
         for group in self.param_groups:
             beta1, beta2 = group['betas']
             group['step'] = group.get('step', 0) + 1

@@ -7,6 +7,8 @@ what changes is where bytes move:
   * logits stay in 16 bits between the LM head and the fused cross entropy (FP16_Module(keep_half_outputs));
   * the loss all-reduces for logging are issued only when `log` is set.
 """
+import os
+
 import torch
 
 from . import mpu
@@ -55,11 +57,20 @@ def forward_step(batch, model, txt_loss_scale=1.0, is_sparse=0, mems=(), log=Tru
 def backward_step(optimizer, model, lm_loss, clip_grad=1.0, fp16=True, world_size=1, reduce_loss=False):
     """pretrain_gpt2.py:344-391 (non-DeepSpeed branch).  Returns the loss averaged over all ranks when
     `reduce_loss` is set (the reference's lm_loss_reduced, :361-365), else the local loss."""
-    optimizer.zero_grad()
+    # The backward pass starts right here, so the memset can be skipped: gradients are marked untouched and the first
+    # kernel that produces each one overwrites it (arena.ParamArena.zero_grad(lazy=True)); parameters the pass did not
+    # reach are zeroed afterwards.  Optimizers without a flat arena take the ordinary path.
+    lazy = getattr(optimizer, 'lazy_zero_grad_ok', False) and os.environ.get('COGV_LAZY_ZERO_GRAD', '1') != '0'
+    if lazy:
+        optimizer.zero_grad(lazy=True)
+    else:
+        optimizer.zero_grad()
     if fp16:
         optimizer.backward(lm_loss, update_master_grads=False)
     else:
         lm_loss.backward()
+    if lazy:
+        optimizer.finish_lazy_zero_grad()
     reduced = lm_loss.detach().clone().view(1)
     if reduce_loss and world_size > 1:
         torch.distributed.all_reduce(reduced)

@@ -171,3 +171,63 @@ def test_fp32_data_parallel_gradients_stay_in_the_arena(golden_dir):
             assert p.grad is not None and p.grad.data_ptr() == arena.grad.data_ptr() + off * esz
         assert float(arena.grad.float().abs().sum()) > 0
         opt.step()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_lazy_zero_grad_gives_the_gradients_of_a_memset(golden_dir, dtype):
+    """arena.zero_grad(lazy=True) skips the memset and lets the first backward kernel of every gradient overwrite it
+    (training.backward_step runs that way).  The gradients must equal the memset path bit for bit -- from a POISONED
+    buffer, over one and over two accumulated backward passes; gradients no kernel reaches become zeros when the
+    gradients are consumed.  (Word embeddings: 16-bit atomics, compared to a tolerance -- see the resume test above.)"""
+    from cogview_amd import training
+    g = _golden(golden_dir)
+    batch = _batch(g)
+    model, opt = _make(g, dtype, drop=0.0, seed=1234)
+    arena = model.module._cogv_arena
+    first = arena.params[0].numel()
+
+    def run(lazy, passes):
+        if lazy:
+            arena.grad.fill_(7.0)                                  # stale garbage everywhere
+            opt.zero_grad(lazy=True)
+        else:
+            opt.zero_grad()
+        for _ in range(passes):
+            loss, *_ = training.forward_step(batch, model, 1.0)
+            opt.backward(loss, update_master_grads=False)
+        if lazy:
+            assert arena._fresh == set()                           # every gradient was written by a kernel
+            opt.finish_lazy_zero_grad()
+            assert arena._fresh is None
+        return arena.grad.clone()
+
+    # scatter-added with 16-bit atomics (order-dependent rounding): the word and the position embedding tables
+    atomics = {id(model.module.word_embeddings.weight), id(model.module.transformer.position_embeddings.weight)}
+    for passes in (1, 2):
+        want, got = run(False, passes), run(True, passes)
+        for prm, off in zip(arena.params, arena.offsets):
+            w, g_ = want[off:off + prm.numel()], got[off:off + prm.numel()]
+            if id(prm) in atomics:
+                assert torch.allclose(w.float(), g_.float(), rtol=2e-2, atol=2e-3 * w.float().abs().max().item()), passes
+            else:
+                assert torch.equal(w, g_), (passes, off)
+    # no backward pass at all: whoever consumes the gradients finds zeros, not the stale values
+    arena.grad.fill_(7.0)
+    opt.zero_grad(lazy=True)
+    assert float(arena.params[3].grad.float().abs().max()) == 7.0
+    opt.finish_lazy_zero_grad()
+    assert all(float(p.grad.float().abs().max()) == 0.0 for p in arena.params)
+    # the whole step through training.train_step (lazy inside) == the same step with the memset path
+    ref_model, ref_opt = _make(g, dtype, drop=0.0, seed=1234)
+    ref_opt.zero_grad()
+    loss, *_ = training.forward_step(batch, ref_model, 1.0)
+    ref_opt.backward(loss, update_master_grads=False)
+    ref_opt.update_master_grads()
+    ref_opt.step()
+    model2, opt2 = _make(g, dtype, drop=0.0, seed=1234)
+    model2.module._cogv_arena.grad.fill_(3.0)
+    training.train_step(batch, model2, opt2, clip_grad=0.0)
+    a, b = ref_opt._master_flat, opt2._master_flat
+    second = arena.offsets[2]                   # word + position embeddings come first in the arena
+    assert {id(q) for q in arena.params[:2]} == atomics
+    assert torch.equal(a[second:], b[second:])
