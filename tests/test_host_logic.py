@@ -331,3 +331,33 @@ def test_weight_gradient_grouping_rule():
         assert F_.wgrad_group_layers(fake_layer(2048)) == 1          # 768 tiles per layer
         assert F_.wgrad_group_layers(fake_layer(1536)) == 2          # 432 tiles per layer
         assert F_.wgrad_group_layers(fake_layer(256)) == 4           # capped: 4 layers x 4 problems = 16
+
+
+def test_lazy_zero_grad_bookkeeping():
+    """arena.zero_grad(lazy=True): nothing is written; a producer that finds ALL of its gradients untouched overwrites
+    (accumulate False) -- once; mixed groups zero their untouched members and accumulate; scatter-adding producers get a
+    zeroed buffer; whatever nobody touched is zeroed by finish_lazy.  functional.grad_accumulate is the producers' view."""
+    from cogview_amd import functional as F_
+    from cogview_amd.arena import ParamArena
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 300, 7, 64)]
+    a = ParamArena(ps, torch.float32, torch.device("cpu"))
+    a.grad.fill_(7.0)
+    a.zero_grad(lazy=True)
+    assert float(a.grad.abs().max()) == 7.0 and all(p.grad.data_ptr() == a.grad.data_ptr() + 4 * o for p, o in zip(ps, a.offsets))
+    assert F_.grad_accumulate(ps[0]) is False            # first producer of ps[0]: overwrite ...
+    assert F_.grad_accumulate(ps[0]) is True             # ... afterwards accumulate
+    assert float(ps[0].grad[0]) == 7.0                   # (grad_accumulate itself wrote nothing)
+    assert F_.grad_accumulate(ps[0], ps[1]) is True      # mixed group: the untouched member is zeroed, the kernel adds
+    assert float(ps[1].grad.abs().max()) == 0.0
+    a.ensure_zeroed(ps[2])                               # scatter-add producer
+    assert float(ps[2].grad.abs().max()) == 0.0
+    a.ensure_zeroed(ps[2]); a.ensure_zeroed(ps[0])       # no-ops now
+    assert float(ps[0].grad[0]) == 7.0
+    assert a._fresh == {id(ps[3])}
+    a.finish_lazy()
+    assert a._fresh is None and float(ps[3].grad.abs().max()) == 0.0 and float(ps[0].grad[0]) == 7.0
+    assert F_.grad_accumulate(ps[3]) is True             # no lazy zero pending: always accumulate
+    loose = torch.nn.Parameter(torch.randn(3))           # a parameter outside any arena never overwrites
+    assert F_.grad_accumulate(loose) is True and F_.grad_accumulate(loose, ps[1]) is True
+    a.zero_grad()                                        # the ordinary call is still a memset
+    assert float(a.grad.abs().max()) == 0.0 and a._fresh is None
