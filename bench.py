@@ -52,10 +52,9 @@ def padded_vocab(mp):
 
 
 VOCAB = padded_vocab(1)
-# logits rel-L2 against the fp32 reference, measured by tests/test_model_gpu.py (golden 2-layer model / one layer at the
-# 4B width): the north star's 1e-3 is met by fp16 storage only; bf16 carries 8 significant bits
-LOGITS_REL_L2 = {"fp16": {"measured": 8.5e-4, "tolerance_in_tests": 1e-3},
-                 "bf16": {"measured": 7.6e-3, "tolerance_in_tests": 2e-2}}
+# bars of tests/test_depth_parity_gpu.py for the logits rel-L2 against the fp32 CPU oracle at FULL depth; the value
+# next to them in the JSON line is MEASURED by this run on the model it timed (measure_parity)
+LOGITS_TOLERANCE = {"fp16": 1e-3, "bf16": 8e-3}
 PEAK_FP32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 (exact fp32), MI355X_MICROARCH.md
 ROW = 1089               # tokens per data row; the model sees ROW-1 = 1088 positions (pretrain_gpt2.py:273-275)
 PEAK_MFMA_TFLOPS = 2500.0   # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md)
@@ -115,6 +114,22 @@ def cpu_baseline(L, h, heads, sample_layers=4):
             "sample": f"1 sequence x 1088 positions, fp32 oracle fwd+bwd: embedding + {sample_layers} of {L} layers "
                       f"(scaled x{L / sample_layers:g}) + tied LM head + CE; head {t_head:.2f}s, "
                       f"{sample_layers} layers {t_full - t_head:.2f}s"}
+
+
+def measure_parity(inner, L, heads):
+    """The CPU oracle as the CHECKER of the model this run just timed (part of the cpu_baseline leg: rank 0, N = 1):
+    one 1088-position sequence through ALL layers of the timed model's current weights (as stored, widened to fp32) on
+    the CPU in fp32, against the HIP forward of the same sequence -- relative L2 of the logits and of the residual stream
+    after 1, 2, 4, ... layers (oracle/depth_check.py).  The oracle forward is also a CPU timing sample (forward only)."""
+    from oracle import depth_check as D
+    ids = torch.randint(0, N_TOKEN_IDS, (1, ROW - 1), generator=torch.Generator().manual_seed(4321)).cuda()
+    rep = D.depth_report(inner, ids, L, heads)
+    return {"logits_rel_l2": rep["logits"],
+            "residual_stream_rel_l2_after_n_layers": {str(n): e for n, e in rep["stream"].items()},
+            "against": "oracle/cogview_oracle.py fp32 on the CPU, all %d layers, the timed model's weights as stored, "
+                       "1 sequence x 1088 positions, dropout off" % L,
+            "oracle_forward_seconds": rep["oracle_seconds"],
+            "oracle_forward_tokens_per_s": rep["tokens"] / rep["oracle_seconds"]}
 
 
 def cpu_baseline_vqvae(n_img=16):
@@ -204,8 +219,9 @@ def latest_profile(pattern):
     return hits[-1] if hits else None
 
 
-def run_gpt(args, dtype_name, world, rank, mp):
-    """One measurement of the GPT train step in `dtype_name`; returns the JSON object (without cpu_baseline)."""
+def run_gpt(args, dtype_name, world, rank, mp, parity=False):
+    """One measurement of the GPT train step in `dtype_name`; returns the JSON object (without cpu_baseline).
+    parity: after the timed steps, check the timed model against the CPU oracle at full depth (measure_parity)."""
     from cogview_amd import mpu, training
     from cogview_amd.fp16 import FP16_Module, FP16_Optimizer
     from cogview_amd.model import GPT2Model, PyTorchDistributedDataParallel, gpt2_get_params_for_weight_decay_optimization
@@ -271,7 +287,7 @@ def run_gpt(args, dtype_name, world, rank, mp):
                    "dropout": args.dropout,
                    "activation_recompute": bool(args.checkpoint_activations), "loss": final_loss,
                    "loss_scale": opt.loss_scale, "skipped_last_step": int(skipped),
-                   "logits_rel_l2_vs_fp32_reference": LOGITS_REL_L2[dtype_name]},
+                   "logits_rel_l2_vs_fp32_reference": {"measured": None, "tolerance_in_tests": LOGITS_TOLERANCE[dtype_name]}},
         "model_tflops_per_gpu": value / world * fpt / 1e12,
         "mfma_roofline_frac_end_to_end": value / world * fpt / 1e12 / PEAK_MFMA_TFLOPS,
     }
@@ -296,6 +312,15 @@ def run_gpt(args, dtype_name, world, rank, mp):
             out["roofline"]["traffic_unit"] = "bytes per launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE, includes Infinity-Cache hits)"
             out["roofline"]["traffic_source"] = os.path.relpath(tpath, ROOT)
             out["roofline"]["algorithmic_bytes_per_launch"] = algo
+    if parity:
+        t0 = time.perf_counter()
+        par = measure_parity(inner, L, heads)
+        out["config"]["logits_rel_l2_vs_fp32_reference"].update(
+            measured=par["logits_rel_l2"], measured_by="this run, on the model it timed (after its %d steps)" % (args.steps + args.warmup),
+            detail=par)
+        log(f"[bench] {dtype_name}: logits rel-L2 vs the fp32 CPU oracle at full depth {par['logits_rel_l2']:.3e} "
+            f"(bar {LOGITS_TOLERANCE[dtype_name]:g}); oracle forward {par['oracle_forward_seconds']:.1f}s, "
+            f"leg {time.perf_counter() - t0:.1f}s")
     # release this model's HBM (a second dtype leg may follow in the same process)
     del step, batch, opt, model, inner, groups, ddp
     import gc
@@ -375,6 +400,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-second-dtype", action="store_true", help="skip the fp16 leg of the default run")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the full-depth logits check of the timed model against the CPU oracle (about one CPU "
+                         "minute per dtype at 4B; part of the cpu_baseline leg, so --no-cpu-baseline skips it too)")
     args = ap.parse_args()
     if args.batch <= 0:
         args.batch = VQ_BATCH if args.config == "vqvae" else DEFAULT_BATCH[args.config]
@@ -393,9 +421,10 @@ def main():
         assert world % mp == 0, "--gpus must be a multiple of --model-parallel"
         mpu.initialize_model_parallel(mp)
         L, h, heads = CONFIGS[args.config]
-        out = run_gpt(args, args.dtype or "bf16", world, rank, mp)
+        parity = world == 1 and mp == 1 and not args.no_cpu_baseline and not args.no_parity
+        out = run_gpt(args, args.dtype or "bf16", world, rank, mp, parity=parity)
         if args.dtype is None and world == 1 and not args.no_second_dtype:
-            leg = run_gpt(args, "fp16", world, rank, mp)
+            leg = run_gpt(args, "fp16", world, rank, mp, parity=parity)
             out["fp16_leg"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "dtype", "model_tflops_per_gpu",
                                                    "mfma_roofline_frac_end_to_end")}
             out["fp16_leg"]["loss"] = leg["config"]["loss"]

@@ -61,7 +61,7 @@ class LnPrologue(C.Structure):
         ("z", C.c_void_p), ("z_absmax", C.c_void_p),
         ("gamma_post", C.c_void_p), ("beta_post", C.c_void_p), ("residual", C.c_void_p), ("t_out", C.c_void_p),
         ("gamma", C.c_void_p), ("beta", C.c_void_p),
-        ("eps", C.c_float),
+        ("eps", C.c_float), ("stream_f32", C.c_int),
     ]
 
 
@@ -116,9 +116,9 @@ SIGNATURES = {
     "cogv_gemm_colsum_rows": (_i, [_i]),
     "cogv_colsum_finalize": (_i, [_i, _vp, _i, _i, _vp, _i, _vp]),
     "cogv_gemm_pick_splitk_tiles": (_i, [_i, _i]),
-    "cogv_sandwich_ln_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "cogv_sandwich_ln_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "cogv_sandwich_ln_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64,
-                                  _vp, _sz, _vp]),
+                                  _vp, _sz, _i, _vp]),
     "cogv_ln_bwd_workspace_bytes": (_sz, [_i, _i]),
     "cogv_ln_bwd_num_blocks": (_i, [_i]),
     "cogv_attention_fwd": (_i, [C.POINTER(AttnDesc), _vp]),
@@ -127,12 +127,14 @@ SIGNATURES = {
     "cogv_attention_decode": (_i, [C.POINTER(AttnDecodeDesc), _vp]),
     "cogv_attention_decode_workspace_bytes": (_sz, [_i, _i, _i]),
     "cogv_sparse_slot_reduce": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "cogv_embedding_fwd": (_i, [_i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _f, _u64, _u64, _vp]),
-    "cogv_embedding_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _i, _f, _u64, _u64, _vp]),
+    "cogv_embedding_fwd": (_i, [_i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _f, _u64, _u64, _i, _vp]),
+    "cogv_embedding_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _i, _f, _u64, _u64, _vp, _sz, _i, _vp]),
+    "cogv_embedding_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "cogv_gelu_fwd": (_i, [_i, _vp, _vp, _sz, _vp]),
     "cogv_gelu_bwd": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
     "cogv_dropout": (_i, [_i, _vp, _vp, _sz, _f, _u64, _u64, _vp, _vp]),
     "cogv_add": (_i, [_i, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "cogv_add_stream": (_i, [_i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cogv_scale": (_i, [_i, _vp, _vp, _sz, _f, _vp]),
     "cogv_absmax": (_i, [_i, _vp, _sz, _vp, _vp]),
     "cogv_colsum": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),

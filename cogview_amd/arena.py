@@ -34,12 +34,31 @@ class ParamArena:
             p._cogv_arena = (self, off)
         self._tables = {}
         self._fresh = None
+        # Lazy zero_grad contract (see zero_grad): it is sound only while EVERY gradient of the arena is produced by a
+        # kernel that consults functional.grad_accumulate / ensure_zeroed.  `lazy_ok` is the owner's declaration of that
+        # (flatten_module copies module._cogv_lazy_zero_grad: GPT2Model sets it, any other module does not), and the
+        # hook below is the guard: a gradient that arrives through autograd's AccumulateGrad (a plain torch op on a
+        # parameter) while gradients are marked untouched would be added onto stale data -- fail loudly instead.
+        self.lazy_ok = False
+        for p in self.params:
+            if p.requires_grad and hasattr(p, "register_post_accumulate_grad_hook"):
+                p.register_post_accumulate_grad_hook(self._autograd_accumulated)
+
+    def _autograd_accumulated(self, p):
+        if self._fresh is not None and id(p) in self._fresh:
+            raise RuntimeError(
+                "a gradient of shape %s reached its arena parameter through autograd's AccumulateGrad while a lazy "
+                "zero_grad was pending: it was added onto stale data.  Lazy zero_grad is only valid for modules whose "
+                "parameter gradients all come from this package's fused backward kernels; call optimizer.zero_grad() "
+                "(a memset) for this model, or set COGV_LAZY_ZERO_GRAD=0" % (tuple(p.shape),))
 
     def zero_grad(self, lazy=False):
         """lazy=False: one memset.  lazy=True: no memset -- every gradient is only MARKED untouched, and the backward
         kernel that produces it first overwrites instead of accumulating (take_fresh); whatever is still untouched when
         the gradients are consumed is zeroed then (finish_lazy).  Saves the 7.9-GB memset and the 7.9-GB read of the
         accumulate epilogues per step at 4B; `param.grad` holds stale values between the call and the backward pass."""
+        if lazy and not self.lazy_ok:
+            raise RuntimeError("lazy zero_grad on an arena whose module did not declare _cogv_lazy_zero_grad")
         if lazy:
             self._fresh = {id(p) for p in self.params}
         else:
@@ -137,6 +156,7 @@ def flatten_module(module, dtype=None):
     assert all(p.dtype == dtype for p in params), "arena needs a single parameter dtype"
     assert all(p.is_cuda for p in params), "arena needs GPU parameters"
     arena = ParamArena(params, dtype, params[0].device)
+    arena.lazy_ok = bool(getattr(module, "_cogv_lazy_zero_grad", False))
     module._cogv_arena = arena
     return arena
 

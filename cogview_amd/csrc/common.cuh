@@ -172,6 +172,67 @@ __device__ __forceinline__ float absmax_pk_block(uint32_t m, uint32_t* smem) {
   return bits_to_f<T>((uint16_t)r);
 }
 
+// ---------------------------------------------------------------- the fp32 residual stream
+// Round 3: the residual stream of the transformer (embedding output, y = x + LN3(.), out = y + LN4(.), and its
+// gradient) is held in fp32; everything that feeds a GEMM stays in the 16-bit storage type.  Rounding the stream to
+// 16 bits twice per layer was THE depth-dependent error of the forward pass: logits rel-L2 against the fp32 reference
+// grew from 5.6e-4 after one layer to 1.8e-3 after 48 (fp16; bf16 4.5e-3 -> 1.4e-2), all but 6 % of the per-layer
+// growth being those two roundings (tools/r3/depth_probe.py, profiles/r03_depth_parity.log).
+// Row8<T, F32>: the 8 consecutive elements of a row one lane owns -- one 16-byte access in the storage type T, two for
+// the fp32 stream.
+struct raw8_f32 { u32x4 a, b; };
+template <typename T, bool F32> struct Row8;
+template <typename T> struct Row8<T, false> {
+  typedef u32x4 raw;
+  static __device__ __forceinline__ raw zero() { return u32x4{0u, 0u, 0u, 0u}; }
+  static __device__ __forceinline__ raw ld(const void* base, size_t idx) {
+    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(base) + idx);
+  }
+  static __device__ __forceinline__ void to_f(const raw& r, float* f) { unpack8<T>(r, f); }
+  // stores the values rounded to T and hands the rounded values back in f
+  static __device__ __forceinline__ uint32_t st(void* base, size_t idx, float* f, uint32_t amax) {
+    const u32x4 v = pack8<T>(f);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(base) + idx) = v;
+    unpack8<T>(v, f);
+    return absmax_pk8(amax, v);
+  }
+};
+template <typename T> struct Row8<T, true> {
+  typedef raw8_f32 raw;
+  static __device__ __forceinline__ raw zero() { return raw8_f32{u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}}; }
+  static __device__ __forceinline__ raw ld(const void* base, size_t idx) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(base) + idx);
+    return raw8_f32{p[0], p[1]};
+  }
+  static __device__ __forceinline__ void to_f(const raw& r, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = __uint_as_float(r.a[i]); f[4 + i] = __uint_as_float(r.b[i]); }
+  }
+  // amax: running integer max of the |value| bit patterns (NaN patterns sort above infinity, as in absmax_pk)
+  static __device__ __forceinline__ uint32_t st(void* base, size_t idx, float* f, uint32_t amax) {
+    u32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = __float_as_uint(f[i]); b[i] = __float_as_uint(f[4 + i]); }
+    u32x4* p = reinterpret_cast<u32x4*>(reinterpret_cast<float*>(base) + idx);
+    p[0] = a; p[1] = b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) amax = max(amax, max(a[i] & 0x7fffffffu, b[i] & 0x7fffffffu));
+    return amax;
+  }
+};
+// block-wide max of fp32 |value| bit patterns, returned as the float with that pattern
+__device__ __forceinline__ float absmax_f32_block(uint32_t v, uint32_t* smem) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  uint32_t r = smem[0];
+  for (int i = 1; i < nw; ++i) r = max(r, smem[i]);
+  return __uint_as_float(r);
+}
+
 // non-negative float atomic max through the integer ordering of IEEE-754.
 // Same-address atomics serialise at L2 (~90 per microsecond on MI355X), and a launch has thousands of
 // workgroups, so the current value is read first (relaxed, agent scope -> served by L2) and the atomic is

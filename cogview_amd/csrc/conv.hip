@@ -118,7 +118,7 @@ __device__ __forceinline__ RowCtx make_b_ctx(const float* w, int ldw, int n0, in
   for (int q = 0; q < 4; ++q) {
     const int n = n0 + (t >> 3) + 32 * q;
     const bool ok = n < N;
-    c.base[q] = w + (size_t)(ok ? n : 0) * ldw + (t & 7) * 4;
+    c.base[q] = w + (size_t)(ok ? n : 0) * ldw;          // row start; the lane's 16-byte chunk is added by load_b
     c.y0[q] = c.x0[q] = 0;
     c.valid |= ok ? (1u << q) : 0u;
   }
@@ -157,9 +157,14 @@ __device__ __forceinline__ uint32_t load_a(const ConvArgs& p, const RowCtx& c, i
 }
 // B tile: 128 rows x 32 k from a row-major [N][ldw] matrix (weights W[z][co][K]; x / E^T in the nearest-code search)
 __device__ __forceinline__ uint32_t load_b(const RowCtx& c, int k0, int K, f32x4 (&r)[4]) {
-  const bool kok = k0 + (threadIdx.x & 7) * 4 < K;
+  // a chunk past the row's K columns (K < 32 or K % 32 != 0) loads the ROW START instead (zeroed when parked): the
+  // round-2 form added the chunk offset even then and read up to 112 bytes past the end of the matrix from its last row
+  // -- a memory fault whenever that matrix ended a mapped segment (found in round 3: the 64 x 16 codebook of the small
+  // golden model aborted the whole GPU suite in one particular allocation order)
+  const int kc = k0 + (threadIdx.x & 7) * 4;
+  const bool kok = kc < K;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) ld4_async(r[q], c.base[q] + (kok ? k0 : 0));
+  for (int q = 0; q < 4; ++q) ld4_async(r[q], c.base[q] + (kok ? kc : 0));
   return kok ? c.valid : 0u;
 }
 __device__ __forceinline__ void store_tile(char* lds, const f32x4 (&r)[4], uint32_t keep) {

@@ -37,7 +37,9 @@ struct EmbArgs {
   int64_t n_tok; int h;
   uint64_t seed, stream_id; uint32_t thr16; float keep_scale;
 };
-template <typename T>
+// OUT32: `out` is the fp32 residual stream -- word + position are added in fp32 (no rounding of the sum), the abs-max
+// is taken over the fp32 values.  Otherwise everything is T and the sum is rounded once (a T + T add in the reference).
+template <typename T, bool OUT32>
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const EmbArgs p) {
   __shared__ float red[16];
   const int hv = p.h >> 3;
@@ -59,12 +61,9 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const EmbArgs p) {
       pid = pid < 0 ? 0 : (pid >= p.n_pos ? p.n_pos - 1 : pid);
       float pe[8];
       unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.pos_table) + (size_t)pid * p.h + col), pe);
-      // word + position is a T + T add in the reference: round once
-      u32x4 s; { float t[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = v[k] + pe[k];
-        s = pack8<T>(t); }
-      unpack8<T>(s, v);
+      for (int k = 0; k < 8; ++k) v[k] += pe[k];
+      if (!OUT32) { const u32x4 s = pack8<T>(v); unpack8<T>(s, v); }     // a T + T add in the reference: round once
     }
     if (p.thr16) {
       const uint64_t e = (uint64_t)tok * (uint64_t)p.h + (uint64_t)col;
@@ -72,12 +71,10 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const EmbArgs p) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = (drop_bits16(r, k) >= p.thr16) ? v[k] * p.keep_scale : 0.f;
     }
-    const u32x4 o = pack8<T>(v);
-    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.out) + (size_t)tok * p.h + col) = o;
+    (void)Row8<T, OUT32>::st(p.out, (size_t)tok * p.h + col, v, 0u);      // v <- the stored values
     if (p.absmax_out) {
-      float rr[8]; unpack8<T>(o, rr);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { if (rr[k] != rr[k]) nan = true; else amax = fmaxf(amax, fabsf(rr[k])); }
+      for (int k = 0; k < 8; ++k) { if (v[k] != v[k]) nan = true; else amax = fmaxf(amax, fabsf(v[k])); }
     }
   }
   if (p.absmax_out) {
@@ -87,45 +84,106 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const EmbArgs p) {
   }
 }
 
-// backward: d(table)[id] += mask(dout), d(pos_table)[pid] += mask(dout)   (packed 16-bit atomics)
+// backward: d(table)[id] += sum over the tokens with that id of mask(dout[tok]);  same for the position table.
+// DETERMINISTIC and rounded ONCE (the reference's embedding_dense_backward accumulates in fp32 and rounds once; the
+// round-1/2 kernel scatter-added with packed 16-bit atomics: order-dependent, one rounding per add -- 24 per position
+// row at b = 24).  No atomics on floating-point data:
+//   pass 1 (emb_key_stats_kernel): per key, the number of tokens carrying it and its FIRST token (integer atomics on a
+//          zeroed 2 x int32 table per key: order-independent results);
+//   pass 2 (emb_segsum_kernel): one workgroup per (token, 2048-column slab).  Only a key's first token works: it sums
+//          the masked gradient rows of all tokens with the key in ASCENDING token order in fp32 (the other occurrences
+//          are found by scanning the ids behind it 256 at a time, wave ballots give the order) and adds the sum to the
+//          table row with one rounding.  Keys that occur once (most word ids) skip the scan.
 struct EmbBwdArgs {
-  const void* dout; const int64_t* ids; void* dtable; int64_t vocab_start, vocab_end;
-  const int64_t* pos_ids; void* dpos; int64_t n_pos;
-  void* dx;                  // optional: masked dout written out (MP>1 path needs it for nothing; tests use it)
-  int64_t n_tok; int h;
+  const void* dout; void* dx; int64_t n_tok; int h;
   uint64_t seed, stream_id; uint32_t thr16; float keep_scale;
 };
-template <typename T>
-__global__ __launch_bounds__(256) void embedding_bwd_kernel(const EmbBwdArgs p) {
+template <typename T, bool D32>        // D32: dout (and dx) are the fp32 gradient of the residual stream
+__device__ __forceinline__ void emb_masked_row(const EmbBwdArgs& p, int64_t tok, int col, float* v) {
+  Row8<T, D32>::to_f(Row8<T, D32>::ld(p.dout, (size_t)tok * p.h + col), v);
+  if (p.thr16) {
+    const uint64_t e = (uint64_t)tok * (uint64_t)p.h + (uint64_t)col;
+    const u32x4 r = Philox::gen(p.seed, p.stream_id, e >> 3);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (drop_bits16(r, k) >= p.thr16) ? v[k] * p.keep_scale : 0.f;
+  }
+}
+// dx = mask(dout) (only the tests ask for it)
+template <typename T, bool D32>
+__global__ __launch_bounds__(256) void embedding_dx_kernel(const EmbBwdArgs p) {
   const int hv = p.h >> 3;
   const size_t nvec = (size_t)p.n_tok * hv;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     const int64_t tok = (int64_t)(i / hv);
     const int col = (int)(i % hv) * 8;
     float v[8];
-    unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.dout) + (size_t)tok * p.h + col), v);
-    if (p.thr16) {
-      const uint64_t e = (uint64_t)tok * (uint64_t)p.h + (uint64_t)col;
-      const u32x4 r = Philox::gen(p.seed, p.stream_id, e >> 3);
+    emb_masked_row<T, D32>(p, tok, col, v);
+    (void)Row8<T, D32>::st(p.dx, (size_t)tok * p.h + col, v, 0u);
+  }
+}
+
+struct EmbKeys {           // word ids: keys outside [lo, hi) take no part; position ids: clamped into [0, hi)
+  const int64_t* keys; int64_t lo, hi; int clamp;
+  int32_t* stats;          // [hi - lo][2]: {count, n_tok - first token} (zeroed before pass 1)
+};
+__device__ __forceinline__ int64_t emb_key(const EmbKeys& k, int64_t tok) {     // -1: not in this table
+  int64_t v = k.keys[tok];
+  if (k.clamp) return v < 0 ? 0 : (v >= k.hi ? k.hi - 1 : v);
+  return (v >= k.lo && v < k.hi) ? v - k.lo : -1;
+}
+__global__ __launch_bounds__(256) void emb_key_stats_kernel(const EmbKeys k, int64_t n_tok) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n_tok; t += (int64_t)gridDim.x * 256) {
+    const int64_t key = emb_key(k, t);
+    if (key < 0) continue;
+    atomicAdd(&k.stats[2 * key], 1);
+    atomicMax(&k.stats[2 * key + 1], (int32_t)(n_tok - t));
+  }
+}
+template <typename T, bool D32>
+__global__ __launch_bounds__(256) void emb_segsum_kernel(const EmbBwdArgs p, const EmbKeys k, void* dtable) {
+  __shared__ unsigned long long masks[4];
+  const int64_t t = blockIdx.x;
+  const int64_t key = emb_key(k, t);
+  if (key < 0) return;
+  if ((int64_t)k.stats[2 * key + 1] != p.n_tok - t) return;          // not the first token of its key
+  int remaining = k.stats[2 * key] - 1;
+  const int hv = p.h >> 3;
+  const int cv = blockIdx.y * 256 + threadIdx.x;
+  const bool active = cv < hv;
+  const int col = cv * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (active) emb_masked_row<T, D32>(p, t, col, acc);
+  const int wave = threadIdx.x >> 6;
+  for (int64_t w0 = t + 1; remaining > 0 && w0 < p.n_tok; w0 += 256) {
+    const int64_t j = w0 + threadIdx.x;
+    const bool m = j < p.n_tok && emb_key(k, j) == key;
+    const unsigned long long bal = __ballot(m);
+    if ((threadIdx.x & 63) == 0) masks[wave] = bal;
+    __syncthreads();
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      unsigned long long mm = masks[w];
+      while (mm) {
+        const int bit = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        --remaining;
+        if (active) {
+          float v[8];
+          emb_masked_row<T, D32>(p, w0 + w * 64 + bit, col, v);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = (drop_bits16(r, k) >= p.thr16) ? v[k] * p.keep_scale : 0.f;
-    }
-    if (p.dx) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.dx) + (size_t)tok * p.h + col) = pack8<T>(v);
-    if (p.dtable) {
-      const int64_t id = p.ids[tok];
-      if (id >= p.vocab_start && id < p.vocab_end) {
-        T* dst = reinterpret_cast<T*>(p.dtable) + (size_t)(id - p.vocab_start) * p.h + col;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) atomic_add_pk<T>(dst + 2 * k, v[2 * k], v[2 * k + 1]);
+          for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
       }
     }
-    if (p.dpos) {
-      int64_t pid = p.pos_ids[tok];
-      pid = pid < 0 ? 0 : (pid >= p.n_pos ? p.n_pos - 1 : pid);
-      T* dst = reinterpret_cast<T*>(p.dpos) + (size_t)pid * p.h + col;
+    __syncthreads();
+  }
+  if (active) {
+    u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<T*>(dtable) + (size_t)key * p.h + col);
+    float old[8];
+    unpack8<T>(*dst, old);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) atomic_add_pk<T>(dst + 2 * k, v[2 * k], v[2 * k + 1]);
-    }
+    for (int e = 0; e < 8; ++e) old[e] += acc[e];
+    *dst = pack8<T>(old);
   }
 }
 
@@ -187,6 +245,40 @@ __global__ __launch_bounds__(256) void absmax_kernel(const void* x, size_t n, fl
   const float bm = block_max(amax, red);
   const bool any_nan = __syncthreads_or(nan);
   if (threadIdx.x == 0) atomic_max_nonneg(out, any_nan ? __uint_as_float(0x7fc00000u) : bm);
+}
+
+// abs-max of an fp32 tensor (the residual stream when no producer epilogue published it); n % 4 == 0
+__global__ __launch_bounds__(256) void absmax_f32_kernel(const float* x, size_t n, float* out) {
+  __shared__ uint32_t red[16];
+  const size_t nvec = n >> 2;
+  uint32_t m = 0u;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = max(m, v[k] & 0x7fffffffu);
+  }
+  const float bm = absmax_f32_block(m, red);
+  if (threadIdx.x == 0) atomic_max_nonneg(out, bm);
+}
+
+// out(fp32) = a(fp32) + b(T): a branch output joins the fp32 residual stream (op-by-op composition of the layer)
+template <typename T>
+__global__ __launch_bounds__(256) void add_stream_kernel(const float* a, const void* b, float* out, size_t n, float* absmax_out) {
+  __shared__ uint32_t red[16];
+  const size_t nvec = n >> 3;
+  uint32_t m = 0u;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    float x[8], y[8];
+    Row8<T, true>::to_f(Row8<T, true>::ld(a, i * 8), x);
+    unpack8<T>(reinterpret_cast<const u32x4*>(b)[i], y);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] += y[k];
+    m = Row8<T, true>::st(out, i * 8, x, m);
+  }
+  if (absmax_out) {
+    const float bm = absmax_f32_block(m, red);
+    if (threadIdx.x == 0) atomic_max_nonneg(absmax_out, bm);
+  }
 }
 
 // ------------------------------------------------------------------ column sum  db[n] = sum_m dY[m][n]
@@ -266,7 +358,7 @@ int dispatch_ew(int dtype, const void* a, const void* b, void* out, size_t n, fl
 extern "C" int cogv_embedding_fwd(int dtype, const int64_t* ids, const void* table, int64_t vocab_start,
                                   int64_t vocab_end, const void* x_in, const int64_t* pos_ids, const void* pos_table,
                                   int64_t n_pos, void* out, float* absmax_out, int64_t n_tok, int h, float dropout_p,
-                                  uint64_t seed, uint64_t stream_id, void* stream) {
+                                  uint64_t seed, uint64_t stream_id, int out_f32, void* stream) {
   if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
   if (n_tok <= 0 || h <= 0 || (h & 7) || !out) return COGV_ERR_ARG;
   if (!ids && !x_in) return COGV_ERR_ARG;
@@ -282,31 +374,65 @@ extern "C" int cogv_embedding_fwd(int dtype, const int64_t* ids, const void* tab
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int g = grid_for((size_t)n_tok * (h >> 3));
-  if (dtype == COGV_F16) hipLaunchKernelGGL((embedding_fwd_kernel<f16_t>), dim3(g), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((embedding_fwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, a);
+  if (out_f32) {
+    if (dtype == COGV_F16) hipLaunchKernelGGL((embedding_fwd_kernel<f16_t, true>), dim3(g), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((embedding_fwd_kernel<bf16_t, true>), dim3(g), dim3(256), 0, st, a);
+  } else {
+    if (dtype == COGV_F16) hipLaunchKernelGGL((embedding_fwd_kernel<f16_t, false>), dim3(g), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((embedding_fwd_kernel<bf16_t, false>), dim3(g), dim3(256), 0, st, a);
+  }
   return cogv_check_launch();
+}
+
+extern "C" size_t cogv_embedding_bwd_workspace_bytes(int64_t table_rows, int64_t n_pos) {
+  return (size_t)(table_rows > 0 ? table_rows : 0) * 8 + (size_t)(n_pos > 0 ? n_pos : 0) * 8;
 }
 
 extern "C" int cogv_embedding_bwd(int dtype, const void* dout, const int64_t* ids, void* dtable, int64_t vocab_start,
                                   int64_t vocab_end, const int64_t* pos_ids, void* dpos, int64_t n_pos, void* dx,
                                   int64_t n_tok, int h, float dropout_p, uint64_t seed, uint64_t stream_id,
-                                  void* stream) {
+                                  void* workspace, size_t workspace_bytes, int dout_f32, void* stream) {
   if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
-  if (n_tok <= 0 || h <= 0 || (h & 7) || !dout) return COGV_ERR_ARG;
-  if (dtable && !ids) return COGV_ERR_ARG;
+  if (n_tok <= 0 || n_tok >= (int64_t)0x7fffffff || h <= 0 || (h & 7) || !dout) return COGV_ERR_ARG;
+  if (dtable && (!ids || vocab_end <= vocab_start)) return COGV_ERR_ARG;
   if (dpos && (!pos_ids || n_pos <= 0)) return COGV_ERR_ARG;
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return COGV_ERR_ARG;
-  if (((uintptr_t)dout | (uintptr_t)dtable | (uintptr_t)dpos | (uintptr_t)dx) & 15) return COGV_ERR_ARG;
+  if (((uintptr_t)dout | (uintptr_t)dtable | (uintptr_t)dpos | (uintptr_t)dx | (uintptr_t)workspace) & 15) return COGV_ERR_ARG;
+  const int64_t rows = dtable ? vocab_end - vocab_start : 0;
+  const size_t need = cogv_embedding_bwd_workspace_bytes(rows, dpos ? n_pos : 0);
+  if (need && (!workspace || workspace_bytes < need)) return COGV_ERR_ARG;
   EmbBwdArgs a;
-  a.dout = dout; a.ids = ids; a.dtable = dtable; a.vocab_start = vocab_start; a.vocab_end = vocab_end;
-  a.pos_ids = pos_ids; a.dpos = dpos; a.n_pos = n_pos; a.dx = dx; a.n_tok = n_tok; a.h = h;
+  a.dout = dout; a.dx = dx; a.n_tok = n_tok; a.h = h;
   a.seed = seed; a.stream_id = stream_id;
   a.thr16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int g = grid_for((size_t)n_tok * (h >> 3));
-  if (dtype == COGV_F16) hipLaunchKernelGGL((embedding_bwd_kernel<f16_t>), dim3(g), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((embedding_bwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, a);
+#define EMB_LAUNCH(KERNEL, GRID, ...)                                                                       \
+  do {                                                                                                     \
+    if (dtype == COGV_F16) {                                                                               \
+      if (dout_f32) hipLaunchKernelGGL((KERNEL<f16_t, true>), GRID, dim3(256), 0, st, __VA_ARGS__);        \
+      else hipLaunchKernelGGL((KERNEL<f16_t, false>), GRID, dim3(256), 0, st, __VA_ARGS__);                \
+    } else {                                                                                               \
+      if (dout_f32) hipLaunchKernelGGL((KERNEL<bf16_t, true>), GRID, dim3(256), 0, st, __VA_ARGS__);       \
+      else hipLaunchKernelGGL((KERNEL<bf16_t, false>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
+    }                                                                                                      \
+  } while (0)
+  if (dx) {
+    const int g = grid_for((size_t)n_tok * (h >> 3));
+    EMB_LAUNCH(embedding_dx_kernel, dim3(g), a);
+  }
+  if (need) {
+    if (hipMemsetAsync(workspace, 0, need, st) != hipSuccess) return COGV_ERR_LAUNCH;
+    const int gk = (int)((n_tok + 255) / 256 > 1024 ? 1024 : (n_tok + 255) / 256);
+    const dim3 gs((unsigned)n_tok, (unsigned)(((h >> 3) + 255) / 256));
+    EmbKeys kw{ids, vocab_start, vocab_end, 0, reinterpret_cast<int32_t*>(workspace)};
+    EmbKeys kp{pos_ids, 0, n_pos, 1, reinterpret_cast<int32_t*>(workspace) + 2 * rows};
+    if (dtable) hipLaunchKernelGGL(emb_key_stats_kernel, dim3(gk), dim3(256), 0, st, kw, n_tok);
+    if (dpos) hipLaunchKernelGGL(emb_key_stats_kernel, dim3(gk), dim3(256), 0, st, kp, n_tok);
+    if (dtable) EMB_LAUNCH(emb_segsum_kernel, gs, a, kw, dtable);
+    if (dpos) EMB_LAUNCH(emb_segsum_kernel, gs, a, kp, dpos);
+  }
+#undef EMB_LAUNCH
   return cogv_check_launch();
 }
 
@@ -330,10 +456,26 @@ extern "C" int cogv_scale(int dtype, const void* x, void* y, size_t n, float sca
   return dispatch_ew<OP_SCALE>(dtype, x, nullptr, y, n, scale, nullptr, 0.f, 0, 0, stream);
 }
 
-extern "C" int cogv_absmax(int dtype, const void* x, size_t n, float* out, void* stream) {
+extern "C" int cogv_add_stream(int dtype, const float* a, const void* b, float* out, size_t n, float* absmax_out, void* stream) {
   if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
+  if ((n & 7) || !a || !b || !out) return COGV_ERR_ARG;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return COGV_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int g = grid_for(n >> 3);
+  if (dtype == COGV_F16) hipLaunchKernelGGL((add_stream_kernel<f16_t>), dim3(g), dim3(256), 0, st, a, b, out, n, absmax_out);
+  else hipLaunchKernelGGL((add_stream_kernel<bf16_t>), dim3(g), dim3(256), 0, st, a, b, out, n, absmax_out);
+  return cogv_check_launch();
+}
+
+extern "C" int cogv_absmax(int dtype, const void* x, size_t n, float* out, void* stream) {
+  if (dtype != COGV_F16 && dtype != COGV_BF16 && dtype != COGV_F32) return COGV_ERR_UNSUPPORTED;
   if (!x || !out || n == 0 || ((uintptr_t)x & 15)) return COGV_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == COGV_F32) {
+    if (n & 3) return COGV_ERR_ARG;
+    hipLaunchKernelGGL(absmax_f32_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, st, reinterpret_cast<const float*>(x), n, out);
+    return cogv_check_launch();
+  }
   const int g = grid_for(n >> 3);
   if (dtype == COGV_F16) hipLaunchKernelGGL((absmax_kernel<f16_t>), dim3(g), dim3(256), 0, st, x, n, out);
   else hipLaunchKernelGGL((absmax_kernel<bf16_t>), dim3(g), dim3(256), 0, st, x, n, out);

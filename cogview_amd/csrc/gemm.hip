@@ -1625,8 +1625,11 @@ struct GemvLnArgs {
   const void* gamma; const void* beta;          // pre-LN affine
   float eps;
 };
-template <typename T, int MT>        // MT: compile-time bound of the row count (1, 2, 4, 8): registers follow the real batch
+// SF: the residual stream is fp32 -- `res`, `t_out` and (without a post-LN) `z` are fp32 rows, t is formed and
+// normalised without an intermediate rounding (the decode counterpart of ln_fwd_kernel's STREAM modes).
+template <typename T, int MT, bool SF>   // MT: compile-time bound of the row count (1, 2, 4, 8): registers follow the real batch
 __global__ __launch_bounds__(256) void gemv_ln_kernel(const GemvLnArgs q) {
+  typedef Row8<T, SF> SR;                // a stream row slice
   extern __shared__ __attribute__((aligned(16))) char xs_raw[];           // x_in [M][K] as T
   __shared__ float part[4][MT][8];
   __shared__ float red[8];
@@ -1654,7 +1657,8 @@ __global__ __launch_bounds__(256) void gemv_ln_kernel(const GemvLnArgs q) {
   }
   const T* Z = reinterpret_cast<const T*>(q.z);
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  u32x4 zr[MT][2], rr[MT][2], gpr[2], bpr[2], gnr[2], bnr[2];
+  u32x4 zr[MT][2], gpr[2], bpr[2], gnr[2], bnr[2];
+  typename SR::raw rr[MT][2];            // the stream rows: the residual (post-LN form) or z itself (plain-input form)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int v = u ? v1 : v0; const bool ok = u ? ok1 : ok0;
@@ -1664,8 +1668,8 @@ __global__ __launch_bounds__(256) void gemv_ln_kernel(const GemvLnArgs q) {
     bpr[u] = (ok && has_post) ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(q.beta_p) + v * 8) : zero4;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      zr[m][u] = (ok && m < p.M) ? *reinterpret_cast<const u32x4*>(Z + (size_t)m * K + v * 8) : zero4;
-      rr[m][u] = (ok && has_post && m < p.M) ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(q.res) + (size_t)m * K + v * 8) : zero4;
+      zr[m][u] = (ok && m < p.M && (has_post || !SF)) ? *reinterpret_cast<const u32x4*>(Z + (size_t)m * K + v * 8) : zero4;
+      rr[m][u] = (ok && m < p.M && (has_post || SF)) ? SR::ld(has_post ? q.res : q.z, (size_t)m * K + v * 8) : SR::zero();
     }
   }
   const float zamax = q.z_absmax ? *q.z_absmax : 0.f;
@@ -1686,7 +1690,10 @@ __global__ __launch_bounds__(256) void gemv_ln_kernel(const GemvLnArgs q) {
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) unpack8<T>(zr[m][u], tv[m][u]);
+    for (int u = 0; u < 2; ++u) {
+      if (SF && !has_post) SR::to_f(rr[m][u], tv[m][u]);         // the plain input IS the fp32 stream
+      else unpack8<T>(zr[m][u], tv[m][u]);
+    }
   if (has_post) {                 // t = residual + LN_post(z), rounded where ln_fwd_kernel rounds
     const float c = zamax * 0.125f;
     const float eps_p = q.eps * c * c;
@@ -1720,19 +1727,20 @@ __global__ __launch_bounds__(256) void gemv_ln_kernel(const GemvLnArgs q) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         float r[8], o[8];
-        unpack8<T>(rr[m][u], r);
+        SR::to_f(rr[m][u], r);
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (tv[m][u][i] - mean) * rstd * gp[u][i] + bp[u][i];
-        u32x4 lo = pack8<T>(o); unpack8<T>(lo, o);          // LayerNorm output rounded before the residual add
+        if (!SF) { u32x4 lo = pack8<T>(o); unpack8<T>(lo, o); }   // all-T form: LayerNorm output rounded before the residual add
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] += r[i];
-        const u32x4 ov = pack8<T>(o);
-        unpack8<T>(ov, tv[m][u]);
+        if (!SF) { const u32x4 ov = pack8<T>(o); unpack8<T>(ov, o); }   // t rounded to its storage type
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tv[m][u][i] = o[i];
         if (!(u ? ok1 : ok0)) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) tv[m][u][i] = 0.f;
         } else if (blockIdx.x == 0 && q.t_out && m < p.M)
-          *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(q.t_out) + (size_t)m * K + (u ? v1 : v0) * 8) = ov;
+          (void)SR::st(q.t_out, (size_t)m * K + (u ? v1 : v0) * 8, o, 0u);
       }
     }
   }
@@ -1746,9 +1754,14 @@ __global__ __launch_bounds__(256) void gemv_ln_kernel(const GemvLnArgs q) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) amax_pk = absmax_pk8(amax_pk, pack8<T>(tv[m][u]));     // rows >= M and vectors past K are zero
+      for (int u = 0; u < 2; ++u) {                                 // rows >= M and vectors past K are zero
+        if (SF) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) amax_pk = max(amax_pk, __float_as_uint(tv[m][u][i]) & 0x7fffffffu);
+        } else amax_pk = absmax_pk8(amax_pk, pack8<T>(tv[m][u]));
+      }
     __syncthreads();
-    const float a = absmax_pk_block<T>(amax_pk, redm);
+    const float a = SF ? absmax_f32_block(amax_pk, redm) : absmax_pk_block<T>(amax_pk, redm);
     if (threadIdx.x == 0) s_amax = a;
     __syncthreads();
     amax = s_amax;
@@ -2158,6 +2171,7 @@ extern "C" int cogv_gemv_ln(const cogv_gemm_desc* d, const cogv_ln_prologue* ln,
        (uintptr_t)ln->residual | (uintptr_t)ln->t_out) & 15) return COGV_ERR_ARG;
   a.z = ln->z; a.z_absmax = ln->z_absmax; a.gamma_p = ln->gamma_post; a.beta_p = ln->beta_post; a.res = ln->residual;
   a.t_out = ln->t_out; a.gamma = ln->gamma; a.beta = ln->beta; a.eps = ln->eps;
+  const bool sf = ln->stream_f32 != 0;
   a.g.splitk = 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int mt = a.g.M <= 1 ? 1 : a.g.M <= 2 ? 2 : a.g.M <= 4 ? 4 : 8;
@@ -2166,8 +2180,13 @@ extern "C" int cogv_gemv_ln(const cogv_gemm_desc* d, const cogv_ln_prologue* ln,
 #define GEMV_LN_LAUNCH(T_, MT_)                                                                                          \
   do {                                                                                                                   \
     static bool attr = false;                                                                                            \
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_ln_kernel<T_, MT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; } \
-    hipLaunchKernelGGL((gemv_ln_kernel<T_, MT_>), grid, block, shmem, st, a);                                             \
+    if (!attr) {                                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_ln_kernel<T_, MT_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_ln_kernel<T_, MT_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);  \
+      attr = true;                                                                                                       \
+    }                                                                                                                    \
+    if (sf) hipLaunchKernelGGL((gemv_ln_kernel<T_, MT_, true>), grid, block, shmem, st, a);                               \
+    else hipLaunchKernelGGL((gemv_ln_kernel<T_, MT_, false>), grid, block, shmem, st, a);                                 \
   } while (0)
   if (d->dtype == COGV_F16) { if (mt == 1) GEMV_LN_LAUNCH(f16_t, 1); else if (mt == 2) GEMV_LN_LAUNCH(f16_t, 2); else if (mt == 4) GEMV_LN_LAUNCH(f16_t, 4); else GEMV_LN_LAUNCH(f16_t, 8); }
   else { if (mt == 1) GEMV_LN_LAUNCH(bf16_t, 1); else if (mt == 2) GEMV_LN_LAUNCH(bf16_t, 2); else if (mt == 4) GEMV_LN_LAUNCH(bf16_t, 4); else GEMV_LN_LAUNCH(bf16_t, 8); }

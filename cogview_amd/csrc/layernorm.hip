@@ -12,6 +12,13 @@
 
 #include <cstdlib>
 
+// rows in flight of the wide STREAM_IN backward (fp32 x, add_in, dx: 20 prefetch registers per row instead of 12).
+// h = 2560, 26112 rows (tools/r3/mb_ln_stream.py): two rows at 162 registers 171.6 us, four rows at 256 registers
+// (+12 B of scratch) 184.7 us.  COGV_LN_BWD_ROWS overrides at run time.
+#ifndef COGV_LN_BWD_STREAM_IN_ROWS
+#define COGV_LN_BWD_STREAM_IN_ROWS 2
+#endif
+
 namespace {
 
 struct LnFwdArgs {
@@ -21,14 +28,16 @@ struct LnFwdArgs {
   int rows, h; float eps;
 };
 
-template <typename T, int NV>
+// MODE (cogview_hip.h COGV_LN_*): 0 = every tensor in the storage type T; 1 (STREAM_IN) = x is the fp32 residual
+// stream, y is T (LN1, LN2, final LN); 2 (STREAM_OUT) = x is T, residual and y are the fp32 stream (LN3, LN4: the
+// LayerNorm output is added to the stream in fp32, no rounding in between), abs-max of y over fp32 values.
+template <typename T, int NV, int MODE>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
+  typedef Row8<T, MODE == 1> XR;
+  typedef Row8<T, MODE == 2> YR;
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
-  const T* X = reinterpret_cast<const T*>(p.x);
-  const T* R = reinterpret_cast<const T*>(p.res);
-  T* Y = reinterpret_cast<T*>(p.y);
   float eps = p.eps;
   if (p.absmax_in) { const float c = *p.absmax_in * 0.125f; eps = p.eps * c * c; }
   const float inv_h = 1.0f / (float)p.h;
@@ -42,7 +51,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
       unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.beta) + col), b[v]);
     }
   }
-  uint32_t amax_pk = 0u;               // running max of |output| bit patterns (absmax_pk)
+  uint32_t amax = 0u;                  // running max of |output| bit patterns (absmax_pk / fp32 patterns)
   for (int row = wave_global; row < p.rows; row += nwaves) {
     float x[NV][8];
     float s = 0.f;
@@ -50,7 +59,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
     for (int v = 0; v < NV; ++v) {
       const int col = (v * 64 + lane) * 8;
       if (col < p.h) {
-        unpack8<T>(*reinterpret_cast<const u32x4*>(X + (size_t)row * p.h + col), x[v]);
+        XR::to_f(XR::ld(p.x, (size_t)row * p.h + col), x[v]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) s += x[v][i];
       } else {
@@ -78,23 +87,24 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (x[v][i] - mean) * rstd * g[v][i] + b[v][i];
-        if (R) {
-          // the reference rounds LN's output to the storage type before the residual add
-          // (mpu/sparse_transformer.py:326-329, :337-340); keep that rounding point
-          u32x4 lo = pack8<T>(o); unpack8<T>(lo, o);
-          float r[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(R + (size_t)row * p.h + col), r);
+        if (p.res) {
+          float r[8];
+          if (MODE != 2) {
+            // all-T form (stand-alone modules): the reference rounds LN's output to the storage type before the
+            // residual add (mpu/sparse_transformer.py:326-329, :337-340); that rounding point is kept here
+            u32x4 lo = pack8<T>(o); unpack8<T>(lo, o);
+          }
+          YR::to_f(YR::ld(p.res, (size_t)row * p.h + col), r);
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] += r[i];
         }
-        const u32x4 ov = pack8<T>(o);
-        *reinterpret_cast<u32x4*>(Y + (size_t)row * p.h + col) = ov;
-        amax_pk = absmax_pk8(amax_pk, ov);
+        amax = YR::st(p.y, (size_t)row * p.h + col, o, amax);
       }
     }
   }
   if (p.absmax_out) {
     __shared__ uint32_t red[16];
-    const float bm = absmax_pk_block<T>(amax_pk, red);
+    const float bm = MODE == 2 ? absmax_f32_block(amax, red) : absmax_pk_block<T>(amax, red);
     if (threadIdx.x == 0) atomic_max_nonneg(p.absmax_out, bm);
   }
 }
@@ -114,17 +124,18 @@ struct LnBwdArgs {
 // no cross-wave reduction -- the wave-per-row form kept 3 * h / 64 of them per lane (120 at h = 2560), which capped
 // occupancy at two waves per SIMD and ran at 2 TB/s.  R rows are in flight per iteration (R * 2..3 16-byte
 // loads per lane); the two row statistics go through a double-buffered LDS exchange, one barrier per R rows.
-template <typename T, int R>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 2 ? 4 : 2)))
+// MODE as in ln_fwd_kernel, seen from the backward side: 1 (STREAM_IN: LN1, LN2) = x, add_in and dx are the fp32
+// stream / its gradient, dy is T;  2 (STREAM_OUT: LN3, LN4) = dy is the fp32 stream gradient, x, add_in, dx are T.
+template <typename T, int R, int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 2 ? 3 : 2)))
 void ln_bwd_kernel(const LnBwdArgs p) {
+  typedef Row8<T, MODE == 2> DYR;
+  typedef Row8<T, MODE == 1> XR;       // x, add_in, dx
   __shared__ float red[2][R][8][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int col = threadIdx.x * 8;
   const bool act = col < p.h;
-  const T* DY = reinterpret_cast<const T*>(p.dy);
-  const T* X = reinterpret_cast<const T*>(p.x);
-  const T* AD = reinterpret_cast<const T*>(p.add_in);
-  T* DX = reinterpret_cast<T*>(p.dx);
+  const bool has_add = p.add_in != nullptr;
   const float inv_h = 1.0f / (float)p.h;
 
   float g[8], dg[8], db[8], cs[8];
@@ -132,29 +143,30 @@ void ln_bwd_kernel(const LnBwdArgs p) {
   for (int i = 0; i < 8; ++i) { g[i] = 0.f; dg[i] = 0.f; db[i] = 0.f; cs[i] = 0.f; }
   if (act) unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.gamma) + col), g);
   int buf = 0;
-  u32x4 dyn[R], xn_[R], adn[R];      // the NEXT iteration's rows: loaded before this iteration's barrier and stores
+  typename DYR::raw dyn[R];            // the NEXT iteration's rows: loaded before this iteration's barrier and stores
+  typename XR::raw xn_[R], adn[R];
   float meann[R], rstdn[R];
   auto fetch = [&](int row0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int row = row0 + r;
       const bool ok = act && row < p.rows;
-      dyn[r] = ok ? *reinterpret_cast<const u32x4*>(DY + (size_t)row * p.h + col) : u32x4{0u, 0u, 0u, 0u};
-      xn_[r] = ok ? *reinterpret_cast<const u32x4*>(X + (size_t)row * p.h + col) : u32x4{0u, 0u, 0u, 0u};
-      if (AD) adn[r] = ok ? *reinterpret_cast<const u32x4*>(AD + (size_t)row * p.h + col) : u32x4{0u, 0u, 0u, 0u};
+      dyn[r] = ok ? DYR::ld(p.dy, (size_t)row * p.h + col) : DYR::zero();
+      xn_[r] = ok ? XR::ld(p.x, (size_t)row * p.h + col) : XR::zero();
+      if (has_add) adn[r] = ok ? XR::ld(p.add_in, (size_t)row * p.h + col) : XR::zero();
       meann[r] = row < p.rows ? p.mean[row] : 0.f;
       rstdn[r] = row < p.rows ? p.rstd[row] : 0.f;
     }
   };
   fetch(blockIdx.x * R);
   for (int row0 = blockIdx.x * R; row0 < p.rows; row0 += gridDim.x * R) {
-    u32x4 adv[R];
+    typename XR::raw adv[R];
     float rstd[R], s1[R], s2[R];
     float xhk[R][8], gyk[R][8];        // normalised input and gamma * dy of the rows in flight (kept for phase 2)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       float dy[8];
-      unpack8<T>(dyn[r], dy); unpack8<T>(xn_[r], xhk[r]);
+      DYR::to_f(dyn[r], dy); XR::to_f(xn_[r], xhk[r]);
       adv[r] = adn[r]; rstd[r] = rstdn[r];
       const float mr = meann[r] * rstdn[r];
       float a1 = 0.f, a2 = 0.f;
@@ -193,17 +205,15 @@ void ln_bwd_kernel(const LnBwdArgs p) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] = (drop_bits16(rn, i) >= p.thr16) ? o[i] * p.keep_scale : 0.f;
         }
-        if (AD) {
-          float a[8]; unpack8<T>(adv[r], a);
+        if (has_add) {
+          float a[8]; XR::to_f(adv[r], a);
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] += a[i];
         }
-        const u32x4 ov = pack8<T>(o);
-        *reinterpret_cast<u32x4*>(DX + (size_t)row * p.h + col) = ov;
+        (void)XR::st(p.dx, (size_t)row * p.h + col, o, 0u);        // o <- the stored (rounded) values
         if (p.want_colsum) {
-          float rr[8]; unpack8<T>(ov, rr);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) cs[i] += rr[i];
+          for (int i = 0; i < 8; ++i) cs[i] += o[i];
         }
       }
     }
@@ -252,25 +262,40 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* partia
 // Forward grid: ONE resident round of workgroups, each wave looping over its rows (h = 2560: 152 registers = 3
 // workgroups per CU = 768; the former 4096 ran 5.3 rounds with a third-full last one: 47.4 -> 45.1 us plain,
 // 95.8 -> 84.2 us with the fused residual add; h = 1024: 1536 resident, same time as 4096).  COGV_LN_FWD_BLOCKS overrides.
-template <typename T, int NV> void launch_fwd(const LnFwdArgs& a, int blocks, hipStream_t st) {
+template <typename T, int NV, int MODE> void launch_fwd_m(const LnFwdArgs& a, int blocks, hipStream_t st) {
   static const int resident = [] {
     const char* e = getenv("COGV_LN_FWD_BLOCKS");
     if (e && atoi(e) > 0) return atoi(e);
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ln_fwd_kernel<T, NV>, 256, 0) != hipSuccess || per_cu < 1) return 4096;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ln_fwd_kernel<T, NV, MODE>, 256, 0) != hipSuccess || per_cu < 1) return 4096;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 4096;
     return per_cu * prop.multiProcessorCount;
   }();
   if (blocks > resident) blocks = resident;
-  hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((ln_fwd_kernel<T, NV, MODE>), dim3(blocks), dim3(256), 0, st, a);
 }
-template <typename T> void launch_bwd(const LnBwdArgs& a, int blocks, hipStream_t st) {
+template <typename T, int NV> void launch_fwd(const LnFwdArgs& a, int mode, int blocks, hipStream_t st) {
+  if (mode == COGV_LN_STREAM_IN) launch_fwd_m<T, NV, 1>(a, blocks, st);
+  else if (mode == COGV_LN_STREAM_OUT) launch_fwd_m<T, NV, 2>(a, blocks, st);
+  else launch_fwd_m<T, NV, 0>(a, blocks, st);
+}
+inline int ln_bwd_stream_in_rows() {
+  static const int rows_env = [] { const char* e = getenv("COGV_LN_BWD_ROWS"); return e ? atoi(e) : 0; }();
+  return rows_env ? rows_env : COGV_LN_BWD_STREAM_IN_ROWS;
+}
+template <typename T, int MODE> void launch_bwd_m(const LnBwdArgs& a, int blocks, hipStream_t st) {
   const int nw = (a.h + 511) / 512;             // waves per row (h <= 4096 -> <= 8)
   // wide rows with the dropout replay: two rows in flight at 128 registers (two workgroups per CU) beat four rows at
   // 206 (one per CU) -- 112 vs 129 us at h = 2560; without the replay four rows and one workgroup per CU win (109 vs 116)
-  if (nw >= 4 && a.thr16) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(blocks), dim3(nw * 64), 0, st, a);
-  else hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), dim3(blocks), dim3(nw * 64), 0, st, a);
+  if (nw >= 4 && (a.thr16 || (MODE == 1 && ln_bwd_stream_in_rows() == 2)))
+    hipLaunchKernelGGL((ln_bwd_kernel<T, 2, MODE>), dim3(blocks), dim3(nw * 64), 0, st, a);
+  else hipLaunchKernelGGL((ln_bwd_kernel<T, 4, MODE>), dim3(blocks), dim3(nw * 64), 0, st, a);
+}
+template <typename T> void launch_bwd(const LnBwdArgs& a, int mode, int blocks, hipStream_t st) {
+  if (mode == COGV_LN_STREAM_IN) launch_bwd_m<T, 1>(a, blocks, st);
+  else if (mode == COGV_LN_STREAM_OUT) launch_bwd_m<T, 2>(a, blocks, st);
+  else launch_bwd_m<T, 0>(a, blocks, st);
 }
 
 #define NV_SWITCH(FN, T, nv, ...)                          \
@@ -293,7 +318,7 @@ template <typename T> void launch_bwd(const LnBwdArgs& a, int blocks, hipStream_
 // (plain / residual-gradient add) vs 101 / 115 with 512, and 512 of the two-row form (two per CU) for the dropout-replay
 // variant 112 vs 134 us; a third resident workgroup or a second round is 10-30 % slower.  h = 1024 (2 waves per
 // workgroup): 1024 workgroups 44 us vs 59 with 512, 79 with 256.
-static int ln_bwd_blocks(int rows, int h, bool dropout_replay) {
+static int ln_bwd_blocks(int rows, int h, bool dropout_replay /* or any other use of the two-row form */) {
   static const int forced = [] { const char* e = getenv("COGV_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
   const int nw = (h + 511) / 512;
   int cap = nw >= 4 ? (dropout_replay ? 512 : 256) : 2560 / nw;
@@ -313,16 +338,19 @@ extern "C" size_t cogv_ln_bwd_workspace_bytes(int rows, int h) {
 
 extern "C" int cogv_sandwich_ln_fwd(int dtype, const void* x, const void* gamma, const void* beta, const void* residual,
                                     void* y, float* mean, float* rstd, const float* absmax_in, float* absmax_out,
-                                    int rows, int h, float eps, void* stream) {
+                                    int rows, int h, float eps, int stream_mode, void* stream) {
   if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
   if (rows <= 0 || h <= 0 || (h & 7) || h > 4096) return COGV_ERR_ARG;
   if (!x || !gamma || !beta || !y) return COGV_ERR_ARG;
+  if (stream_mode < 0 || stream_mode > 2) return COGV_ERR_ARG;
+  if (stream_mode == COGV_LN_STREAM_IN && residual) return COGV_ERR_ARG;       // the stream is the input, nothing to add to
+  if (stream_mode == COGV_LN_STREAM_OUT && !residual) return COGV_ERR_ARG;
   if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)residual) & 15) return COGV_ERR_ARG;
   LnFwdArgs a{x, gamma, beta, residual, y, mean, rstd, absmax_in, absmax_out, rows, h, eps};
   const int nv = (h + 511) / 512;
   int blocks = (rows + 3) / 4; if (blocks > 4096) blocks = 4096;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == COGV_F16) { NV_SWITCH(launch_fwd, f16_t, nv, a, blocks, st) } else { NV_SWITCH(launch_fwd, bf16_t, nv, a, blocks, st) }
+  if (dtype == COGV_F16) { NV_SWITCH(launch_fwd, f16_t, nv, a, stream_mode, blocks, st) } else { NV_SWITCH(launch_fwd, bf16_t, nv, a, stream_mode, blocks, st) }
   return cogv_check_launch();
 }
 
@@ -330,8 +358,9 @@ extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, co
                                     const float* rstd, const void* add_in, void* dx, void* dgamma, void* dbeta,
                                     void* colsum, int accumulate_param_grads, int rows, int h, float dropout_p,
                                     uint64_t seed, uint64_t stream_id, void* workspace, size_t workspace_bytes,
-                                    void* stream) {
+                                    int stream_mode, void* stream) {
   if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
+  if (stream_mode < 0 || stream_mode > 2) return COGV_ERR_ARG;
   if (rows <= 0 || h <= 0 || (h & 7) || h > 4096) return COGV_ERR_ARG;
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !workspace) return COGV_ERR_ARG;
   if (workspace_bytes < cogv_ln_bwd_workspace_bytes(rows, h)) return COGV_ERR_ARG;
@@ -343,9 +372,9 @@ extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, co
   a.seed = seed; a.stream_id = stream_id;
   a.thr16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
-  const int blocks = ln_bwd_blocks(rows, h, a.thr16 != 0);
+  const int blocks = ln_bwd_blocks(rows, h, a.thr16 != 0 || (stream_mode == COGV_LN_STREAM_IN && ln_bwd_stream_in_rows() == 2));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == COGV_F16) launch_bwd<f16_t>(a, blocks, st); else launch_bwd<bf16_t>(a, blocks, st);
+  if (dtype == COGV_F16) launch_bwd<f16_t>(a, stream_mode, blocks, st); else launch_bwd<bf16_t>(a, stream_mode, blocks, st);
   if (dgamma || dbeta || colsum) {
     dim3 grid((h + 63) / 64, 3);
     if (dtype == COGV_F16)

@@ -160,6 +160,7 @@ class FP16_Optimizer(object):
             assert self._arena is not None and self._arena is ddp.arena, "sharding needs the fused flat optimizer path"
             self._shard = shard
             self._tables = self._arena.chunk_table(self._group_of, self._norm_of, owned=shard.owned())
+            ddp._shard_consumer = self       # allreduce_params refuses to scatter gradients nobody will gather back
 
     def __getstate__(self):
         raise RuntimeError("FP16_Optimizer should be serialized using state_dict().")
@@ -169,7 +170,8 @@ class FP16_Optimizer(object):
 
     @property
     def lazy_zero_grad_ok(self):
-        return self._arena is not None
+        """Opt-in declared by the model (arena.lazy_ok <- module._cogv_lazy_zero_grad), not a property of the arena."""
+        return self._arena is not None and self._arena.lazy_ok
 
     def finish_lazy_zero_grad(self):
         if self._arena is not None:

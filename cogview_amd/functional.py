@@ -39,7 +39,7 @@ def grad_accumulate(*params):
         return not arenas[0].take_fresh(params)
     for p, a in zip(params, arenas):          # mixed / no arena: zero what is untouched, then accumulate
         if a is not None:
-            a.take_fresh([p])
+            a.ensure_zeroed(p)                # (take_fresh([p]) would hand back "overwrite" WITHOUT zeroing)
     return True
 
 
@@ -106,14 +106,21 @@ def linear(x, weight, bias=None):
 
 
 class _SandwichLN(torch.autograd.Function):
+    """y = [residual +] SandwichLN(x).  The fp32 residual stream is recognised by dtype (ops.sandwich_ln_fwd): an fp32
+    x yields a 16-bit y (LN1, LN2, final LN); an fp32 residual yields the fp32 stream residual + LN(x) (LN3, LN4)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, absmax):
+    def forward(ctx, x, weight, bias, eps, absmax, residual, absmax_out):
         xc = x if x.is_contiguous() else x.contiguous()
         if absmax is None:
             absmax = ops.absmax(xc)
-        y, mean, rstd = ops.sandwich_ln_fwd(xc, weight, bias, eps, absmax)
+        rc = None
+        if residual is not None:
+            rc = residual if residual.is_contiguous() else residual.contiguous()
+        y, mean, rstd = ops.sandwich_ln_fwd(xc, weight, bias, eps, absmax, residual=rc, absmax_out=absmax_out)
         ctx.save_for_backward(xc, weight, mean, rstd)
         ctx.bias = bias
+        ctx.has_res = residual is not None
         return y
 
     @staticmethod
@@ -124,12 +131,18 @@ class _SandwichLN(torch.autograd.Function):
         db = grad_buffer(ctx.bias) if ctx.bias.requires_grad else None
         dx = ops.sandwich_ln_bwd(dyc, xc, weight, mean, rstd, dgamma=dg, dbeta=db,
                                  accumulate=grad_accumulate(weight if dg is not None else None, ctx.bias if db is not None else None))
-        return dx, None, None, None, None
+        return dx, None, None, None, None, (dyc if ctx.has_res else None), None
 
 
-def sandwich_layer_norm(x, weight, bias, eps=1e-5):
-    """LayerNorm(x / (max|x| / 8)) -- mpu/sparse_transformer.py:40-44."""
-    return _SandwichLN.apply(x, weight, bias, eps, getattr(x, "_cogv_absmax", None))
+def sandwich_layer_norm(x, weight, bias, eps=1e-5, residual=None):
+    """LayerNorm(x / (max|x| / 8)) -- mpu/sparse_transformer.py:40-44; with `residual` the sum residual + LN(x) of
+    :329 / :340 (carrying its abs-max for the LayerNorm that follows)."""
+    if residual is None:
+        return _SandwichLN.apply(x, weight, bias, eps, getattr(x, "_cogv_absmax", None), None, None)
+    slot = ops.new_absmax_slot(x.device)
+    y = _SandwichLN.apply(x, weight, bias, eps, getattr(x, "_cogv_absmax", None), residual, slot)
+    y._cogv_absmax = slot
+    return y
 
 
 class _Attention(torch.autograd.Function):
@@ -335,16 +348,18 @@ class _Embedding(torch.autograd.Function):
     Returns (out, absmax slot)."""
 
     @staticmethod
-    def forward(ctx, ids, weight, vocab_start, pos_ids, pos_weight, drop):
+    def forward(ctx, ids, weight, vocab_start, pos_ids, pos_weight, drop, stream):
         mp = mp_world_size_or_1()
         slot = ops.new_absmax_slot(weight.device)
         if mp == 1:
-            out = ops.embedding_fwd(ids, weight, vocab_start, pos_ids, pos_weight, dropout=drop, absmax_out=slot)
+            out = ops.embedding_fwd(ids, weight, vocab_start, pos_ids, pos_weight, dropout=drop, absmax_out=slot,
+                                    out_f32=stream)
         else:
             word = ops.embedding_fwd(ids, weight, vocab_start)
             _mp_allreduce(word)
-            if pos_weight is not None or drop is not None:
-                out = ops.embedding_fwd(None, None, 0, pos_ids, pos_weight, dropout=drop, absmax_out=slot, x_in=word)
+            if pos_weight is not None or drop is not None or stream:
+                out = ops.embedding_fwd(None, None, 0, pos_ids, pos_weight, dropout=drop, absmax_out=slot, x_in=word,
+                                        out_f32=stream)
             else:
                 out = word
                 ops.absmax(out, slot)
@@ -361,13 +376,14 @@ class _Embedding(torch.autograd.Function):
         dtab = grad_buffer(w) if w.requires_grad else None
         for q in (pw if dpos is not None else None, w if dtab is not None else None):
             if q is not None and getattr(q, "_cogv_arena", None) is not None:
-                q._cogv_arena[0].ensure_zeroed(q)         # scatter-add kernel: an untouched gradient is zeroed first
+                q._cogv_arena[0].ensure_zeroed(q)         # the kernel adds its sums to the table: zero an untouched one first
         ops.embedding_bwd(dout, ids, dtab, ctx.vocab_start, pos_ids, dpos, dropout=ctx.drop)
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
-def embedding(ids, weight, vocab_start, pos_ids=None, pos_weight=None, drop=None):
-    out, slot = _Embedding.apply(ids, weight, vocab_start, pos_ids, pos_weight, drop)
+def embedding(ids, weight, vocab_start, pos_ids=None, pos_weight=None, drop=None, stream=False):
+    """stream=True: the result is the transformer's fp32 residual stream (GPT2ParallelTransformer.embed)."""
+    out, slot = _Embedding.apply(ids, weight, vocab_start, pos_ids, pos_weight, drop, bool(stream))
     out._cogv_absmax = slot
     return out
 
@@ -444,7 +460,9 @@ class _LayerCtx:
 
 
 def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
-    """x [b,s,h] -> (out, absmax_out); `keep` is a _LayerCtx to fill (None: inference, nothing retained).
+    """x [b,s,h] fp32 (the residual stream) -> (out fp32, absmax_out); `keep` is a _LayerCtx to fill (None: inference,
+    nothing retained).  Everything that feeds a GEMM (a, qkv, att, ao, c, g, mo) is in the 16-bit storage type; the
+    stream x -> y -> out stays fp32: LN1 / LN2 read it, LN3 / LN4 add their output to it in fp32.
     kv_slot (inference): the layer's key/value cache (mpu.transformer.KVCacheSlot): the new keys / values are appended
     and attention runs over the cache.
     Kernel chain (MP=1): LN1 | QKV GEMM+bias | attention | dense GEMM+bias+dropout+absmax | LN3+residual+absmax |
@@ -498,7 +516,7 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
     c, m2, r2 = ops.sandwich_ln_fwd(y, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.bias,
                                     eps, slot_y, save_stats=keep is not None)
     f4 = mlp_m.dense_h_to_4h.weight.shape[0]
-    u = torch.empty((rows, f4), dtype=x.dtype, device=dev) if keep is not None else None
+    u = torch.empty((rows, f4), dtype=a.dtype, device=dev) if keep is not None else None
     # u receives gelu'(pre-activation): backward multiplies by it instead of re-evaluating the sigmoid
     g = ops.gemm(c.view(rows, h), mlp_m.dense_h_to_4h.weight, bias=mlp_m.dense_h_to_4h.bias, gelu=True, gelu_daux=u)
     slot_mo = ops.new_absmax_slot(dev)
@@ -520,7 +538,8 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
 
 
 def _layer_backward(layer, kp, dout, sep):
-    """dout [b,s,h] -> dx; parameter gradients are accumulated into param.grad."""
+    """dout [b,s,h] fp32 (gradient of the residual stream) -> dx fp32; parameter gradients are accumulated into
+    param.grad (16-bit)."""
     att_m, mlp_m = layer.attention, layer.mlp
     b, s, h = kp.x.shape
     rows = b * s

@@ -147,9 +147,8 @@ class DistributedDataParallel(Module):
         # (an optimizer that set .grad = None makes backward allocate loose tensors the exchange would never see)
         esz = self.arena.grad.element_size()
         base = self.arena.grad.data_ptr()
-        self._alias_calls = getattr(self, "_alias_calls", 0) + 1
-        # (772 parameters at 48 layers: checked on the first steps and then every 64th, not 772 pointer reads per step)
-        for p, off in (zip(self.arena.params, self.arena.offsets) if (self._alias_calls <= 2 or self._alias_calls % 64 == 0) else ()):
+        # (772 parameters at 48 layers: ~0.2 ms of host pointer compares per step, hidden behind the queued backward)
+        for p, off in zip(self.arena.params, self.arena.offsets):
             if p.grad is not None and p.grad.data_ptr() != base + off * esz:
                 self.arena.grad[off:off + p.numel()].view(p.shape).copy_(p.grad)
                 p.grad = self.arena.grad[off:off + p.numel()].view(p.shape)
@@ -168,6 +167,12 @@ class DistributedDataParallel(Module):
         if cur < self.arena.total:
             rest.append((cur, self.arena.total))
         if self.shard is not None:
+            if getattr(self, "_shard_consumer", None) is None:
+                # after a reduce-scatter only the owner's slice of each region holds the mean gradient and the parameters
+                # only become consistent again through the optimizer's all-gather: a plain optimizer (or mpu.clip_grad_norm
+                # over model.parameters()) would read partial sums and the replicas would silently diverge
+                raise RuntimeError("DistributedDataParallel(shard_optimizer=True) needs an FP16_Optimizer attached with "
+                                   "optimizer.attach_data_parallel(ddp) before the first gradient exchange")
             if fp32_allreduce or no_scale:
                 raise NotImplementedError("shard_optimizer exchanges mean gradients in their 16-bit storage type")
             for s, e in rest:

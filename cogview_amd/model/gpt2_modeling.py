@@ -35,6 +35,10 @@ class GPT2Model(torch.nn.Module):
     """GPT-2 style decoder over concatenated text + image tokens.  `forward` returns
     (logits, *memories); logits are vocabulary-parallel unless parallel_output=False."""
 
+    # Every parameter gradient of this module is written by a fused backward kernel that asks functional.grad_accumulate
+    # (or arena.ensure_zeroed) whether to overwrite or add: the declaration arena.ParamArena.zero_grad(lazy=True) needs.
+    _cogv_lazy_zero_grad = True
+
     def __init__(self, num_layers, vocab_size, hidden_size, num_attention_heads, embedding_dropout_prob,
                  attention_dropout_prob, output_dropout_prob, max_sequence_length, max_memory_length,
                  checkpoint_activations, checkpoint_num_layers=1, parallel_output=True, query_window=128,

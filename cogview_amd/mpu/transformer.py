@@ -36,8 +36,9 @@ class LayerNorm(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.ones(*normalized_shape))
         self.bias = torch.nn.Parameter(torch.zeros(*normalized_shape))
 
-    def forward(self, x):
-        return F_.sandwich_layer_norm(x, self.weight, self.bias, self.eps)
+    def forward(self, x, residual=None):
+        """residual (extension): returns residual + LN(x) -- in fp32 when `residual` is the fp32 residual stream."""
+        return F_.sandwich_layer_norm(x, self.weight, self.bias, self.eps, residual=residual)
 
 
 def gelu(x):
@@ -221,6 +222,12 @@ class GPT2ParallelTransformerLayer(torch.nn.Module):
     def forward(self, hidden_states, ltor_mask, pivot_idx=None, is_sparse=0, mem=None, recompute=False,
                 on_backward_done=None):
         is_sparse = int(is_sparse)
+        # The hidden state that runs through the layer loop is the fp32 RESIDUAL STREAM (csrc/common.cuh); a 16-bit
+        # input (a layer used on its own, as the reference's modules allow) is widened here and the result narrowed back
+        in_dtype = hidden_states.dtype
+        if in_dtype != torch.float32:
+            out = self.forward(hidden_states.float(), ltor_mask, pivot_idx, is_sparse, mem, recompute, on_backward_done)
+            return out.to(in_dtype)
         if mem is None and self.scale_normalization and is_sparse == 0:
             s = hidden_states.size(1)
             sep = F_.mask_to_sep(ltor_mask, s, s)
@@ -233,14 +240,15 @@ class GPT2ParallelTransformerLayer(torch.nn.Module):
         # op-by-op composition (memories / no Sandwich-LN), exactly the reference's dataflow
         a = self.input_layernorm(hidden_states)
         if mem is not None and not isinstance(mem, KVCacheSlot):
-            mem = self.input_layernorm(mem)
+            mem = self.input_layernorm(mem.float() if mem.dtype != torch.float32 else mem)
         att = self.attention(a, ltor_mask, pivot_idx, is_sparse, mem)
         if self.scale_normalization:
-            att = self.third_layernorm(att)
-        y = F_.add(hidden_states, att)
+            y = self.third_layernorm(att, residual=hidden_states)        # x + LN3(att), summed in fp32
+        else:
+            y = F_.add(hidden_states, att)
         m = self.mlp(self.post_attention_layernorm(y))
         if self.scale_normalization:
-            m = self.fourth_layernorm(m)
+            return self.fourth_layernorm(m, residual=y)
         return F_.add(y, m)
 
 
@@ -299,7 +307,7 @@ class GPT2ParallelTransformer(torch.nn.Module):
         mpu/sparse_transformer.py:522-524); returns hidden states carrying their abs-max slot."""
         drop = F_._drop(self.embedding_dropout.p, self.training)
         return F_.embedding(input_ids, word_embeddings.weight, word_embeddings.vocab_start_index, position_ids,
-                            self.position_embeddings.weight, drop)
+                            self.position_embeddings.weight, drop, stream=True)
 
     def forward(self, hidden_states, position_ids, attention_mask, txt_indices_bool, img_indices_bool, is_sparse=0,
                 *mems, embedded=False):
@@ -318,6 +326,8 @@ class GPT2ParallelTransformer(torch.nn.Module):
             pos = F_.embedding(position_ids, self.position_embeddings.weight, 0)
             hidden_states = F_.add(hidden_states, pos.expand_as(hidden_states).contiguous())
             hidden_states = F_.dropout(hidden_states, self.embedding_dropout.p, self.training)
+        if hidden_states.dtype != torch.float32:
+            hidden_states = hidden_states.float()        # from here on: the fp32 residual stream
         mem_layers = [hidden_states.detach()] if self.max_memory_length > 0 else []
         recompute = bool(self.checkpoint_activations) and torch.is_grad_enabled()
         if is_sparse == 1:

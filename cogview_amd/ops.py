@@ -267,9 +267,13 @@ def gemv_ln(z, w, bias, gamma, beta, eps, z_absmax=None, post=None, residual=Non
     assert z.dim() == 2 and w.dim() == 2 and z.is_contiguous() and w.stride(1) == 1 and z.shape[1] == w.shape[1]
     M, K = z.shape
     N = w.shape[0]
-    out = torch.empty((M, N), dtype=z.dtype, device=z.device)
+    # fp32 residual stream (see sandwich_ln_fwd): the residual of the post-LN form, or z itself in the plain-input form
+    stream32 = (residual.dtype == torch.float32) if post is not None else (z.dtype == torch.float32)
+    if post is not None:
+        assert z.dtype == w.dtype
+    out = torch.empty((M, N), dtype=w.dtype, device=z.device)
     d = L.GemmDesc()
-    d.dtype = dt_code(z)
+    d.dtype = dt_code(w)
     d.M, d.N, d.K = M, N, K
     d.A, d.lda = z.data_ptr(), K
     d.B, d.ldb = w.data_ptr(), w.stride(0)
@@ -292,9 +296,10 @@ def gemv_ln(z, w, bias, gamma, beta, eps, z_absmax=None, post=None, residual=Non
         assert residual is not None and residual.is_contiguous() and residual.shape == z.shape and z_absmax is not None
         ln.gamma_post, ln.beta_post, ln.residual = post[0].data_ptr(), post[1].data_ptr(), residual.data_ptr()
         if want_t:
-            t = torch.empty_like(z)
+            t = torch.empty_like(residual)
             ln.t_out = t.data_ptr()
     ln.gamma, ln.beta, ln.eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
+    ln.stream_f32 = int(stream32)
     L.check(L.lib().cogv_gemv_ln(C.byref(d), C.byref(ln), _stream()), "cogv_gemv_ln")
     return out, t
 
@@ -356,33 +361,63 @@ def gemm_grouped(problems, trans_a=True, trans_b=True, accumulate=True):
 
 
 # ------------------------------------------------------------------------------------------ Sandwich-LN
+LN_ALL_T, LN_STREAM_IN, LN_STREAM_OUT = 0, 1, 2       # cogview_hip.h COGV_LN_*
+
+
 def sandwich_ln_fwd(x, gamma, beta, eps, absmax_in, residual=None, absmax_out=None, save_stats=True):
+    """y = [residual +] SandwichLN(x).  The fp32 RESIDUAL STREAM is recognised by dtype: an fp32 `x` (with 16-bit
+    gamma) is the stream feeding a branch -> y in gamma's type (LN1, LN2, final LN); an fp32 `residual` is the stream
+    a branch output joins -> y fp32 = residual + LN(x), no rounding in between (LN3, LN4)."""
     _need_gpu(x, gamma, beta)
     h = x.shape[-1]
     x2 = x.reshape(-1, h)
     assert x2.is_contiguous()
     rows = x2.shape[0]
-    y = torch.empty_like(x2)
-    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
-    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    mode, ydt = LN_ALL_T, gamma.dtype
     r2 = None
     if residual is not None:
         r2 = residual.reshape(-1, h)
         assert r2.is_contiguous()
-    L.check(L.lib().cogv_sandwich_ln_fwd(dt_code(x), _p(x2), _p(gamma), _p(beta), _p(r2), _p(y), _p(mean), _p(rstd),
-                                         _p(absmax_in), _p(absmax_out), rows, h, float(eps), _stream()),
+        if residual.dtype == torch.float32:
+            mode, ydt = LN_STREAM_OUT, torch.float32
+        elif residual.dtype != gamma.dtype:
+            raise L.CogviewHipError("Sandwich-LN residual must be fp32 (the residual stream) or the storage type")
+    if x.dtype == torch.float32:
+        if mode == LN_STREAM_OUT:
+            raise L.CogviewHipError("Sandwich-LN: an fp32 input with an fp32 residual is not a form the layer uses")
+        mode = LN_STREAM_IN
+    elif x.dtype != gamma.dtype:
+        raise L.CogviewHipError(f"Sandwich-LN input {x.dtype} vs parameters {gamma.dtype}")
+    y = torch.empty((rows, h), dtype=ydt, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    L.check(L.lib().cogv_sandwich_ln_fwd(dt_code(gamma), _p(x2), _p(gamma), _p(beta), _p(r2), _p(y), _p(mean), _p(rstd),
+                                         _p(absmax_in), _p(absmax_out), rows, h, float(eps), mode, _stream()),
             "cogv_sandwich_ln_fwd")
     return y.view(x.shape), mean, rstd
 
 
 def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=None, dbeta=None, colsum=None,
                     accumulate=False):
-    """dx = [add_in +] mask(LN'(dy)).  dgamma/dbeta/colsum: preallocated [h] tensors (or None)."""
+    """dx = [add_in +] mask(LN'(dy)).  dgamma/dbeta/colsum: preallocated [h] tensors (or None).
+    Stream forms by dtype, mirroring sandwich_ln_fwd: fp32 `x` (LN1, LN2: the saved stream) -> dx fp32, add_in fp32;
+    fp32 `dy` (LN3, LN4: the stream's gradient) with a 16-bit x -> dx 16-bit."""
     _need_gpu(dy, x)
     h = x.shape[-1]
     dy2, x2 = dy.reshape(-1, h), x.reshape(-1, h)
     assert dy2.is_contiguous() and x2.is_contiguous()
     rows = x2.shape[0]
+    mode = LN_ALL_T
+    if x.dtype == torch.float32:
+        mode = LN_STREAM_IN
+        if dy.dtype != gamma.dtype or (add_in is not None and add_in.dtype != torch.float32):
+            raise L.CogviewHipError("Sandwich-LN backward (stream input): dy must be 16-bit and add_in fp32")
+    elif dy.dtype == torch.float32:
+        mode = LN_STREAM_OUT
+        if add_in is not None and add_in.dtype != x.dtype:
+            raise L.CogviewHipError("Sandwich-LN backward (stream output): add_in must have x's type")
+    elif dy.dtype != x.dtype or (add_in is not None and add_in.dtype != x.dtype):
+        raise L.CogviewHipError("Sandwich-LN backward: mixed 16-bit types")
     dx = torch.empty_like(x2)
     a2 = None
     if add_in is not None:
@@ -392,9 +427,9 @@ def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=
     nbytes = lib.cogv_ln_bwd_workspace_bytes(rows, h)
     ws = workspace("ln_bwd", nbytes, x.device)
     p, seed, sid = (0.0, 0, 0) if dropout is None else dropout
-    L.check(lib.cogv_sandwich_ln_bwd(dt_code(x), _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(a2), _p(dx),
+    L.check(lib.cogv_sandwich_ln_bwd(dt_code(gamma), _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(a2), _p(dx),
                                      _p(dgamma), _p(dbeta), _p(colsum), int(accumulate), rows, h, float(p), int(seed),
-                                     int(sid), _p(ws), ws.numel(), _stream()), "cogv_sandwich_ln_bwd")
+                                     int(sid), _p(ws), ws.numel(), mode, _stream()), "cogv_sandwich_ln_bwd")
     return dx.view(x.shape)
 
 
@@ -552,7 +587,9 @@ def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, 
 
 
 # ------------------------------------------------------------------------------------------ embedding
-def embedding_fwd(ids, table, vocab_start, pos_ids=None, pos_table=None, dropout=None, absmax_out=None, x_in=None):
+def embedding_fwd(ids, table, vocab_start, pos_ids=None, pos_table=None, dropout=None, absmax_out=None, x_in=None,
+                  out_f32=False):
+    """out_f32: the result is the transformer's fp32 residual stream (word + position summed in fp32)."""
     _need_gpu(table if table is not None else x_in)
     src = table if table is not None else x_in
     h = src.shape[-1]
@@ -566,17 +603,20 @@ def embedding_fwd(ids, table, vocab_start, pos_ids=None, pos_table=None, dropout
     pos_c = None
     if pos_table is not None:
         pos_c = pos_ids.expand(shape[:-1]).contiguous()
-    out = torch.empty(shape, dtype=src.dtype, device=src.device)
+    out = torch.empty(shape, dtype=torch.float32 if out_f32 else src.dtype, device=src.device)
     p, seed, sid = (0.0, 0, 0) if dropout is None else dropout
     vend = vocab_start + (table.shape[0] if table is not None else 0)
     L.check(L.lib().cogv_embedding_fwd(dt_code(src), _p(ids_c), _p(table), int(vocab_start), int(vend), _p(x_in),
                                        _p(pos_c), _p(pos_table), 0 if pos_table is None else pos_table.shape[0],
-                                       _p(out), _p(absmax_out), n_tok, h, float(p), int(seed), int(sid), _stream()),
-            "cogv_embedding_fwd")
+                                       _p(out), _p(absmax_out), n_tok, h, float(p), int(seed), int(sid), int(out_f32),
+                                       _stream()), "cogv_embedding_fwd")
     return out
 
 
 def embedding_bwd(dout, ids, dtable, vocab_start, pos_ids=None, dpos=None, dropout=None, dx=None):
+    """dtable[id - vocab_start] += sum of the (masked) gradient rows of the tokens carrying id; dpos likewise.  fp32
+    sums in ascending token order, one rounding, no floating-point atomics: deterministic.  dout (and dx) may be fp32
+    (the residual stream's gradient) or the tables' 16-bit type."""
     _need_gpu(dout)
     h = dout.shape[-1]
     dout_c = dout.contiguous()
@@ -585,9 +625,16 @@ def embedding_bwd(dout, ids, dtable, vocab_start, pos_ids=None, dpos=None, dropo
     pos_c = None if pos_ids is None else pos_ids.expand(dout.shape[:-1]).contiguous()
     p, seed, sid = (0.0, 0, 0) if dropout is None else dropout
     vend = vocab_start + (dtable.shape[0] if dtable is not None else 0)
-    L.check(L.lib().cogv_embedding_bwd(dt_code(dout), _p(dout_c), _p(ids_c), _p(dtable), int(vocab_start), int(vend),
-                                       _p(pos_c), _p(dpos), 0 if dpos is None else dpos.shape[0], _p(dx), n_tok, h,
-                                       float(p), int(seed), int(sid), _stream()), "cogv_embedding_bwd")
+    tab = dtable if dtable is not None else dpos
+    d32 = dout.dtype == torch.float32
+    assert dx is None or dx.dtype == dout.dtype
+    lib = L.lib()
+    nbytes = lib.cogv_embedding_bwd_workspace_bytes(0 if dtable is None else dtable.shape[0], 0 if dpos is None else dpos.shape[0])
+    ws = workspace("embedding_bwd", nbytes, dout.device) if nbytes else None
+    L.check(lib.cogv_embedding_bwd(dt_code(tab if tab is not None else dout), _p(dout_c), _p(ids_c), _p(dtable),
+                                   int(vocab_start), int(vend), _p(pos_c), _p(dpos), 0 if dpos is None else dpos.shape[0],
+                                   _p(dx), n_tok, h, float(p), int(seed), int(sid), _p(ws), 0 if ws is None else ws.numel(),
+                                   int(d32), _stream()), "cogv_embedding_bwd")
 
 
 # ------------------------------------------------------------------------------------------ element-wise
@@ -619,7 +666,13 @@ def dropout(x, p, seed, stream_id, absmax_out=None):
 
 
 def add(a, b, absmax_out=None):
+    """a + b.  An fp32 `a` is the residual stream joined by the 16-bit branch output `b` (fp32 result)."""
     _need_gpu(a, b)
+    if a.dtype == torch.float32 and b.dtype != torch.float32:
+        out = torch.empty_like(_flat(a))
+        L.check(L.lib().cogv_add_stream(dt_code(b), _p(a), _p(_flat(b)), _p(out), a.numel(), _p(absmax_out), _stream()),
+                "cogv_add_stream")
+        return out
     out = torch.empty_like(_flat(a))
     L.check(L.lib().cogv_add(dt_code(a), _p(a), _p(_flat(b)), _p(out), a.numel(), _p(absmax_out), _stream()), "cogv_add")
     return out

@@ -29,7 +29,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     @property
     def lazy_zero_grad_ok(self):
-        return all(getattr(p, '_cogv_arena', None) is not None for group in self.param_groups for p in group['params'])
+        return all(getattr(p, '_cogv_arena', None) is not None and p._cogv_arena[0].lazy_ok
+                   for group in self.param_groups for p in group['params'])
 
     def finish_lazy_zero_grad(self):
         for a in self._arenas():

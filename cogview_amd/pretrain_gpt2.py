@@ -225,20 +225,23 @@ def train(model, optimizer, lr_scheduler, train_data_iterator, args):
         # backward + gradient exchange + clip, optimizer step; the logged loss is the mean over all ranks (:361-365)
         lm_loss, _, img_loss, txt_loss = training.forward_step(batch, model, args.txt_loss_scale, args.is_sparse, log=True,
                                                                world_size=args.world_size)
-        if not bool(torch.isfinite(img_loss + txt_loss).all().item()):
+        forward_ok = bool(torch.isfinite(img_loss + txt_loss).all().item())
+        if not forward_ok:
+            # the reference's train_step returns early (:414-416) but its train loop still counts, logs, saves and
+            # honours exit_interval for that iteration (:505-566)
             print('Skipping backward and optimizer step for nan or inf in forwarding!')
             if hasattr(model, 'needs_reduction'):
                 model.needs_reduction = False
             skipped_iters += 1
-            args.iteration += 1
-            continue
-        lm_loss = training.backward_step(optimizer, model, lm_loss, args.clip_grad, half, world_size=args.world_size,
-                                         reduce_loss=True)
-        optimizer.step()
-        if half and optimizer.overflow:
-            skipped_iters += 1
+            lm_loss = (img_loss + txt_loss).detach()
         else:
-            lr_scheduler.step()
+            lm_loss = training.backward_step(optimizer, model, lm_loss, args.clip_grad, half, world_size=args.world_size,
+                                             reduce_loss=True)
+            optimizer.step()
+            if half and optimizer.overflow:
+                skipped_iters += 1
+            else:
+                lr_scheduler.step()
         args.iteration += 1
         total += lm_loss.detach().float().view(())
         if log:

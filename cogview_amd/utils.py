@@ -68,6 +68,14 @@ def save_checkpoint(iteration, model, optimizer, lr_scheduler, args):
     global rank 0 then moves the tracker."""
     if getattr(args, 'deepspeed', False):
         raise NotImplementedError("the DeepSpeed engine is not reproduced; checkpoints are written in the same layout")
+    # sharded exchange: step() all-gathers the updated parameters on a side stream and each layer of the NEXT forward
+    # waits for its own region -- nothing orders that against a state_dict() taken through the unwrapped module, so
+    # wait for the whole arena here (no-op for the all-reduce exchange)
+    wrapped = model
+    while wrapped is not None:
+        if getattr(wrapped, 'shard', None) is not None:
+            wrapped.shard.wait_upto(wrapped.arena.total)
+        wrapped = getattr(wrapped, 'module', None)
     model = _unwrap(model)
     if optimizer is not None and not getattr(args, 'no_save_optim', False) and hasattr(optimizer, 'consolidate_state'):
         optimizer.consolidate_state()        # collective: sharded optimizer state -> full state on every rank

@@ -112,6 +112,8 @@ typedef struct cogv_ln_prologue {
   const void* gamma_post; const void* beta_post; const void* residual; void* t_out;
   const void* gamma; const void* beta;
   float eps;
+  int stream_f32;      /* 1: residual, t_out and (without a post-LN) z are fp32 rows -- the fp32 residual stream (see
+                          cogv_sandwich_ln_fwd); t is then formed and normalised without intermediate roundings */
 } cogv_ln_prologue;
 int cogv_gemv_ln(const cogv_gemm_desc* d, const cogv_ln_prologue* ln, void* stream);
 
@@ -120,16 +122,26 @@ int cogv_gemv_ln(const cogv_gemm_desc* d, const cogv_ln_prologue* ln, void* stre
  * replaces mpu/sparse_transformer.py:40-44 (LayerNorm = FusedLayerNorm(x / (x.abs().max()/8))) and the
  * residual adds at :329 and :340.  mean/rstd ([rows] fp32, may be NULL) are saved for backward.
  * absmax_out (may be NULL): atomicMax of |y| -- the next LayerNorm's scale.
+ * stream_mode -- which tensors are the fp32 RESIDUAL STREAM of the transformer (the hidden state that runs through the
+ * layer loop mpu/sparse_transformer.py:571-613 and its gradient; kept in fp32 so that depth does not cost precision):
+ *   COGV_LN_ALL_T       every tensor in the storage type T (stand-alone LayerNorm; with a residual the LN output is
+ *                       rounded to T before the add, the reference's rounding point at :326-329)
+ *   COGV_LN_STREAM_IN   x (backward: x, add_in, dx) fp32, y (backward: dy) T -- LN1, LN2, final LN; no residual
+ *   COGV_LN_STREAM_OUT  x (backward: x, dx) T, residual and y (backward: dy) fp32 -- LN3, LN4; residual required,
+ *                       y = residual + LN(x) evaluated in fp32 without an intermediate rounding
  */
+#define COGV_LN_ALL_T 0
+#define COGV_LN_STREAM_IN 1
+#define COGV_LN_STREAM_OUT 2
 int cogv_sandwich_ln_fwd(int dtype, const void* x, const void* gamma, const void* beta, const void* residual,
                          void* y, float* mean, float* rstd, const float* absmax_in, float* absmax_out,
-                         int rows, int h, float eps, void* stream);
+                         int rows, int h, float eps, int stream_mode, void* stream);
 /* dx = [add_in +] dropout_mask( LN'(dy) ) ; dgamma/dbeta/colsum (T, [h], any may be NULL) get the column
  * reductions (colsum = column sums of the written dx: the bias gradient of the Linear that produced x). */
 int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
                          const float* rstd, const void* add_in, void* dx, void* dgamma, void* dbeta, void* colsum,
                          int accumulate_param_grads, int rows, int h, float dropout_p, uint64_t seed,
-                         uint64_t stream_id, void* workspace, size_t workspace_bytes, void* stream);
+                         uint64_t stream_id, void* workspace, size_t workspace_bytes, int stream_mode, void* stream);
 size_t cogv_ln_bwd_workspace_bytes(int rows, int h);
 int cogv_ln_bwd_num_blocks(int rows);   /* upper bound of the backward kernel's workgroup count (workspace sizing) */
 
@@ -204,15 +216,21 @@ int cogv_sparse_slot_reduce(int dtype, const void* dk_slots, const void* dv_slot
  * out = dropout( table[ids - vocab_start] (0 outside the shard) [+ pos_table[pos_ids]] ), abs-max of out.
  * replaces VocabParallelEmbedding.forward mpu/layers.py:117-133 and the position add + dropout at
  * mpu/sparse_transformer.py:522-524.  ids == NULL: the word part is read from x_in (model-parallel path,
- * after the all-reduce).  Backward scatter-adds into dtable / dpos with packed 16-bit atomics.
+ * after the all-reduce).  Backward: dtable[id] += the fp32 sum, in ascending token order, of the (dropout-masked)
+ * gradient rows of the tokens carrying id, rounded once (torch's embedding_dense_backward under
+ * mpu/layers.py:117-133 accumulates in fp32 too); dpos likewise per position id.  Deterministic: no floating-point
+ * atomics.  workspace: cogv_embedding_bwd_workspace_bytes(vocab_end - vocab_start (0 without dtable), n_pos (0 without
+ * dpos)) bytes of scratch, 16-byte aligned (cleared by the call itself).
  */
 int cogv_embedding_fwd(int dtype, const int64_t* ids, const void* table, int64_t vocab_start, int64_t vocab_end,
                        const void* x_in, const int64_t* pos_ids, const void* pos_table, int64_t n_pos, void* out,
                        float* absmax_out, int64_t n_tok, int h, float dropout_p, uint64_t seed, uint64_t stream_id,
-                       void* stream);
+                       int out_f32, void* stream);
 int cogv_embedding_bwd(int dtype, const void* dout, const int64_t* ids, void* dtable, int64_t vocab_start,
                        int64_t vocab_end, const int64_t* pos_ids, void* dpos, int64_t n_pos, void* dx,
-                       int64_t n_tok, int h, float dropout_p, uint64_t seed, uint64_t stream_id, void* stream);
+                       int64_t n_tok, int h, float dropout_p, uint64_t seed, uint64_t stream_id, void* workspace,
+                       size_t workspace_bytes, int dout_f32, void* stream);
+size_t cogv_embedding_bwd_workspace_bytes(int64_t table_rows, int64_t n_pos);
 
 /* ------------------------------------------------------------------ element-wise (n % 8 == 0)
  * gelu: mpu/sparse_transformer.py:172-179; dropout: torch.nn.Dropout call sites :167,:233,:524 */
@@ -222,7 +240,10 @@ int cogv_dropout(int dtype, const void* x, void* y, size_t n, float p, uint64_t 
                  float* absmax_out, void* stream);
 int cogv_add(int dtype, const void* a, const void* b, void* out, size_t n, float* absmax_out, void* stream);
 int cogv_scale(int dtype, const void* x, void* y, size_t n, float scale, void* stream);
-int cogv_absmax(int dtype, const void* x, size_t n, float* out, void* stream);      /* atomicMax into *out */
+int cogv_absmax(int dtype, const void* x, size_t n, float* out, void* stream);      /* atomicMax into *out; dtype may be COGV_F32 (n % 4 == 0) */
+/* out(fp32) = a(fp32) + b(T): a branch output joins the fp32 residual stream (the residual adds of
+ * mpu/sparse_transformer.py:329,:340 when the layer is composed op by op); abs-max of out like cogv_add */
+int cogv_add_stream(int dtype, const float* a, const void* b, float* out, size_t n, float* absmax_out, void* stream);
 /* out[n] (+)= sum_m dy[m][n]  -- bias gradients of the Linear layers */
 int cogv_colsum(int dtype, const void* dy, int M, int N, int ld, void* out, int accumulate, void* workspace,
                 size_t workspace_bytes, void* stream);

@@ -1,0 +1,89 @@
+"""Parity AT DEPTH (round-2 verdict, item 1): the HIP forward of the configurations BASELINE.json names -- cfg 2
+(24 layers / 1024 hidden / 16 heads) and cfg 3/4 (48 layers / 2560 hidden / 40 heads, vocabulary 58240), one sequence of
+1088 positions -- against the fp32 CPU oracle run through ALL layers on the same storage-rounded weights (seed 1234,
+ids randint(0, 58219); LayerNorm affines and biases perturbed so they are not the trivial 1 / 0 of a fresh model).
+
+Bars (relative L2 of the logits against the fp32 oracle): fp16 < 1e-3 -- BASELINE.json's north-star number, asserted at
+the depth it is quoted for; bf16 < 8e-3 (8 significant bits: 2^-9 per rounding point).  The residual stream after 1, 2,
+4, 8, 16, 24, 32, 48 layers is compared too and the growth printed: with the stream held in fp32 the error no longer
+accumulates with depth (round 2, 16-bit stream: 5.6e-4 after one layer -> 1.8e-3 after 48 in fp16, 1.4e-2 in bf16).
+cfg 2 also runs the oracle's BACKWARD pass: loss and every parameter gradient of the 24-layer model.
+Reference: layer loop mpu/sparse_transformer.py:571-613, logits model/gpt2_modeling.py:106-123.
+"""
+import pytest
+import torch
+
+from oracle import cogview_oracle as O
+from oracle import depth_check as D
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"cogview-small-336M": (24, 1024, 16), "cogview-base-4B": (48, 2560, 40)}
+VOCAB, N_IDS, S = 58240, 58219, 1088
+LOGIT_TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+STREAM_TOL = {torch.float16: 8e-4, torch.bfloat16: 6e-3}
+GRAD_TOL = {torch.float16: 1e-2, torch.bfloat16: 6e-2}
+
+
+def _build(cfg, dtype):
+    from cogview_amd.fp16 import FP16_Module
+    from cogview_amd.model import GPT2Model
+    L, h, heads = CFG[cfg]
+    torch.manual_seed(1234)
+    m = GPT2Model(L, VOCAB, h, heads, 0.1, 0.1, 0.1, S + 1, 0, False)
+    with torch.no_grad():
+        for _, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    return FP16_Module(m.cuda(), dtype=dtype, keep_half_outputs=True), L, heads
+
+
+def _ids():
+    return torch.randint(0, N_IDS, (1, S), generator=torch.Generator().manual_seed(1234))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cfg", ["cogview-small-336M", "cogview-base-4B"])
+def test_logits_and_residual_stream_at_full_depth(cfg, dtype):
+    model, L, heads = _build(cfg, dtype)
+    rep = D.depth_report(model.module, _ids().cuda(), L, heads)
+    print(f"\n[{cfg} {dtype}] logits rel-L2 {rep['logits']:.3e}; residual stream after n layers: " +
+          " ".join(f"{n}:{e:.2e}" for n, e in rep["stream"].items()) + f" (oracle {rep['oracle_seconds']:.0f}s)")
+    assert rep["logits"] < LOGIT_TOL[dtype], rep
+    assert max(rep["stream"].values()) < STREAM_TOL[dtype], rep
+    assert rep["stream"][0] < 1e-6          # the embedding sum is exact in the fp32 stream
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gradients_of_the_24_layer_model_vs_oracle(dtype):
+    """cfg 2, full depth: loss and every parameter gradient against the oracle's autograd (fp32, same rounded weights)."""
+    from cogview_amd import training
+    cfg = "cogview-small-336M"
+    model, L, heads = _build(cfg, dtype)
+    model.eval()                                            # dropout off (parity protocol)
+    g = torch.Generator().manual_seed(99)
+    row = torch.randint(0, N_IDS, (1, S + 1), generator=g)
+    tokens, labels = row[:, :-1], row[:, 1:]
+    lmask = torch.ones(1, S)
+    pos = torch.arange(S).unsqueeze(0)
+    batch = (tokens.cuda(), labels.cuda(), lmask.cuda(), 0, pos.cuda())
+    loss, _, _, _ = training.forward_step(batch, model, log=False)
+    # fp16 needs the loss scale the training step runs with (fp16/loss_scaler.py): d(loss)/d(logit) ~ 1e-5 / 1088 is
+    # below fp16's smallest subnormal.  A power of two, so unscaling is exact.
+    scale = 2.0 ** 14 if dtype == torch.float16 else 1.0
+    (loss * scale).backward()
+    pr = {n: p.detach().float().cpu().requires_grad_(True) for n, p in model.module.named_parameters()}
+    l_ref = O.lm_loss(O.gpt2_forward(tokens, pos, O.build_mask(S, S), pr, L, heads), labels, lmask)
+    l_ref.backward()
+    assert abs(loss.item() - l_ref.item()) < 2e-3 * abs(l_ref.item()), (loss.item(), l_ref.item())
+    worst, worst_n, by_layer = 0.0, "", {}
+    for n, p in model.module.named_parameters():
+        e = D.rel_l2(p.grad.float() / scale, pr[n].grad)
+        if n.startswith("transformer.layers."):
+            li = int(n.split(".")[2])
+            by_layer[li] = max(by_layer.get(li, 0.0), e)
+        if e > worst:
+            worst, worst_n = e, n
+    print(f"\n[{cfg} {dtype}] loss {loss.item():.5f} (oracle {l_ref.item():.5f}); worst gradient rel-L2 {worst:.2e} ({worst_n}); "
+          "worst per layer: " + " ".join(f"{li}:{by_layer[li]:.1e}" for li in (0, 1, 3, 7, 15, 23)))
+    assert worst < GRAD_TOL[dtype], (worst, worst_n)

@@ -342,6 +342,9 @@ def test_lazy_zero_grad_bookkeeping():
     ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 300, 7, 64)]
     a = ParamArena(ps, torch.float32, torch.device("cpu"))
     a.grad.fill_(7.0)
+    with pytest.raises(RuntimeError):                    # lazy is an opt-in the owning module declares
+        a.zero_grad(lazy=True)
+    a.lazy_ok = True
     a.zero_grad(lazy=True)
     assert float(a.grad.abs().max()) == 7.0 and all(p.grad.data_ptr() == a.grad.data_ptr() + 4 * o for p, o in zip(ps, a.offsets))
     assert F_.grad_accumulate(ps[0]) is False            # first producer of ps[0]: overwrite ...
@@ -361,3 +364,38 @@ def test_lazy_zero_grad_bookkeeping():
     assert F_.grad_accumulate(loose) is True and F_.grad_accumulate(loose, ps[1]) is True
     a.zero_grad()                                        # the ordinary call is still a memset
     assert float(a.grad.abs().max()) == 0.0 and a._fresh is None
+    # mixed groups while BOTH members are still fresh (round-2 advisor finding: take_fresh([p]) on a single fresh
+    # parameter answered "overwrite" without zeroing, and the caller then accumulated onto stale values)
+    pa = [torch.nn.Parameter(torch.randn(n)) for n in (9, 130)]
+    pb = [torch.nn.Parameter(torch.randn(n)) for n in (4,)]
+    A, B = ParamArena(pa, torch.float32, torch.device("cpu")), ParamArena(pb, torch.float32, torch.device("cpu"))
+    A.lazy_ok = B.lazy_ok = True
+    A.grad.fill_(3.0); B.grad.fill_(5.0)
+    A.zero_grad(lazy=True); B.zero_grad(lazy=True)
+    assert F_.grad_accumulate(loose, pa[0]) is True and float(pa[0].grad.abs().max()) == 0.0      # loose + fresh arena param
+    assert F_.grad_accumulate(pa[1], pb[0]) is True                                                # two arenas, both fresh
+    assert float(pa[1].grad.abs().max()) == 0.0 and float(pb[0].grad.abs().max()) == 0.0
+    assert not A._fresh and not B._fresh
+
+
+def test_lazy_zero_grad_is_an_opt_in_with_an_autograd_guard():
+    """Lazy zero_grad is sound only when every gradient of the arena comes from a kernel that asks grad_accumulate: the
+    module declares it (_cogv_lazy_zero_grad -> arena.lazy_ok -> optimizer.lazy_zero_grad_ok), and a gradient that reaches
+    an untouched arena parameter through autograd's AccumulateGrad raises instead of adding onto stale data."""
+    from cogview_amd.arena import ParamArena
+    from cogview_amd.model import GPT2Model
+    from cogview_amd.optim import FusedAdam
+    assert GPT2Model._cogv_lazy_zero_grad is True
+    ps = [torch.nn.Parameter(torch.randn(6)), torch.nn.Parameter(torch.randn(3))]
+    a = ParamArena(ps, torch.float32, torch.device("cpu"))
+    opt = FusedAdam(ps, lr=1e-3)
+    assert opt.lazy_zero_grad_ok is False                # nobody declared the contract for these parameters
+    a.lazy_ok = True
+    assert opt.lazy_zero_grad_ok is True
+    a.grad.fill_(9.0)
+    a.zero_grad(lazy=True)
+    with pytest.raises(RuntimeError, match="AccumulateGrad"):
+        (ps[0] * 2.0).sum().backward()                   # a plain torch op on an arena parameter
+    a.zero_grad()                                        # the memset path takes autograd gradients as usual
+    (ps[0] * 2.0).sum().backward()
+    assert torch.equal(ps[0].grad, torch.full((6,), 2.0))

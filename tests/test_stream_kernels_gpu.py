@@ -1,0 +1,205 @@
+"""GPU parity of the round-3 kernel forms, through the C ABI, against the CPU oracle:
+
+  * the fp32 RESIDUAL STREAM forms of Sandwich-LN (stream in: fp32 x -> 16-bit y; stream out: 16-bit x + fp32 residual
+    -> fp32 y, no rounding between the LayerNorm and the add), forward and backward, incl. dropout replay, residual-
+    gradient add and column sums; the embedding writing the stream; the decode GEMV's LayerNorm prologue on the stream;
+  * the deterministic, once-rounded embedding backward (fp32 segmented sums in ascending token order: what torch's
+    embedding_dense_backward does under mpu/layers.py:117-133) -- bit-identical run to run, heavy id repetition,
+    ids outside the shard, clamped position ids.
+
+Tolerances: results stored in fp32 are compared at 2e-6 (they carry no storage rounding); 16-bit results at the
+single-kernel bars of test_kernels_gpu.py (fp16 3e-3, bf16 2e-2).
+"""
+import pytest
+import torch
+
+from oracle import cogview_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: 3e-3, torch.bfloat16: 2e-2}
+TOL32 = 2e-6
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X; run with -m 'not gpu' elsewhere"
+    from cogview_amd import ops as _ops
+    return _ops
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def rnd(shape, dtype, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,h", [(37, 256), (300, 1024), (130, 2560), (9, 4096)])
+def test_sandwich_ln_stream_in(ops, dtype, rows, h):
+    """LN1 / LN2 / final LN: the fp32 stream is normalised into the storage type; backward returns the fp32 stream
+    gradient add_in + LN'(dy)."""
+    g = torch.Generator().manual_seed(rows + h)
+    x = rnd((rows, h), torch.float32, g, 3.0)
+    w, b = (torch.rand(h, generator=g) + 0.5).to(dtype), rnd((h,), dtype, g, 0.1)
+    dy, add_in = rnd((rows, h), dtype, g), rnd((rows, h), torch.float32, g)
+    xr, wr, br = x.clone().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    yr = O.sandwich_layernorm(xr, wr, br, 1e-5)
+    yr.backward(dy.float())
+    xd = x.cuda()
+    amax = ops.absmax(xd)
+    assert amax.item() == x.abs().max().item()
+    y, mean, rstd = ops.sandwich_ln_fwd(xd, w.cuda(), b.cuda(), 1e-5, amax)
+    assert y.dtype == dtype and rel(y, yr) < TOL[dtype]
+    dg, db = torch.zeros(h, dtype=dtype, device="cuda"), torch.zeros(h, dtype=dtype, device="cuda")
+    dx = ops.sandwich_ln_bwd(dy.cuda(), xd, w.cuda(), mean, rstd, add_in=add_in.cuda(), dgamma=dg, dbeta=db)
+    assert dx.dtype == torch.float32 and rel(dx, add_in + xr.grad) < TOL32 * 5
+    assert rel(dg, wr.grad) < TOL[dtype] * 2 and rel(db, br.grad) < TOL[dtype] * 2
+    dx2 = ops.sandwich_ln_bwd(dy.cuda(), xd, w.cuda(), mean, rstd)                 # without the residual-gradient add
+    assert rel(dx2, xr.grad) < TOL32 * 5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,h", [(41, 512), (300, 1024), (130, 2560)])
+def test_sandwich_ln_stream_out(ops, dtype, rows, h):
+    """LN3 / LN4: y = residual + LN(x) evaluated and stored in fp32 (abs-max over the fp32 values); backward takes the
+    fp32 stream gradient, replays the dropout mask of the branch output and emits the branch gradient in 16 bits with
+    its column sums (the bias gradient of the Linear that produced x)."""
+    g = torch.Generator().manual_seed(rows * 3 + h)
+    x, res = rnd((rows, h), dtype, g, 2.0), rnd((rows, h), torch.float32, g, 4.0)
+    w, b = (torch.rand(h, generator=g) + 0.5).to(dtype), rnd((h,), dtype, g, 0.1)
+    xd = x.cuda()
+    amax = ops.absmax(xd)
+    slot = ops.new_absmax_slot(xd.device)
+    y, mean, rstd = ops.sandwich_ln_fwd(xd, w.cuda(), b.cuda(), 1e-5, amax, residual=res.cuda(), absmax_out=slot)
+    ref = res + O.sandwich_layernorm(x.float(), w.float(), b.float())
+    assert y.dtype == torch.float32 and rel(y, ref) < TOL32
+    assert slot.item() == y.abs().max().item()
+    dy = rnd((rows, h), torch.float32, g)
+    xr = x.float().requires_grad_(True)
+    O.sandwich_layernorm(xr, w.float(), b.float()).backward(dy)
+    mask = torch.from_numpy(O.dropout_keep_mask(rows * h, 0.1, 7, 3)).view(rows, h)
+    cs = torch.zeros(h, dtype=dtype, device="cuda")
+    dx = ops.sandwich_ln_bwd(dy.cuda(), xd, w.cuda(), mean, rstd, dropout=(0.1, 7, 3), colsum=cs)
+    assert dx.dtype == dtype and rel(dx, xr.grad * mask) < TOL[dtype]
+    assert rel(cs, dx.float().cpu().sum(0)) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stream_add_and_absmax(ops, dtype):
+    g = torch.Generator().manual_seed(2)
+    a, b = rnd((33, 256), torch.float32, g, 2.0), rnd((33, 256), dtype, g)
+    slot = ops.new_absmax_slot(torch.device("cuda"))
+    out = ops.add(a.cuda(), b.cuda(), absmax_out=slot)
+    assert out.dtype == torch.float32 and torch.equal(out.cpu(), a + b.float())
+    assert slot.item() == out.abs().max().item()
+    a[3, 5] = float("nan")
+    assert ops.absmax(a.cuda()).isnan().item()                    # x.abs().max() propagates NaN
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embedding_writes_the_fp32_stream(ops, dtype):
+    g = torch.Generator().manual_seed(6)
+    V, P, h, b, s = 96, 48, 128, 2, 40
+    table, pos_table = rnd((V, h), dtype, g), rnd((P, h), dtype, g)
+    ids = torch.randint(0, 128, (b, s), generator=g)
+    pos = torch.arange(s).unsqueeze(0).expand(b, -1)
+    vs = 16
+    inside = (ids >= vs) & (ids < vs + V)
+    word = torch.where(inside.unsqueeze(-1), table.float()[(ids - vs).clamp(0, V - 1)], torch.zeros(1))
+    mask = torch.from_numpy(O.dropout_keep_mask(b * s * h, 0.1, 3, 1)).view(b, s, h)
+    slot = ops.new_absmax_slot(torch.device("cuda"))
+    out = ops.embedding_fwd(ids.cuda(), table.cuda(), vs, pos.cuda(), pos_table.cuda(), dropout=(0.1, 3, 1), absmax_out=slot,
+                            out_f32=True)
+    assert out.dtype == torch.float32 and rel(out, (word + pos_table.float()[pos]) * mask) < TOL32
+    assert slot.item() == out.abs().max().item()
+    # backward from the fp32 stream gradient
+    dout = rnd((b, s, h), torch.float32, g)
+    dt, dp = torch.zeros((V, h), dtype=dtype, device="cuda"), torch.zeros((P, h), dtype=dtype, device="cuda")
+    ops.embedding_bwd(dout.cuda(), ids.cuda(), dt, vs, pos.cuda(), dp, dropout=(0.1, 3, 1))
+    dm = dout * mask
+    rt = torch.zeros(V, h).index_add_(0, (ids - vs).clamp(0, V - 1).view(-1), (dm * inside.unsqueeze(-1)).view(-1, h))
+    rp = torch.zeros(P, h).index_add_(0, pos.reshape(-1), dm.view(-1, h))
+    assert torch.equal(dt.cpu(), rt.to(dtype)) or rel(dt, rt) < TOL[dtype] * 0.5
+    assert rel(dp, rp) < TOL[dtype] * 0.5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d32", [False, True])
+def test_embedding_backward_is_deterministic_and_rounds_once(ops, dtype, d32):
+    """Heavy repetition (a handful of ids over thousands of tokens, as padding / frequent image codes produce), ids
+    outside the shard, position ids repeated per batch row and out of range (clamped like the forward): the table
+    gradient must equal round(previous + fp32 sum over the tokens) -- the reference's embedding_dense_backward rounds
+    once -- and two runs must agree bit for bit."""
+    g = torch.Generator().manual_seed(17)
+    V, P, h, b, s, vs = 300, 70, 2560 + 8, 6, 700, 40           # h > 2048: two column slabs, the last one ragged
+    ids = torch.randint(0, 400, (b, s), generator=g)
+    ids[:, ::3] = 77                                            # one id on a third of all tokens
+    ids[2, 100:400] = 123
+    pos = (torch.arange(s) % 90).unsqueeze(0).expand(b, -1).contiguous()      # beyond P - 1: clamped
+    dout = rnd((b, s, h), torch.float32 if d32 else dtype, g)
+    prev_t, prev_p = rnd((V, h), dtype, g), rnd((P, h), dtype, g)
+    mask = torch.from_numpy(O.dropout_keep_mask(b * s * h, 0.1, 5, 9)).view(b, s, h)
+    dm = (dout.double() * mask.double())
+    inside = (ids >= vs) & (ids < vs + V)
+    rt = prev_t.double().index_add_(0, (ids - vs).clamp(0, V - 1).view(-1), (dm * inside.unsqueeze(-1)).view(-1, h))
+    rp = prev_p.double().index_add_(0, pos.clamp(0, P - 1).reshape(-1), dm.view(-1, h))
+    runs = []
+    for _ in range(2):
+        dt, dp = prev_t.cuda().clone(), prev_p.cuda().clone()
+        ops.embedding_bwd(dout.cuda(), ids.cuda(), dt, vs, pos.cuda(), dp, dropout=(0.1, 5, 9))
+        runs.append((dt.cpu(), dp.cpu()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    for got, ref in ((runs[0][0], rt), (runs[0][1], rp)):
+        # ONE rounding of an fp32 sum: equal to the rounded exact (fp64) value except where the fp32 accumulation error
+        # (~1e-6 relative over a few thousand terms) flips a round-to-nearest decision (~0.2 % of the elements); never
+        # further than one unit in the last place.  The 16-bit-atomics kernel of rounds 1-2 rounded once per add.
+        exact = ref.to(dtype)
+        half_ulp_rel = 2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8
+        # (+ the fp32 accumulation error itself, which matters where 1400 unit-size terms cancel to a small sum)
+        assert bool(((got.double() - ref).abs() <= ref.abs() * (2 * half_ulp_rel) + 3e-4).all())
+        assert (got == exact).float().mean().item() > 0.98
+    # rows nobody referenced keep their previous value
+    untouched = torch.ones(V, dtype=torch.bool)
+    untouched[(ids[inside] - vs).unique()] = False
+    assert torch.equal(runs[0][0][untouched], prev_t[untouched])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,N,post,gelu", [(1, 512, 768, False, False), (3, 1024, 512, True, True), (8, 2560, 1024, True, False),
+                                              (2, 4096, 256, True, True)])
+def test_gemv_layernorm_prologue_on_the_fp32_stream(ops, dtype, M, K, N, post, gelu):
+    """cogv_gemv_ln with stream_f32: residual / t (and the plain input) are fp32 rows; t = residual + LN_post(z) without
+    intermediate roundings == what the Sandwich-LN kernel writes in its stream-out form, bit for bit."""
+    g = torch.Generator().manual_seed(M * 100 + K + N)
+    z = rnd((M, K), dtype if post else torch.float32, g, 3.0)
+    res = rnd((M, K), torch.float32, g)
+    w, bias = rnd((N, K), dtype, g, 0.05), rnd((N,), dtype, g)
+    gp, bp = (1.0 + 0.1 * torch.randn(K, generator=g)).to(dtype), (0.1 * torch.randn(K, generator=g)).to(dtype)
+    gn, bn = (1.0 + 0.1 * torch.randn(K, generator=g)).to(dtype), (0.1 * torch.randn(K, generator=g)).to(dtype)
+    eps = 1e-5
+    zd, resd = z.cuda(), res.cuda()
+    zmax = ops.absmax(zd)
+    if post:
+        slot_t = ops.new_absmax_slot(zd.device)
+        t_ref, _, _ = ops.sandwich_ln_fwd(zd, gp.cuda(), bp.cuda(), eps, zmax, residual=resd, absmax_out=slot_t, save_stats=False)
+    else:
+        t_ref, slot_t = zd, zmax
+    x_ref, _, _ = ops.sandwich_ln_fwd(t_ref, gn.cuda(), bn.cuda(), eps, slot_t, save_stats=False)
+    out_ref = ops.gemm(x_ref, w.cuda(), bias=bias.cuda(), gelu=gelu)
+    out, t = ops.gemv_ln(zd, w.cuda(), bias.cuda(), gn.cuda(), bn.cuda(), eps, z_absmax=zmax, post=(gp.cuda(), bp.cuda()) if post else None,
+                         residual=resd if post else None, want_t=post, gelu=gelu)
+    if post:
+        assert t.dtype == torch.float32 and rel(t, t_ref) < 1e-6
+    assert out.dtype == dtype
+    assert rel(out, out_ref) < (2e-3 if dtype == torch.float16 else 1.5e-2)
+    tf = (res + O.sandwich_layernorm(z.float(), gp.float(), bp.float(), eps)) if post else z
+    xin = O.sandwich_layernorm(tf, gn.float(), bn.float(), eps).to(dtype).float()
+    ref = O.linear(xin, w.float(), bias.float())
+    if gelu:
+        ref = O.gelu(ref.to(dtype).float())
+    assert rel(out, ref) < TOL[dtype]
