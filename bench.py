@@ -2,6 +2,7 @@
 """bench.py -- train tokens/sec of the CogView GPT hot path on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 --steps 10 --warmup 3            (spawns its own 8 ranks through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -165,11 +166,29 @@ def cpu_baseline_vqvae(n_img=16):
                       f"encode+quantise {t1 - t0:.2f}s, decode {t2 - t1:.2f}s"}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher -- re-exec this script under
+    torch.distributed.run with one rank per GPU on 127.0.0.1 (what scripts/pretrain_single_node.sh:49 does for the
+    reference with the deepspeed launcher).  Rank 0 of the spawned job prints the one JSON line; the launcher form
+    `python -m torch.distributed.run ... bench.py --gpus N` keeps working (WORLD_SIZE is then already set)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {args.gpus} without a launcher: spawning {args.gpus} ranks: {' '.join(cmd)}")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def setup_dist(args):
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                    # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     # COGV_BENCH_ONE_DEVICE=1 (development only): all ranks share cuda:0 and talk over gloo -- exercises the N > 1
     # control flow of this script on a one-GPU box; RCCL refuses two ranks on one device.  Never set by the driver.

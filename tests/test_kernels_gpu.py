@@ -331,6 +331,39 @@ def test_attention_dropout_mask_replay(ops, dtype):
         assert rel(got, want) < TOL[dtype] * 2, name
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,H,s_q,s_k,sep", [(2, 3, 1088, 1088, 0), (1, 2, 320, 1088, 70)])
+def test_attention_dropout_at_the_bench_length_vs_oracle(ops, dtype, b, H, s_q, s_k, sep):
+    """Attention dropout (p = 0.1, what bench.py runs) against the oracle's mask at the BASELINE length: 1088 x 1088
+    is 17 key blocks per query tile -- the per-row keys published by the dQ kernel, the Weyl step per 4-key group and the
+    quad-shared masks of the dK/dV kernel all have to line up across blocks (round 2 checked one block, s = 96) -- and a
+    `sep` + memory shape (320 queries over 1088 keys, the first 70 + 768 fully visible).  Forward and dQ / dK / dV,
+    q / k / v as strided views of the QKV buffer as in the layer (mpu/sparse_transformer.py:652-673)."""
+    g = torch.Generator().manual_seed(s_q + 7 * s_k)
+    qkv = rnd((b, s_k, 3 * H * 64), dtype, g)
+    q = qkv[:, s_k - s_q:, 0:H * 64].reshape(b, s_q, H, 64)
+    k = qkv[:, :, H * 64:2 * H * 64].reshape(b, s_k, H, 64)
+    v = qkv[:, :, 2 * H * 64:].reshape(b, s_k, H, 64)
+    dout = rnd((b, s_q, H, 64), dtype, g)
+    drop = torch.from_numpy(O.attention_keep_mask(b, H, s_q, s_k, 0.1, 77, 5))
+    o_ref, grads = _attn_ref(q, k, v, sep, drop, dout)
+    qkv_d = dev(qkv)
+    qd = qkv_d[:, s_k - s_q:, 0:H * 64].view(b, s_q, H, 64)
+    kd = qkv_d[:, :, H * 64:2 * H * 64].view(b, s_k, H, 64)
+    vd = qkv_d[:, :, 2 * H * 64:].view(b, s_k, H, 64)
+    o, lse = ops.attention_fwd(qd, kd, vd, sep=sep, dropout=(0.1, 77, 5))
+    assert rel(o, o_ref) < TOL[dtype]
+    # a wrong mask on a single key block is a ~10 % error of that block's rows: look at the worst 64-row slab too
+    worst = max(rel(o[:, i:i + 64], o_ref[:, i:i + 64]) for i in range(0, s_q, 64))
+    assert worst < TOL[dtype] * 2, worst
+    dq, dk, dv = ops.attention_bwd(dev(dout), qd, kd, vd, o, lse, sep=sep, dropout=(0.1, 77, 5))
+    for name, got, want in zip("qkv", (dq, dk, dv), grads):
+        assert rel(got, want) < TOL[dtype] * 2, name
+        n = got.shape[1]
+        worst = max(rel(got[:, i:i + 64], want[:, i:i + 64]) for i in range(0, n, 64))
+        assert worst < TOL[dtype] * 4, (name, worst)
+
+
 def test_attention_full_length_properties(ops):
     """s = 1088 (BASELINE sequence): causal property -- output at position i must not change when
     later keys/values change; checked bit-exactly."""
