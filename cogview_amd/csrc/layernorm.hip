@@ -372,7 +372,9 @@ extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, co
   a.seed = seed; a.stream_id = stream_id;
   a.thr16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
-  const int blocks = ln_bwd_blocks(rows, h, a.thr16 != 0 || (stream_mode == COGV_LN_STREAM_IN && ln_bwd_stream_in_rows() == 2));
+  // (the two-row STREAM_IN form without dropout replay keeps the one-workgroup-per-CU cap: 256 workgroups 167 us vs 178
+  // with 512 at h = 2560, tools/r3/exp1.sh)
+  const int blocks = ln_bwd_blocks(rows, h, a.thr16 != 0);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == COGV_F16) launch_bwd<f16_t>(a, stream_mode, blocks, st); else launch_bwd<bf16_t>(a, stream_mode, blocks, st);
   if (dgamma || dbeta || colsum) {

@@ -263,6 +263,9 @@ def test_data_parallel_wrapper_on_one_gpu(golden_dir):
         dist.init_process_group("nccl", init_method="env://", world_size=1, rank=0)
     if not mpu.model_parallel_is_initialized():
         mpu.initialize_model_parallel(1)
+    # an earlier test of the session may have initialised the default group over gloo: ask for RCCL explicitly
+    rccl = dist.new_group(ranks=[0], backend="nccl")
+    assert dist.get_backend(rccl) == "nccl"
     g = _golden(golden_dir)
     S_, B_ = int(g["cfg"][5]), int(g["cfg"][6])
     pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
@@ -272,8 +275,7 @@ def test_data_parallel_wrapper_on_one_gpu(golden_dir):
     loss.backward()
     want = ref.module._cogv_arena.grad.clone()
     model = _build(g, torch.float16)
-    ddp = PyTorchDistributedDataParallel(model, process_group=mpu.get_data_parallel_group(), bucket_layers=1,
-                                         force_collectives=True)
+    ddp = PyTorchDistributedDataParallel(model, process_group=rccl, bucket_layers=1, force_collectives=True)
     assert ddp.overlap and len(ddp._buckets) == 2
     loss2, _, _, _ = training.forward_step(batch, ddp, log=False)
     loss2.backward()
@@ -304,9 +306,11 @@ def test_rccl_only_branches_of_the_exchanges_on_a_one_rank_group(golden_dir, dty
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29591")
         dist.init_process_group("nccl", init_method="env://", world_size=1, rank=0)
-    assert dist.get_backend() == "nccl"
     if not mpu.model_parallel_is_initialized():
         mpu.initialize_model_parallel(1)
+    # an earlier test of the session may have initialised the default group over gloo: ask for RCCL explicitly
+    rccl = dist.new_group(ranks=[0], backend="nccl")
+    assert dist.get_backend(rccl) == "nccl"
     g = _golden(golden_dir)
     S_, B_ = int(g["cfg"][5]), int(g["cfg"][6])
     pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
@@ -318,7 +322,7 @@ def test_rccl_only_branches_of_the_exchanges_on_a_one_rank_group(golden_dir, dty
         mpu.model_parallel_cuda_manual_seed(1234)
         runner = model
         if wrap:
-            runner = PyTorchDistributedDataParallel(model, process_group=mpu.get_data_parallel_group(), bucket_layers=1,
+            runner = PyTorchDistributedDataParallel(model, process_group=rccl, bucket_layers=1,
                                                     force_collectives=True, shard_optimizer=True)
             assert runner.shard is not None and len(runner.shard.regions) >= 3
             assert sum(b - a for a, b in runner.shard.owned()) == runner.arena.total
