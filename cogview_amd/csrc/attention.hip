@@ -219,8 +219,9 @@ __device__ __forceinline__ void tr_frags_issue(uint32_t tile_addr, const uint32_
 
 // Synchronous variant (reads + wait in ONE asm statement): the destination registers are valid when the
 // statement ends, so it stays correct even if the compiler spills them.  Used by the dK/dV kernel, whose
-// register pressure is at the limit; the asynchronous form above must only be used in spill-free kernels
-// (cogview_amd/csrc/build.py checks ScratchSize == 0 for them).
+// register pressure is at the limit; the asynchronous form above must only be used where the compiler does not spill
+// around it (cogview_amd/csrc/build.py's scan_asm_hazards fails the build on any scratch access or register read while
+// an asm-issued load is still in flight).
 template <typename T, int SB>
 __device__ __forceinline__ void tr_frags_sync(uint32_t tile_addr, const uint32_t (&loff)[2], TrRaw (&r)[2][2]) {
   constexpr int S0 = SB * 32, S1 = SB * 32 + 16;

@@ -64,7 +64,8 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 // bookkeeping turned "tile kt+1 is needed, tile kt+2 may stay in flight" into vmcnt(0) (it drained both register sets
 // before every park in LDS, and half of the older set before issuing the newer one).  The consumer must call
 // wait_loads<N>() on the destination registers before the first use (loads return in order: N = number of younger loads
-// that may remain outstanding).  Only for spill-free kernels (cogview_amd/csrc/build.py checks).
+// that may remain outstanding).  Must not be spilled around (cogview_amd/csrc/build.py scan_asm_hazards: no scratch access
+// and no read of a destination register while the load is in flight).
 __device__ __forceinline__ void ld4_async(f32x4& dst, const float* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
 }
