@@ -259,7 +259,16 @@ class FP16_Optimizer(object):
         if self.overflow:
             return -1
         if self._arena is not None:
-            assert float(norm_type) == 2.0
+            if float(norm_type) != 2.0:
+                # other norms (fp16/fp16.py:312-334 hands norm_type through to clip_grad_norm): the unfused way -- the norm
+                # of the unscaled gradients by mpu.clip_grad_norm's rule, the coefficient folded into the 16-bit gradients;
+                # the fused step then runs without its own (2-norm) clipping
+                self._arena.finish_lazy()
+                params = [p for g in self.optimizer.param_groups for p in g['params'] if p.grad is not None]
+                total = mpu.clip_grad_norm(params, float(max_norm) * self.loss_scale, norm_type) / self.loss_scale
+                self._clip = 0.0
+                self._stats_valid = False
+                return total
             if not self._stats_valid:
                 self._compute_stats()
             self._clip = float(max_norm)             # applied inside cogv_adamw_step from the device-side norm
@@ -328,8 +337,21 @@ class FP16_Optimizer(object):
                 scale, self.loss_scale))
             return
         if self._arena is not None:
+            retval = None
             if closure is not None:
-                raise NotImplementedError("closures are not supported on the fused FP16_Optimizer path")
+                # fp16/fp16.py:431-453 for an inner optimizer that evaluates its closure once per step (Adam): the closure
+                # (zero_grad + forward + self.backward(loss)) is evaluated here, again with a reduced scale while its
+                # gradients overflow; the fused update then uses the scale that last evaluation ran with
+                self.first_closure_call_this_step = False
+                retval = closure()
+                while self.overflow:
+                    bad = self.loss_scaler.loss_scale
+                    self._update_scale(self.overflow)
+                    self.maybe_print("OVERFLOW within closure! Skipping step. Attempted loss scale: {}, reducing to "
+                                     "{}".format(bad, self.loss_scale))
+                    retval = closure()
+                self.first_closure_call_this_step = True
+                scale = self.loss_scaler.loss_scale
             if not self._stats_valid:
                 self._compute_stats()
             groups = self.optimizer.param_groups
@@ -345,7 +367,7 @@ class FP16_Optimizer(object):
             self._stats_valid = False
             if self._shard is not None:
                 self._shard.gather_params()
-            return None
+            return retval
         retval = self._step_with_closure(closure) if closure is not None else self.optimizer.step()
         self._master_params_to_model_params()
         return retval

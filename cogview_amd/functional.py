@@ -671,7 +671,9 @@ class _TransformerLayer(torch.autograd.Function):
         ctx.layer, ctx.sep, ctx.drops, ctx.recompute, ctx.keep = layer, sep, drops, recompute, keep
         ctx.done_cb = on_backward_done
         if recompute:
-            ctx.save_for_backward(xc, absmax_x)
+            # (with mpu.partition_activations_in_checkpoint(True): this model-parallel rank's slice of the layer input)
+            piece, ctx.x_shape = mpu_random.partition_activation(xc)
+            ctx.save_for_backward(piece, absmax_x)
         ctx.mark_non_differentiable(slot)
         return out, slot
 
@@ -682,6 +684,7 @@ class _TransformerLayer(torch.autograd.Function):
             # activation checkpointing (mpu/random.py:273-372): only the layer input was kept; the dropout
             # streams are part of `drops`, so the recomputed forward replays identical masks
             xc, absmax_x = ctx.saved_tensors
+            xc = mpu_random.gather_activation(xc, ctx.x_shape)
             keep = _LayerCtx()
             _layer_forward(ctx.layer, xc, absmax_x, ctx.sep, ctx.drops, keep)
         dx = _layer_backward(ctx.layer, keep, dout, ctx.sep)

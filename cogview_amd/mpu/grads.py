@@ -52,7 +52,16 @@ def clip_grad_norm(parameters, max_norm, norm_type=2):
             torch.distributed.all_reduce(stats, group=get_model_parallel_group())
         total_norm = float(stats[0].item()) ** 0.5
     else:
-        raise NotImplementedError("clip_grad_norm: only the 2-norm and the inf-norm are used by the reference path")
+        # general p-norm (mpu/grads.py:59-69): sum of |g|^p over the counted parameters, summed over the model-parallel
+        # group, then the p-th root.  Nothing on the training path asks for it (the scripts clip the 2-norm), so this is
+        # the reference's own formulation on torch reductions: one device reduction per tensor, ONE host read.
+        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        for p in parameters:
+            if getattr(p, 'model_parallel', False) or mp_rank_or_0() == 0:
+                acc += p.grad.data.double().abs().pow(norm_type).sum()
+        if mp > 1:
+            torch.distributed.all_reduce(acc, group=get_model_parallel_group())
+        total_norm = float(acc.item()) ** (1.0 / norm_type)
     clip_coef = max_norm / (total_norm + 1e-6)
     if clip_coef < 1:
         for p in parameters:

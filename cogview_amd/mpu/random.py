@@ -15,7 +15,8 @@ import contextlib
 
 import torch
 
-from .initialize import get_data_parallel_rank, get_model_parallel_rank, mp_rank_or_0
+from .initialize import (get_data_parallel_rank, get_model_parallel_group, get_model_parallel_rank, mp_rank_or_0,
+                         mp_world_size_or_1)
 
 _MODEL_PARALLEL_RNG_TRACKER_NAME = 'model-parallel-rng'
 
@@ -137,6 +138,28 @@ def detach_variable(inputs):
     return tuple(out)
 
 
+def partition_activation(t):
+    """mpu/random.py:298-310 (with `partition_activations_in_checkpoint(True)`): a checkpointed activation is kept as this
+    model-parallel rank's 1/p of its elements.  Returns (what to save, original shape or None when kept whole)."""
+    mp = mp_world_size_or_1()
+    if not PARTITION_ACTIVATIONS or mp == 1 or t.numel() % mp or not t.is_floating_point():
+        return t, None
+    n = t.numel() // mp
+    r = mp_rank_or_0()
+    return t.detach().contiguous().view(-1)[r * n:(r + 1) * n].clone(), tuple(t.shape)
+
+
+def gather_activation(part, shape):
+    """mpu/random.py:248-266 (get_full_inputs): rebuild the full activation from every model-parallel rank's piece."""
+    if shape is None:
+        return part
+    mp = mp_world_size_or_1()
+    full = torch.empty(part.numel() * mp, dtype=part.dtype, device=part.device)
+    pieces = list(full.chunk(mp))
+    torch.distributed.all_gather(pieces, part.contiguous(), group=get_model_parallel_group())
+    return full.view(shape)
+
+
 class CheckpointFunction(torch.autograd.Function):
     """Re-entrant activation checkpoint (mpu/random.py:273-372): forward under no_grad keeping only the
     inputs and the RNG states; backward restores the states, recomputes with grad, and backpropagates."""
@@ -149,7 +172,19 @@ class CheckpointFunction(torch.autograd.Function):
         ctx.fwd_tracker_states = get_cuda_rng_tracker().get_states()
         ctx.tensor_idx = [i for i, a in enumerate(args) if isinstance(a, torch.Tensor)]
         ctx.other = [None if isinstance(a, torch.Tensor) else a for a in args]
-        ctx.save_for_backward(*[args[i] for i in ctx.tensor_idx])
+        # activation partitioning (mpu/random.py:298-310): every tensor argument but the last one (the mask) is kept as
+        # this rank's slice and all-gathered again in backward
+        saved, ctx.part_shapes, ctx.part_grad = [], [], []
+        for k, i in enumerate(ctx.tensor_idx):
+            t = args[i]
+            if k < len(ctx.tensor_idx) - 1:
+                piece, shape = partition_activation(t)
+            else:
+                piece, shape = t, None
+            saved.append(piece)
+            ctx.part_shapes.append(shape)
+            ctx.part_grad.append(t.requires_grad)
+        ctx.save_for_backward(*saved)
         with torch.no_grad():
             outputs = run_function(*args)
         return outputs
@@ -159,7 +194,10 @@ class CheckpointFunction(torch.autograd.Function):
         if not torch.autograd._is_checkpoint_valid():
             raise RuntimeError("Checkpointing is not compatible with .grad(), please use .backward() if possible")
         args = list(ctx.other)
-        for i, t in zip(ctx.tensor_idx, ctx.saved_tensors):
+        for i, t, shape, rg in zip(ctx.tensor_idx, ctx.saved_tensors, ctx.part_shapes, ctx.part_grad):
+            if shape is not None:
+                t = gather_activation(t, shape)
+                t.requires_grad = rg
             args[i] = t
         detached = detach_variable(tuple(args))
         bwd_cpu = torch.get_rng_state()
@@ -185,9 +223,8 @@ def checkpoint(function, *args):
 
 
 def partition_activations_in_checkpoint(partition_activation):
-    """Kept for API compatibility (mpu/random.py:380-384).  Partitioning checkpointed activations across the
-    model-parallel group is a memory device for 32 GB GPUs; with 288 GB of HBM3E per MI355X it is not used."""
+    """mpu/random.py:380-384.  With it on, a checkpointed layer input is kept as each model-parallel rank's 1/p slice and
+    all-gathered over the model-parallel group when the layer is recomputed (a memory device for 32 GB GPUs: one 4B layer
+    input is 267 MB at b = 24 -- 13 GB over 48 layers -- against 288 GB of HBM3E, so nothing here turns it on)."""
     global PARTITION_ACTIVATIONS
-    PARTITION_ACTIVATIONS = partition_activation
-    if PARTITION_ACTIVATIONS:
-        raise NotImplementedError("activation partitioning is not implemented (not needed with 288 GB HBM)")
+    PARTITION_ACTIVATIONS = bool(partition_activation)

@@ -221,6 +221,39 @@ def w_shard_plan(rank, world):
         assert torch.allclose(arena.grad[a:b], mean[a:b], rtol=1e-6), "owned slice does not hold the mean gradient"
 
 
+def w_activation_partitioning(rank, world):
+    """mpu.partition_activations_in_checkpoint(True) (mpu/random.py:298-360): a checkpointed function's tensor inputs
+    (all but the last, the mask) are kept as this model-parallel rank's 1/p slice and all-gathered for the recompute;
+    outputs and gradients equal the un-checkpointed run."""
+    from cogview_amd import mpu
+    from cogview_amd.mpu import random as R
+    mpu.initialize_model_parallel(world)
+    torch.manual_seed(5)                                  # the same activation on every model-parallel rank
+    x = torch.randn(4, 6, 16, requires_grad=True)
+    mask = torch.tril(torch.ones(6, 6))
+    w = torch.randn(16, 16, requires_grad=True)
+
+    def fn(h, m):
+        return torch.tanh(h @ w) * m.sum(-1).view(1, 6, 1)
+    ref = fn(x, mask)
+    ref.sum().backward()
+    gx, gw = x.grad.clone(), w.grad.clone()
+    x.grad = w.grad = None
+    assert R.partition_activation(x)[1] is None           # off by default: kept whole
+    mpu.partition_activations_in_checkpoint(True)
+    try:
+        piece, shape = R.partition_activation(x)
+        assert piece.numel() == x.numel() // world and shape == tuple(x.shape)
+        assert torch.equal(R.gather_activation(piece, shape), x.detach())
+        out = mpu.checkpoint(fn, x, mask)
+        saved = out.grad_fn.saved_tensors
+        assert saved[0].numel() == x.numel() // world and saved[1].numel() == mask.numel()      # the mask stays whole
+        out.sum().backward()
+    finally:
+        mpu.partition_activations_in_checkpoint(False)
+    assert torch.equal(out, ref) and torch.allclose(x.grad, gx) and torch.allclose(w.grad, gw)
+
+
 def w_checkpoint_mp2_dp2(rank, world):
     """utils.save/load_checkpoint on a 2 x 2 grid: each model-parallel rank's file is written once (by its data-parallel
     rank 0), the tracker by global rank 0, and every rank reloads its own shard."""
@@ -299,6 +332,10 @@ def test_trainer_data_path_world2():
 
 def test_checkpoint_files_world4_mp2():
     _run("w_checkpoint_mp2_dp2", 4)
+
+
+def test_activation_partitioning_world2():
+    _run("w_activation_partitioning", 2)
 
 
 def test_shard_plan_world2():

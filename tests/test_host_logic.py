@@ -399,3 +399,24 @@ def test_lazy_zero_grad_is_an_opt_in_with_an_autograd_guard():
     a.zero_grad()                                        # the memset path takes autograd gradients as usual
     (ps[0] * 2.0).sum().backward()
     assert torch.equal(ps[0].grad, torch.full((6,), 2.0))
+
+
+def test_clip_grad_norm_general_p_norm_matches_torch():
+    """mpu.clip_grad_norm with a p-norm other than 2 / inf (mpu/grads.py:59-69): total = (sum |g|^p)^(1/p) over all
+    parameters, gradients scaled in place by max_norm / (total + 1e-6) when that is < 1 -- torch's clip_grad_norm_ is
+    the same rule at model-parallel size 1."""
+    from cogview_amd import mpu
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (7, 130, 64)]
+    for p in ps:
+        p.grad = torch.randn_like(p)
+        p.model_parallel = False
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    for r, p in zip(ref, ps):
+        r.grad = p.grad.clone()
+    for norm_type, max_norm in ((3.0, 0.5), (1.0, 2.0), (4, 1e9)):
+        want = torch.nn.utils.clip_grad_norm_(ref, max_norm, norm_type=norm_type)
+        got = mpu.clip_grad_norm(ps, max_norm, norm_type)
+        assert abs(got - float(want)) < 1e-5 * float(want)
+        for r, p in zip(ref, ps):
+            assert torch.allclose(r.grad, p.grad, rtol=1e-5, atol=1e-7)

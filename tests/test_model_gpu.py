@@ -182,6 +182,80 @@ def test_train_steps_vs_oracle(golden_dir, dtype):
         assert torch.equal(before, opt._master_flat)
 
 
+def test_fused_optimizer_step_with_closure_and_p_norm_clipping(golden_dir):
+    """FP16_Optimizer on the fused flat path: `step(closure)` (fp16/fp16.py:399-453 -- the closure does zero_grad, forward,
+    optimizer.backward(loss)) must equal backward + step without a closure bit for bit, re-evaluate with a halved scale
+    when the closure's gradients overflow, and `clip_master_grads(max_norm, norm_type=3)` (fp16/fp16.py:312-334 with
+    mpu/grads.py:59-69) must clip by the 3-norm of the unscaled gradients."""
+    from cogview_amd import training
+    from cogview_amd.fp16 import FP16_Optimizer
+    from cogview_amd.model import gpt2_get_params_for_weight_decay_optimization
+    from cogview_amd.optim import FusedAdam
+    g = _golden(golden_dir)
+    S_, B_ = int(g["cfg"][5]), int(g["cfg"][6])
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    batch = (g["tokens"].cuda(), g["labels"].cuda(), g["loss_mask"].cuda(), 0, pos)
+
+    def make(init_scale=2 ** 10):
+        model = _build(g, torch.float16)
+        groups = gpt2_get_params_for_weight_decay_optimization(model.module)
+        for grp in groups:
+            for p in grp["params"]:
+                if not hasattr(p, "model_parallel"):
+                    p.model_parallel = False
+        opt = FP16_Optimizer(FusedAdam(groups, lr=1e-3, weight_decay=0.01), dynamic_loss_scale=True,
+                             dynamic_loss_args={"init_scale": init_scale, "scale_window": 1000, "min_scale": 1, "delayed_shift": 1})
+        return model, opt
+
+    model_a, opt_a = make()
+    for _ in range(2):
+        opt_a.zero_grad()
+        loss_a, *_ = training.forward_step(batch, model_a, log=False)
+        opt_a.backward(loss_a)
+        opt_a.step()
+    model_b, opt_b = make()
+    calls = []
+
+    def closure():
+        opt_b.zero_grad()
+        loss, *_ = training.forward_step(batch, model_b, log=False)
+        opt_b.backward(loss)
+        calls.append(opt_b.loss_scale)
+        return loss
+    for _ in range(2):
+        loss_b = opt_b.step(closure)
+    assert len(calls) == 2 and loss_b.item() == loss_a.item()
+    assert torch.equal(opt_a._master_flat, opt_b._master_flat) and torch.equal(opt_a._m_flat, opt_b._m_flat)
+    assert torch.equal(model_a.module._cogv_arena.data, model_b.module._cogv_arena.data)
+    # overflow inside the closure: evaluated again with the scale halved until the gradients are finite
+    model_c, opt_c = make(init_scale=2.0 ** 40)
+    seen = []
+
+    def closure_c():
+        opt_c.zero_grad()
+        loss, *_ = training.forward_step(batch, model_c, log=False)
+        opt_c.backward(loss)
+        seen.append(opt_c.loss_scale)
+        return loss
+    before = opt_c._master_flat.clone()
+    opt_c.step(closure_c)
+    assert len(seen) > 1 and seen[-1] < seen[0] and not opt_c.overflow
+    assert not torch.equal(before, opt_c._master_flat)
+    # 3-norm clipping on the fused path
+    model_d, opt_d = make()
+    opt_d.zero_grad()
+    loss_d, *_ = training.forward_step(batch, model_d, log=False)
+    opt_d.backward(loss_d)
+    grads = [p.grad.detach().float().cpu() / opt_d.loss_scale for p in model_d.module.parameters()]
+    want = sum(float(t.double().abs().pow(3).sum()) for t in grads) ** (1.0 / 3.0)
+    got = opt_d.clip_master_grads(want / 2, norm_type=3)
+    assert abs(got - want) < 2e-3 * want
+    after = sum(float((p.grad.detach().double().cpu() / opt_d.loss_scale).abs().pow(3).sum()) for p in model_d.module.parameters()) ** (1.0 / 3.0)
+    assert abs(after - want / 2) < 1e-2 * want
+    opt_d.step()
+    assert not opt_d.overflow
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_full_width_layer_vs_oracle(dtype):
     """One layer at the 4B configuration's real width and length (h = 2560, 40 heads, 1088 positions; small vocabulary to
