@@ -264,7 +264,7 @@ class FP16_Optimizer(object):
                 # of the unscaled gradients by mpu.clip_grad_norm's rule, the coefficient folded into the 16-bit gradients;
                 # the fused step then runs without its own (2-norm) clipping
                 self._arena.finish_lazy()
-                params = [p for g in self.optimizer.param_groups for p in g['params'] if p.grad is not None]
+                params = [p for p in self._arena.params if p.grad is not None]      # the 16-bit model parameters (arena views)
                 total = mpu.clip_grad_norm(params, float(max_norm) * self.loss_scale, norm_type) / self.loss_scale
                 self._clip = 0.0
                 self._stats_valid = False

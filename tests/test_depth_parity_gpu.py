@@ -10,6 +10,8 @@ accumulates with depth (round 2, 16-bit stream: 5.6e-4 after one layer -> 1.8e-3
 cfg 2 also runs the oracle's BACKWARD pass: loss and every parameter gradient of the 24-layer model.
 Reference: layer loop mpu/sparse_transformer.py:571-613, logits model/gpt2_modeling.py:106-123.
 """
+import os
+
 import pytest
 import torch
 
@@ -87,3 +89,83 @@ def test_gradients_of_the_24_layer_model_vs_oracle(dtype):
     print(f"\n[{cfg} {dtype}] loss {loss.item():.5f} (oracle {l_ref.item():.5f}); worst gradient rel-L2 {worst:.2e} ({worst_n}); "
           "worst per layer: " + " ".join(f"{li}:{by_layer[li]:.1e}" for li in (0, 1, 3, 7, 15, 23)))
     assert worst < GRAD_TOL[dtype], (worst, worst_n)
+
+
+# ------------------------------------------------------------------------------------------------ cfg 3: model parallel = 2
+MP_VOCAB = 58368                     # 58219 padded to a multiple of 128 x 2 (arguments.py --make-vocab-size-divisible-by)
+
+
+def _perturb_replicated(module, seed=77):
+    """Non-trivial LayerNorm affines and row-parallel biases (replicated over the model-parallel group): the same
+    perturbation on every rank and in the unsharded reference, keyed by the parameter's position."""
+    with torch.no_grad():
+        for k, (n, p) in enumerate(module.named_parameters()):
+            replicated = p.dim() == 1 and ("layernorm" in n or n.endswith("attention.dense.bias") or n.endswith("dense_4h_to_h.bias"))
+            if replicated:
+                p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(seed + k)).to(p.device, p.dtype))
+
+
+def _mp2_worker(rank, world, port, cfg, out_dir, ret):
+    import sys
+    import traceback
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+        torch.cuda.set_device(0)
+        from cogview_amd import mpu
+        from cogview_amd.fp16 import FP16_Module
+        from cogview_amd.model import GPT2Model
+        mpu.initialize_model_parallel(world)
+        L, h, heads = CFG[cfg]
+        torch.manual_seed(1234)                            # every rank draws the FULL master weights, keeps its shard
+        m = GPT2Model(L, MP_VOCAB, h, heads, 0.1, 0.1, 0.1, S + 1, 0, False)
+        _perturb_replicated(m)
+        model = FP16_Module(m.cuda(), dtype=torch.float16, keep_half_outputs=True).eval()
+        ids = _ids().cuda()
+        pos = torch.arange(S, device="cuda").unsqueeze(0)
+        with torch.no_grad():
+            logits, = model(ids, pos, 0, None, None, 0)
+        assert logits.shape == (1, S, MP_VOCAB // world)
+        torch.save(logits.float().cpu(), os.path.join(out_dir, f"logits_{rank}.pt"))
+        ret[rank] = "ok"
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        ret[rank] = traceback.format_exc()
+
+
+@pytest.mark.parametrize("cfg", ["cogview-small-336M", "cogview-base-4B"])
+def test_model_parallel_2_logits_at_full_depth(cfg, tmp_path):
+    """BASELINE configs[2] (the 4B model split column / row-wise over two adjacent ranks, vocabulary 58368 = 2 x 29184) at
+    FULL depth: two model-parallel processes share the GPU (gloo carries the CUDA all-reduces of mpu/mappings.py:22-31 and
+    the vocab-parallel embedding), their logit shards concatenated along the vocabulary against the fp32 CPU oracle on the
+    UNSHARDED weights (the same seed: every rank draws the full master weights and keeps its shard, mpu/layers.py:42-74).
+    fp16, bar 1e-3."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_mp2_worker, args=(r, 2, port, cfg, str(tmp_path), ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        # meanwhile: the unsharded reference weights (rounded to fp16 as the shards are) and the oracle forward
+        from cogview_amd.model import GPT2Model
+        L, h, heads = CFG[cfg]
+        torch.manual_seed(1234)
+        full = GPT2Model(L, MP_VOCAB, h, heads, 0.1, 0.1, 0.1, S + 1, 0, False)
+        _perturb_replicated(full)
+        params = {n: p.detach().to(torch.float16).float() for n, p in full.state_dict().items()}
+        del full
+        ref, _, secs = D.oracle_streams(_ids(), params, L, heads, keep=())
+        for p in procs:
+            p.join(900)
+        for r in range(2):
+            assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"
+    got = torch.cat([torch.load(os.path.join(str(tmp_path), f"logits_{r}.pt")) for r in range(2)], dim=-1)
+    e = D.rel_l2(got, ref)
+    print(f"\n[{cfg} fp16, model parallel 2] logits rel-L2 vs the oracle on the unsharded weights {e:.3e} (oracle {secs:.0f}s)")
+    assert e < LOGIT_TOL[torch.float16], e
