@@ -851,6 +851,95 @@ __device__ __forceinline__ void pp64_epilogue(const GemmArgs& pg, f32x4 (&acc)[8
   }
 }
 
+// ---- the same epilogue WITHOUT the LDS transposition (round 3, generation-4 kernel): the MFMA layout leaves a lane with 4
+//      consecutive columns of one row per 16x16 block (lane = row l & 15, columns 4 (l >> 4) .. +3).  v_permlane16_swap
+//      exchanges registers between the lane rows l >> 4 = (0, 1) and (2, 3): one swap per accumulator register of a pair of
+//      neighbouring blocks (j, j + 1) hands every lane 8 consecutive columns of its row --
+//          lane row kb = 0: block j, columns 0..7      kb = 1: block j + 1, columns 0..7
+//                   kb = 2: block j, columns 8..15     kb = 3: block j + 1, columns 8..15
+//      -- i.e. 16 rows x 64 contiguous bytes per store instruction.  Measured (tools/probes/store_pattern.hip, round 3):
+//      that pattern streams at the rate of the 8 rows x 128 B of the strip form (5.2-5.4 TB/s both), and the 32 dependent LDS
+//      round trips per tile (write 8 rows, read them back transposed, wait) disappear; nothing else changes: the fused
+//      element-wise chain is the same epilogue8 on 8 consecutive columns.
+template <typename T, int F>
+__device__ __forceinline__ void w4_epilogue_swap(const GemmArgs& pg, f32x4 (&acc)[8][4], int m_base, int n_base, int ksplit,
+                                                 int lane, uint32_t& amax_pk, int colsum_row) {
+  const int l15 = lane & 15, kb = lane >> 4;
+  GemmArgs p = pg;
+  pin_s(p.C); pin_s(p.M); pin_s(p.N); pin_s(p.ldc);
+  if (F < 0 || (F & (COGV_EPI_GELU | COGV_EPI_DGELU | COGV_EPI_MULAUX))) { pin_s(p.aux); pin_s(p.ldaux); }
+  if (F < 0 || (F & COGV_EPI_DROPOUT)) { pin_s(p.seed); pin_s(p.stream_id); pin_s(p.thr16); pin_s(p.keep_scale); }
+  if (F < 0) { pin_s(p.flags); pin_s(p.out_f32); pin_s(p.bias); }
+  if (F == -2) pin_s(p.ws);
+  const bool want_cs = (F == -1) ? ((p.flags & COGV_EPI_COLSUM) != 0 && !p.out_f32) : (F >= 0 && (F & COGV_EPI_COLSUM));
+  float cs[2][8];
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[jp][e] = 0.f;
+  const int ncol = n_base + 16 * (kb & 1) + 8 * (kb >> 1);        // the lane's 8 columns inside block pair jp: ncol + 32 jp
+  constexpr bool PRE_BIAS = F >= 0 && (F & COGV_EPI_BIAS), PRE_AUX = F >= 0 && (F & (COGV_EPI_DGELU | COGV_EPI_MULAUX)), PRE_C = F >= 0 && (F & COGV_EPI_ACCUM);
+  u32x4 bias_v[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, aux_v[PRE_AUX ? 16 : 1], c_v[PRE_C ? 16 : 1];
+  if (PRE_BIAS) {
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+      if (ncol + 32 * jp < p.N) bias_v[jp] = gload16(reinterpret_cast<const T*>(pg.bias) + ncol + 32 * jp);
+  }
+  if (PRE_AUX || PRE_C) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m_base + 16 * (q >> 1) + l15, n = ncol + 32 * (q & 1);
+      const bool ok = m < p.M && n < p.N;
+      if (PRE_AUX) aux_v[q] = ok ? gload16(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n) : u32x4{0u, 0u, 0u, 0u};
+      if (PRE_C) c_v[q] = ok ? gload16(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int t2 = q >> 1, jp = q & 1;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[t2][2 * jp][i]), __float_as_uint(acc[t2][2 * jp + 1][i]), false, false);
+      v[i] = __uint_as_float(r[0]); v[4 + i] = __uint_as_float(r[1]);
+    }
+    const int m = m_base + 16 * t2 + l15, n = ncol + 32 * jp;
+    if (m < p.M && n < p.N) {
+      if (F == -2) {                                          // split-K partial: raw fp32 slab
+        float* w = p.ws + ((size_t)ksplit * p.M + m) * p.N + n;
+        gstore16(w, f32x4{v[0], v[1], v[2], v[3]});
+        gstore16(w + 4, f32x4{v[4], v[5], v[6], v[7]});
+      } else {
+        float rv[8];
+        amax_pk = absmax_pk(amax_pk, epilogue8<T, (F < 0 ? -1 : F)>(p, m, n, v, PRE_BIAS ? &bias_v[jp] : nullptr,
+                                                                     PRE_AUX ? &aux_v[q] : nullptr,
+                                                                     PRE_C ? &c_v[q] : nullptr, want_cs ? rv : nullptr));
+        if (want_cs) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[jp][e] += rv[e];
+        }
+      }
+    }
+  }
+  if (want_cs) {     // the 16 lanes of a lane row hold the same columns: fold them, lane l15 = 0 of each row writes
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = cs[jp][e];
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+        cs[jp][e] = t;
+      }
+      const int n = ncol + 32 * jp;
+      if (l15 == 0 && n < p.N) {
+        float* w = pg.colsum_ws + (size_t)colsum_row * p.N + n;
+        gstore16(w, f32x4{cs[jp][0], cs[jp][1], cs[jp][2], cs[jp][3]});
+        gstore16(w + 4, f32x4{cs[jp][4], cs[jp][5], cs[jp][6], cs[jp][7]});
+      }
+    }
+  }
+}
+
 // =====================================================================================================
 // Generation-3 kernel: 256x256 tile, 64-deep k-tiles, 8 waves (2 x 4, 128x64 each), ping-pong schedule,
 // v_mfma_f32_16x16x32, persistent over (tile, k-split) items of up to four problems.
@@ -1507,11 +1596,20 @@ void gemm_w4_kernel(const GroupArgs ga) {
     float* strip = reinterpret_cast<float*>(smem + 2 * BREG + wave * 2048);
     constexpr int F_FWD_DROP = COGV_EPI_BIAS | COGV_EPI_DROPOUT | COGV_EPI_ABSMAX, F_FWD_GELU = COGV_EPI_BIAS | COGV_EPI_GELU;
     const int mb = done.m0 + wr * 128, nb = done.n0 + wc * 128, csr = (done.m0 >> 7) + wr;
+#if defined(COGV_W4_STRIP_EPI)          // rounds 1-2: transposition through the wave's LDS strip
 #define W4_EPI(F_)                                                                                   \
   do {                                                                                               \
     pp64_epilogue<T, F_>(p, acc[0], strip, mb, nb, done.ksplit, lane, amax_pk, csr);                 \
     pp64_epilogue<T, F_>(p, acc[1], strip, mb, nb + 64, done.ksplit, lane, amax_pk, csr);            \
   } while (0)
+#else                                   // round 3: register exchange (v_permlane16_swap), no LDS
+#define W4_EPI(F_)                                                                                   \
+  do {                                                                                               \
+    (void)strip;                                                                                     \
+    w4_epilogue_swap<T, F_>(p, acc[0], mb, nb, done.ksplit, lane, amax_pk, csr);                     \
+    w4_epilogue_swap<T, F_>(p, acc[1], mb, nb + 64, done.ksplit, lane, amax_pk, csr);                \
+  } while (0)
+#endif
     if (p.splitk > 1) W4_EPI(-2);
     else if (p.out_f32) W4_EPI(-1);
     else if (p.flags == 0) W4_EPI(0);
