@@ -929,8 +929,14 @@ __device__ __forceinline__ void w4_epilogue_swap(const GemmArgs& pg, f32x4 (&acc
     for (int jp = 0; jp < 2; ++jp) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
+        // sum over the 16 lanes of the lane row through DPP only (quad butterflies, half-row and row mirrors: four
+        // v_add_f32_dpp; __shfl_xor would be a ds_bpermute round trip each -- 64 of them per sub-tile measured -3.6 % on
+        // the dgrad launch that carries the bias-gradient column sums)
         float t = cs[jp][e];
-        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false));
+        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, false));
+        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xf, 0xf, false));
+        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x140, 0xf, 0xf, false));
         cs[jp][e] = t;
       }
       const int n = ncol + 32 * jp;
@@ -1599,13 +1605,17 @@ void gemm_w4_kernel(const GroupArgs ga) {
     float* strip = reinterpret_cast<float*>(smem + 2 * BREG + wave * 2048);
     constexpr int F_FWD_DROP = COGV_EPI_BIAS | COGV_EPI_DROPOUT | COGV_EPI_ABSMAX, F_FWD_GELU = COGV_EPI_BIAS | COGV_EPI_GELU;
     const int mb = done.m0 + wr * 128, nb = done.n0 + wc * 128, csr = (done.m0 >> 7) + wr;
-#if defined(COGV_W4_STRIP_EPI)          // rounds 1-2: transposition through the wave's LDS strip
+#if !defined(COGV_W4_SWAP_EPI)          // default: transposition through the wave's LDS strip
 #define W4_EPI(F_)                                                                                   \
   do {                                                                                               \
     pp64_epilogue<T, F_>(p, acc[0], strip, mb, nb, done.ksplit, lane, amax_pk, csr);                 \
     pp64_epilogue<T, F_>(p, acc[1], strip, mb, nb + 64, done.ksplit, lane, amax_pk, csr);            \
   } while (0)
-#else                                   // round 3: register exchange (v_permlane16_swap), no LDS
+#else                                   // -DCOGV_W4_SWAP_EPI: register exchange (v_permlane16_swap), no LDS.  Measured in round 3
+                                        // (profiles/r03_gemm_swap_epilogue_ab.log): equal on plain / bias epilogues, +1.5 % on
+                                        // GeLU + stored gelu', -2.3 % on the column-sum instance (16 per-lane column accumulators
+                                        // instead of 8), all 256 VGPRs in use; instantiating BOTH forms in one kernel made the
+                                        // register allocator spill 816 bytes and cost 30-40 % -- hence a build switch, off.
 #define W4_EPI(F_)                                                                                   \
   do {                                                                                               \
     (void)strip;                                                                                     \
