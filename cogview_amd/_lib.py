@@ -73,7 +73,7 @@ class AttnDecodeDesc(C.Structure):
         ("cache", C.c_void_p), ("cache_bs", C.c_longlong), ("cache_rs", C.c_int),
         ("out", C.c_void_p), ("out_bs", C.c_longlong),
         ("pos", C.c_void_p),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("skip_combine", C.c_int),
     ]
 
 
@@ -124,6 +124,7 @@ SIGNATURES = {
     "cogv_attention_fwd": (_i, [C.POINTER(AttnDesc), _vp]),
     "cogv_attention_bwd": (_i, [C.POINTER(AttnDesc), _vp]),
     "cogv_gemv_ln": (_i, [C.POINTER(GemmDesc), C.POINTER(LnPrologue), _vp]),
+    "cogv_gemv_attn": (_i, [C.POINTER(GemmDesc), _vp, _i, _i, _vp]),
     "cogv_attention_decode": (_i, [C.POINTER(AttnDecodeDesc), _vp]),
     "cogv_attention_decode_workspace_bytes": (_sz, [_i, _i, _i]),
     "cogv_sparse_slot_reduce": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -1172,7 +1172,7 @@ extern "C" size_t cogv_attention_decode_workspace_bytes(int B, int H, int capaci
 extern "C" int cogv_attention_decode(const cogv_attn_decode_desc* d, void* stream) {
   if (!d || (d->dtype != COGV_F16 && d->dtype != COGV_BF16)) return COGV_ERR_UNSUPPORTED;
   if (d->B <= 0 || d->H <= 0 || d->capacity <= 0 || d->capacity > 4096 || d->head_dim != HD) return COGV_ERR_ARG;
-  if (!d->qkv || !d->cache || !d->out || !d->pos || !d->workspace) return COGV_ERR_ARG;
+  if (!d->qkv || !d->cache || (!d->out && !d->skip_combine) || !d->pos || !d->workspace) return COGV_ERR_ARG;
   if (!aligned16(d->qkv) || !aligned16(d->cache) || ((d->qkv_bs | d->cache_bs | d->cache_rs) & 7)) return COGV_ERR_ARG;
   if (d->workspace_bytes < cogv_attention_decode_workspace_bytes(d->B, d->H, d->capacity) || ((uintptr_t)d->workspace & 15)) return COGV_ERR_ARG;
   DecodeArgs a;
@@ -1184,12 +1184,13 @@ extern "C" int cogv_attention_decode(const cogv_attn_decode_desc* d, void* strea
   a.scale_l2e = d->scale * 1.4426950408889634f;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(a.nsplit, a.H, a.B);
+  // skip_combine: the consumer (cogv_gemv_attn: the attention-output projection of a decode step) recombines the partials itself
   if (d->dtype == COGV_F16) {
     hipLaunchKernelGGL((attn_decode_kernel<f16_t>), grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL((attn_decode_combine_kernel<f16_t>), dim3(a.H, a.B), dim3(64), 0, st, a);
+    if (!d->skip_combine) hipLaunchKernelGGL((attn_decode_combine_kernel<f16_t>), dim3(a.H, a.B), dim3(64), 0, st, a);
   } else {
     hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL((attn_decode_combine_kernel<bf16_t>), dim3(a.H, a.B), dim3(64), 0, st, a);
+    if (!d->skip_combine) hipLaunchKernelGGL((attn_decode_combine_kernel<bf16_t>), dim3(a.H, a.B), dim3(64), 0, st, a);
   }
   return cogv_check_launch();
 }

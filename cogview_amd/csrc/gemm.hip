@@ -1722,6 +1722,89 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemmArgs p) {
   }
 }
 
+// Decode step, attention-output projection: the skinny-M kernel above with the COMBINE of the decode attention's key
+// splits as its prologue (round 3: one launch per layer less in a captured decode step).  attn_decode_kernel leaves per
+// (row, head, split) a partial (max m, sum l, 64 unnormalised outputs o) -- 66 floats; the attention output element the GEMV
+// needs, att[row][head * 64 + d] = sum_s 2^(m_s - M) o_s[d] / sum_s 2^(m_s - M) l_s, is a few hundred bytes of L2-resident
+// partials per lane, so every workgroup recombines the 8-element slices it multiplies instead of a separate combine launch
+// writing att and this one reading it (attn_decode_combine_kernel; same arithmetic, splits in order, att rounded to the
+// storage type before the product as the two-launch form stores it).  The first weight rows are requested before the
+// prologue, so the HBM latency overlaps it.
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_attn_kernel(const GemmArgs p, const float* __restrict__ part_ws, int H, int nsplit) {
+  __shared__ float part[4][GEMV_MAX_M][8];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x * 8;
+  const T* B = reinterpret_cast<const T*>(p.B) + (size_t)n0 * p.ldb;
+  float acc[GEMV_MAX_M][8];
+#pragma unroll
+  for (int m = 0; m < GEMV_MAX_M; ++m)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[m][j] = 0.f;
+  const int nchunk = p.K >> 9;
+  for (int c = wave; c < nchunk; c += 4) {
+    const int k = (c << 9) + lane * 8;
+    u32x4 w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const u32x4*>(B + (size_t)j * p.ldb + k);
+    const int head = k >> 6, dd = k & 63;
+#pragma unroll
+    for (int m = 0; m < GEMV_MAX_M; ++m) {
+      if (m < p.M) {
+        const float* base = part_ws + ((size_t)m * H + head) * nsplit * 66;
+        float mx = -INFINITY;
+        for (int sp = 0; sp < nsplit; ++sp) mx = fmaxf(mx, base[sp * 66]);
+        float L = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < nsplit; ++sp) {
+          const float mi = base[sp * 66];
+          const float wgt = (mi == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mi - mx);
+          L = fmaf(base[sp * 66 + 1], wgt, L);
+          const float* po = base + sp * 66 + 2 + dd;          // 8-byte aligned (66 floats per partial)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = fmaf(po[e], wgt, o[e]);
+        }
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = o[e] / L;
+        const u32x4 xr = pack8<T>(x);                         // the attention output in its storage type
+        unpack8<T>(xr, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float wf[8];
+          unpack8<T>(w[j], wf);
+          float t = acc[m][j];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t = fmaf(x[e], wf[e], t);
+          acc[m][j] = t;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < GEMV_MAX_M; ++m)
+    if (m < p.M) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = wave_sum_uniform(acc[m][j]);
+        if (lane == 0) part[wave][m][j] = t;
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t amax_pk = 0u;
+    for (int m = 0; m < p.M; ++m) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[0][m][j] + part[1][m][j] + part[2][m][j] + part[3][m][j];
+      amax_pk = absmax_pk(amax_pk, epilogue8<T>(p, m, n0, v));
+    }
+    if (p.flags & COGV_EPI_ABSMAX) {
+      const uint32_t wv = max(amax_pk & 0xffffu, amax_pk >> 16);
+      atomic_max_nonneg(p.absmax, bits_to_f<T>((uint16_t)wv));
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Matrix-vector kernel with the layer's LayerNorms as its PROLOGUE (decode steps, M <= 8 rows, K = hidden size <= 4096).
 // A decode step of one token spends more time in its four per-layer Sandwich-LN launches (7 us each: launch latency plus a
@@ -2307,6 +2390,25 @@ extern "C" int cogv_gemv_ln(const cogv_gemm_desc* d, const cogv_ln_prologue* ln,
   if (d->dtype == COGV_F16) { if (mt == 1) GEMV_LN_LAUNCH(f16_t, 1); else if (mt == 2) GEMV_LN_LAUNCH(f16_t, 2); else if (mt == 4) GEMV_LN_LAUNCH(f16_t, 4); else GEMV_LN_LAUNCH(f16_t, 8); }
   else { if (mt == 1) GEMV_LN_LAUNCH(bf16_t, 1); else if (mt == 2) GEMV_LN_LAUNCH(bf16_t, 2); else if (mt == 4) GEMV_LN_LAUNCH(bf16_t, 4); else GEMV_LN_LAUNCH(bf16_t, 8); }
 #undef GEMV_LN_LAUNCH
+  return cogv_check_launch();
+}
+
+// y = epilogue(att . B^T), att = the combination of cogv_attention_decode's split partials (skip_combine form): gemv_attn_kernel.
+extern "C" int cogv_gemv_attn(const cogv_gemm_desc* d, const void* partials, int heads, int capacity, void* stream) {
+  if (!d || !partials || heads <= 0 || capacity <= 0 || capacity > 4096 || ((uintptr_t)partials & 15)) return COGV_ERR_ARG;
+  cogv_gemm_desc dd = *d;
+  dd.A = dd.B;                    // the A operand does not exist: keep build_gemm_args' pointer checks happy
+  dd.lda = dd.K;
+  GemmArgs a;
+  const int rc = build_gemm_args(&dd, a);
+  if (rc != COGV_OK) return rc;
+  if (d->trans_a || d->trans_b || a.M > GEMV_MAX_M || a.K != heads * 64 || (a.K & 511) || (a.N & 7) || (a.ldb & 7)) return COGV_ERR_UNSUPPORTED;
+  if (d->flags & (COGV_EPI_COLSUM | COGV_EPI_ACCUM | COGV_EPI_DGELU | COGV_EPI_MULAUX | COGV_EPI_DROPOUT | COGV_EPI_GELU) || d->out_f32 || d->splitk > 1) return COGV_ERR_UNSUPPORTED;
+  a.splitk = 1;
+  const int nsplit = (capacity + 127) / 128;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == COGV_F16) hipLaunchKernelGGL((gemv_attn_kernel<f16_t>), dim3(a.N / 8), dim3(256), 0, st, a, reinterpret_cast<const float*>(partials), heads, nsplit);
+  else hipLaunchKernelGGL((gemv_attn_kernel<bf16_t>), dim3(a.N / 8), dim3(256), 0, st, a, reinterpret_cast<const float*>(partials), heads, nsplit);
   return cogv_check_launch();
 }
 

@@ -696,6 +696,19 @@ class _TransformerLayer(torch.autograd.Function):
         return dx, None, None, None, None, None, None
 
 
+# decode_chain: combine the decode attention's key splits in the prologue of the attention-output GEMV (one launch per layer
+# less).  Measured at 4B, 1024-position memory (tools/mb_decode.py, same call): EAGER step 4.16 -> 3.73 ms, CAPTURED graph
+# 3.40 -> 3.62 ms (inside a graph a launch costs less than 320 workgroups recombining the partials) -- so the default is
+# "fused unless the stream is being captured"; COGV_DECODE_FUSE_COMBINE=0 / 1 forces either form.
+_DECODE_FUSE_ENV = _os.environ.get("COGV_DECODE_FUSE_COMBINE")
+
+
+def _decode_fuse_combine():
+    if _DECODE_FUSE_ENV is not None:
+        return _DECODE_FUSE_ENV != "0"
+    return not torch.cuda.is_current_stream_capturing()
+
+
 def decode_chain_supported(tr, batch):
     """The fused decode chain (decode_chain) covers the dense, single-partition model in a 16-bit type at one token per
     row: what a captured decode step runs."""
@@ -705,8 +718,9 @@ def decode_chain_supported(tr, batch):
 
 
 def decode_chain(tr, h0, absmax0, slots, emb_weight):
-    """One decode step through all layers with FIVE launches per layer (+1 combine): QKV GEMV with [previous layer's
-    LN4 + residual, LN1] as prologue | decode attention (cache append fused) | dense GEMV | h->4h GEMV with [LN3 +
+    """One decode step through all layers with FIVE launches per layer (round 3: the split-combine of the decode attention
+    rides in the dense GEMV's prologue): QKV GEMV with [previous layer's
+    LN4 + residual, LN1] as prologue | decode attention, key splits (cache append fused) | dense GEMV with the combine as prologue | h->4h GEMV with [LN3 +
     residual, LN2] as prologue and GeLU epilogue | 4h->h GEMV; the last LN4 + residual and the final LayerNorm are the
     prologue of the tied-logits GEMV.  Same arithmetic and rounding points as the layer-by-layer path
     (mpu/sparse_transformer.py:314-342, 612; model/gpt2_modeling.py:115-118).  h0 [b, 1, h]; slots: StaticKVSlot per
@@ -724,10 +738,15 @@ def decode_chain(tr, h0, absmax0, slots, emb_weight):
                              layer.input_layernorm.bias, eps, z_absmax, post, res, want_t=post is not None)
         if x is None:
             x = z
-        att = ops.attention_decode(qkv.view(b, 1, 3 * hp), slot.cache, slot.pos_index, npp)
-        slot.out = slot.cache
         slot_ao = ops.new_absmax_slot(dev)
-        ao = ops.gemm(att.view(b, hp), att_m.dense.weight, bias=att_m.dense.bias, absmax=slot_ao)
+        if hp % 512 == 0 and _decode_fuse_combine():
+            # the key splits' partials are combined in the prologue of the attention-output GEMV (one launch less)
+            parts = ops.attention_decode(qkv.view(b, 1, 3 * hp), slot.cache, slot.pos_index, npp, combine=False)
+            ao = ops.gemv_attn(parts, b, npp, slot.cache.shape[1], att_m.dense.weight, bias=att_m.dense.bias, absmax=slot_ao)
+        else:
+            att = ops.attention_decode(qkv.view(b, 1, 3 * hp), slot.cache, slot.pos_index, npp)
+            ao = ops.gemm(att.view(b, hp), att_m.dense.weight, bias=att_m.dense.bias, absmax=slot_ao)
+        slot.out = slot.cache
         g, y = ops.gemv_ln(ao, mlp_m.dense_h_to_4h.weight, mlp_m.dense_h_to_4h.bias, layer.post_attention_layernorm.weight,
                            layer.post_attention_layernorm.bias, eps, slot_ao,
                            (layer.third_layernorm.weight, layer.third_layernorm.bias), x, want_t=True, gelu=True)

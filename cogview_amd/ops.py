@@ -482,8 +482,10 @@ def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None):
 _DECODE_WS = {}
 
 
-def attention_decode(qkv, cache, pos_index, heads):
-    """One decode step's attention (cogv_attention_decode): qkv [b, 1, 3 * heads * 64] (q | k | v of the new token),
+def attention_decode(qkv, cache, pos_index, heads, combine=True):
+    """combine=False: only the key-split kernel runs; returns the partials workspace for gemv_attn (the attention-output
+    projection recombines the splits in its prologue: one launch less).
+    One decode step's attention (cogv_attention_decode): qkv [b, 1, 3 * heads * 64] (q | k | v of the new token),
     cache [b, capacity, 2 * heads * 64] (keys | values), pos_index: device int64 scalar = slot of the new token (slots
     [0, pos] are attended; the new key / value are written into slot pos by the kernel).  Returns out [b, 1, heads * 64].
     The workspace (partial results of the key splits) is kept per (device, shape): fixed addresses, so the call is
@@ -498,15 +500,42 @@ def attention_decode(qkv, cache, pos_index, heads):
     ws = _DECODE_WS.get(key)
     if ws is None:
         ws = _DECODE_WS[key] = torch.zeros(lib.cogv_attention_decode_workspace_bytes(b, heads, cap), dtype=torch.uint8, device=qkv.device)
-    out = torch.empty((b, 1, hp), dtype=qkv.dtype, device=qkv.device)
+    out = torch.empty((b, 1, hp), dtype=qkv.dtype, device=qkv.device) if combine else None
     d = L.AttnDecodeDesc()
     d.dtype, d.B, d.H, d.capacity, d.head_dim, d.scale = dt_code(qkv), b, heads, cap, 64, 0.125
     d.qkv, d.qkv_bs = qkv.data_ptr(), qkv.stride(0)
     d.cache, d.cache_bs, d.cache_rs = cache.data_ptr(), cache.stride(0), cache.stride(1)
-    d.out, d.out_bs = out.data_ptr(), out.stride(0)
+    d.out, d.out_bs = (out.data_ptr(), out.stride(0)) if combine else (None, hp)
     d.pos = pos_index.data_ptr()
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    d.skip_combine = 0 if combine else 1
     L.check(lib.cogv_attention_decode(C.byref(d), _stream()), "cogv_attention_decode")
+    return out if combine else ws
+
+
+def gemv_attn(partials, batch, heads, capacity, w, bias=None, absmax=None):
+    """Attention-output projection of a decode step with the split-combine as its prologue (cogv_gemv_attn):
+    out [batch, N] = (combined attention output [batch, heads * 64]) . w^T + bias.  `partials`: what
+    attention_decode(..., combine=False) returned for the same (batch, heads, capacity)."""
+    _need_gpu(partials, w)
+    N, K = w.shape
+    assert K == heads * 64 and w.stride(1) == 1 and batch <= 8
+    out = torch.empty((batch, N), dtype=w.dtype, device=w.device)
+    d = L.GemmDesc()
+    d.dtype = dt_code(w)
+    d.M, d.N, d.K = batch, N, K
+    d.A, d.lda = None, K
+    d.B, d.ldb = w.data_ptr(), w.stride(0)
+    d.C, d.ldc = out.data_ptr(), N
+    flags = 0
+    if bias is not None:
+        flags |= L.EPI_BIAS
+        d.bias = bias.data_ptr()
+    if absmax is not None:
+        flags |= L.EPI_ABSMAX
+        d.absmax = absmax.data_ptr()
+    d.flags, d.splitk = flags, 1
+    L.check(L.lib().cogv_gemv_attn(C.byref(d), _p(partials), int(heads), int(capacity), _stream()), "cogv_gemv_attn")
     return out
 
 

@@ -116,6 +116,11 @@ typedef struct cogv_ln_prologue {
                           cogv_sandwich_ln_fwd); t is then formed and normalised without intermediate roundings */
 } cogv_ln_prologue;
 int cogv_gemv_ln(const cogv_gemm_desc* d, const cogv_ln_prologue* ln, void* stream);
+/* Decode step, attention-output projection (mpu/sparse_transformer.py:163-166 after the attention of :652-673): the M <= 8
+ * row matrix-vector product C = epilogue(att . B^T) whose input att [M][heads * 64] is COMBINED inside the kernel from the
+ * split partials cogv_attention_decode left in its workspace (skip_combine = 1; `capacity` as in that call) -- one launch
+ * per layer less than combine + GEMV.  d->A is ignored; K = heads * 64, K % 512 == 0; flags BIAS | ABSMAX only. */
+int cogv_gemv_attn(const cogv_gemm_desc* d, const void* partials, int heads, int capacity, void* stream);
 
 /* ------------------------------------------------------------------ Sandwich-LN
  * y = [residual +] LayerNorm_{eps*(amax/8)^2}(x) * gamma + beta ; amax = *absmax_in (NULL: plain LN).
@@ -197,6 +202,8 @@ typedef struct cogv_attn_decode_desc {
   void* out; long long out_bs;
   const long long* pos;
   void* workspace; size_t workspace_bytes;
+  int skip_combine;                  /* 1: leave the split partials in `workspace` (66 floats per (row, head, split): max,
+                                        sum, 64 outputs) for cogv_gemv_attn to combine; `out` is not written and may be NULL */
 } cogv_attn_decode_desc;
 size_t cogv_attention_decode_workspace_bytes(int B, int H, int capacity);
 int cogv_attention_decode(const cogv_attn_decode_desc* d, void* stream);

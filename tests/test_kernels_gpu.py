@@ -664,6 +664,40 @@ def test_attention_decode_step(ops, dtype, b, H, cap, pos):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,H,cap,pos,N", [(1, 8, 256, 100, 512), (4, 40, 1152, 1024, 2560), (8, 16, 384, 383, 1024), (2, 8, 128, 0, 64)])
+def test_attention_output_projection_with_combine_prologue(ops, dtype, b, H, cap, pos, N):
+    """cogv_gemv_attn: the attention-output projection of a decode step whose input is COMBINED from the decode attention's
+    key-split partials inside the kernel (round 3: one launch per layer less) == the two-launch form of the same library
+    (cogv_attention_decode with its combine kernel, then the skinny-M GEMV) and the oracle's definition
+    (mpu/sparse_transformer.py:652-673, :163-166): dense(standard_attention(q, K[0..pos], V[0..pos])) with bias; abs-max slot."""
+    g = torch.Generator().manual_seed(cap + pos + N)
+    hp = H * 64
+    cache, qkv = rnd((b, cap, 2 * hp), dtype, g), rnd((b, 1, 3 * hp), dtype, g)
+    w, bias = rnd((N, hp), dtype, g, 0.05), rnd((N,), dtype, g)
+    pos_d = torch.tensor([pos], dtype=torch.int64, device="cuda")
+    c1, c2 = dev(cache.clone()), dev(cache.clone())
+    att = ops.attention_decode(dev(qkv), c1, pos_d, H)
+    slot_ref = ops.new_absmax_slot(att.device)
+    ref2 = ops.gemm(att.view(b, hp), dev(w), bias=dev(bias), absmax=slot_ref)
+    parts = ops.attention_decode(dev(qkv), c2, pos_d, H, combine=False)
+    assert torch.equal(c1, c2)                                   # the cache append does not depend on the form
+    slot = ops.new_absmax_slot(att.device)
+    out = ops.gemv_attn(parts, b, H, cap, dev(w), bias=dev(bias), absmax=slot)
+    assert out.shape == (b, N) and rel(out, ref2.float().cpu()) < (1e-3 if dtype == torch.float16 else 8e-3)
+    assert abs(slot.item() - slot_ref.item()) <= 2e-2 * max(1.0, slot_ref.item())
+    want_cache = cache.clone()
+    want_cache[:, pos, :hp] = qkv[:, 0, hp:2 * hp]
+    want_cache[:, pos, hp:] = qkv[:, 0, 2 * hp:]
+    q = qkv[:, :, :hp].float().view(b, 1, H, 64).permute(0, 2, 1, 3)
+    k = want_cache[:, :pos + 1, :hp].float().view(b, pos + 1, H, 64).permute(0, 2, 1, 3)
+    v = want_cache[:, :pos + 1, hp:].float().view(b, pos + 1, H, 64).permute(0, 2, 1, 3)
+    a_ref = O.standard_attention(q, k, v, torch.ones(1, 1, 1, pos + 1)).permute(0, 2, 1, 3).reshape(b, hp)
+    ref = O.linear(a_ref.to(dtype).float(), w.float(), bias.float())
+    assert rel(out, ref) < TOL[dtype]
+    assert torch.equal(out, ops.gemv_attn(parts, b, H, cap, dev(w), bias=dev(bias)))      # replayable: no hidden state
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,K,N,post,gelu", [(1, 512, 768, False, False), (3, 1024, 512, True, True), (8, 2560, 1024, True, False),
                                               (2, 4096, 256, True, True), (5, 512, 64, False, True)])
 def test_gemv_with_layernorm_prologue(ops, dtype, M, K, N, post, gelu):
