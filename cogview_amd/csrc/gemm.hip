@@ -1754,15 +1754,28 @@ __global__ __launch_bounds__(256) void gemv_attn_kernel(const GemmArgs p, const 
         const float* base = part_ws + ((size_t)m * H + head) * nsplit * 66;
         float mx = -INFINITY;
         for (int sp = 0; sp < nsplit; ++sp) mx = fmaxf(mx, base[sp * 66]);
-        float L = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < nsplit; ++sp) {
-          const float mi = base[sp * 66];
-          const float wgt = (mi == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mi - mx);
-          L = fmaf(base[sp * 66 + 1], wgt, L);
-          const float* po = base + sp * 66 + 2 + dd;          // 8-byte aligned (66 floats per partial)
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float tl[32];                                         // l_s 2^(m_s - M) per split (nsplit <= 32), zero beyond
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = fmaf(po[e], wgt, o[e]);
+        for (int i = 0; i < 32; ++i) tl[i] = 0.f;
+#pragma unroll
+        for (int sp = 0; sp < 32; ++sp) {
+          if (sp < nsplit) {
+            const float mi = base[sp * 66];
+            const float wgt = (mi == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mi - mx);
+            tl[sp] = base[sp * 66 + 1] * wgt;
+            const float* po = base + sp * 66 + 2 + dd;        // 8-byte aligned (66 floats per partial)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(po[e], wgt, o[e]);
+          }
         }
+        // the sum in the association of attn_decode_combine_kernel's xor-butterfly (lanes >= nsplit hold zeros there too),
+        // so that both forms of the step produce the same bits
+#pragma unroll
+        for (int w2 = 16; w2 > 0; w2 >>= 1)
+#pragma unroll
+          for (int i = 0; i < w2; ++i) tl[i] += tl[i + w2];
+        const float L = tl[0];
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = o[e] / L;

@@ -683,8 +683,10 @@ def test_attention_output_projection_with_combine_prologue(ops, dtype, b, H, cap
     assert torch.equal(c1, c2)                                   # the cache append does not depend on the form
     slot = ops.new_absmax_slot(att.device)
     out = ops.gemv_attn(parts, b, H, cap, dev(w), bias=dev(bias), absmax=slot)
-    assert out.shape == (b, N) and rel(out, ref2.float().cpu()) < (1e-3 if dtype == torch.float16 else 8e-3)
-    assert abs(slot.item() - slot_ref.item()) <= 2e-2 * max(1.0, slot_ref.item())
+    # same arithmetic in the same association as the combine kernel + the skinny-M GEMV: the two forms agree bit for bit
+    # (a captured decode graph uses the two-launch form, the eager step this one)
+    assert out.shape == (b, N) and torch.equal(out, ref2)
+    assert slot.item() == slot_ref.item()
     want_cache = cache.clone()
     want_cache[:, pos, :hp] = qkv[:, 0, hp:2 * hp]
     want_cache[:, pos, hp:] = qkv[:, 0, 2 * hp:]
