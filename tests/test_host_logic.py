@@ -420,3 +420,57 @@ def test_clip_grad_norm_general_p_norm_matches_torch():
         assert abs(got - float(want)) < 1e-5 * float(want)
         for r, p in zip(ref, ps):
             assert torch.allclose(r.grad, p.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_train_loop_counts_logs_saves_and_exits_on_a_skipped_iteration(monkeypatch):
+    """pretrain_gpt2.py:483-566 -- an iteration whose forward pass produced nan / inf skips backward and the optimizer
+    step (train_step returns early, :414-416) but is still an iteration of the train loop: counted, logged, checkpointed
+    when it lands on save_interval, and it honours exit_interval (round-2 advisor finding: a `continue` had bypassed all of
+    that).  The kernels are stubbed out: this is the loop's bookkeeping only."""
+    import types
+    from cogview_amd import pretrain_gpt2 as P
+    calls = {"fwd": 0, "bwd": 0, "step": 0, "sched": 0, "saved": [], "printed": []}
+    bad_iters = {1, 3}                                   # 0-based iterations whose forward pass is not finite
+
+    def fake_get_batch(it, args):
+        return None
+
+    def fake_forward_step(batch, model, txt_loss_scale, is_sparse, log=True, world_size=1):
+        i = calls["fwd"]
+        calls["fwd"] += 1
+        bad = i in bad_iters
+        part = torch.tensor(float("nan") if bad else 1.0)
+        return torch.tensor(2.0), [], part, part
+
+    def fake_backward_step(optimizer, model, lm_loss, clip, half, world_size=1, reduce_loss=False):
+        calls["bwd"] += 1
+        return lm_loss.detach().view(1)
+    monkeypatch.setattr(P, "get_batch", fake_get_batch)
+    monkeypatch.setattr(P.training, "forward_step", fake_forward_step)
+    monkeypatch.setattr(P.training, "backward_step", fake_backward_step)
+    monkeypatch.setattr(P.utils, "save_checkpoint", lambda it, *a, **k: calls["saved"].append(it))
+    monkeypatch.setattr(P.utils, "print_rank_0", lambda s: calls["printed"].append(s))
+    monkeypatch.setattr(P.mpu, "get_data_parallel_world_size", lambda: 1)
+    monkeypatch.setattr(torch.distributed, "barrier", lambda *a, **k: None)
+
+    class Opt:
+        overflow, loss_scale, param_groups = False, 1.0, [{"lr": 1e-4}]
+
+        def step(self):
+            calls["step"] += 1
+
+    class Sched:
+        def step(self):
+            calls["sched"] += 1
+    model = types.SimpleNamespace(train=lambda: None, needs_reduction=True)
+    args = types.SimpleNamespace(iteration=0, train_iters=6, log_interval=2, fp16=True, bf16=False, txt_loss_scale=1.0,
+                                 is_sparse=0, world_size=1, clip_grad=1.0, batch_size=2, max_position_embeddings=1089,
+                                 save="/tmp/x", save_interval=2, exit_interval=4)
+    it, skipped = P.train(model, Opt(), Sched(), None, args)
+    assert (it, skipped) == (4, 2) and args.iteration == 4            # exit_interval honoured although iteration 4 (index 3) was skipped
+    assert calls["fwd"] == 4 and calls["bwd"] == 2 and calls["step"] == 2 and calls["sched"] == 2
+    assert calls["saved"] == [2, 4]                                  # both save points fall on skipped iterations
+    assert model.needs_reduction is False
+    logs = [s for s in calls["printed"] if "elapsed time per iteration" in s]
+    assert len(logs) == 2 and "skipped 1" in logs[0] and "skipped 2" in logs[1]          # logged at iterations 2 and 4
+    assert "exiting the program at iteration 4" in calls["printed"][-1]
