@@ -474,3 +474,32 @@ def test_train_loop_counts_logs_saves_and_exits_on_a_skipped_iteration(monkeypat
     logs = [s for s in calls["printed"] if "elapsed time per iteration" in s]
     assert len(logs) == 2 and "skipped 1" in logs[0] and "skipped 2" in logs[1]          # logged at iterations 2 and 4
     assert "exiting the program at iteration 4" in calls["printed"][-1]
+
+
+def test_save_checkpoint_waits_for_the_sharded_parameter_gather(tmp_path):
+    """With the sharded exchange the optimizer's step all-gathers the updated 16-bit parameters on a side stream and only the
+    NEXT forward waits for them; utils.save_checkpoint unwraps the data-parallel wrapper, so it must order the copy-out
+    behind that gather itself (round-2 advisor finding) -- before the state dict is taken, for every wrapper in the chain."""
+    import types
+    from cogview_amd import utils
+    events = []
+
+    class Shard:
+        def wait_upto(self, end):
+            events.append(("wait", end))
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.module, self.shard, self.arena = inner, Shard(), types.SimpleNamespace(total=4711)
+
+        def state_dict(self, *a, **k):
+            events.append(("state_dict",))
+            return self.module.state_dict(*a, **k)
+    model = Wrapper(torch.nn.Linear(4, 3))
+    args = types.SimpleNamespace(save=str(tmp_path), no_save_optim=True, no_save_rng=True, deepspeed=False)
+    utils.save_checkpoint(5, model, None, None, args)
+    assert events[0] == ("wait", 4711) and ("state_dict",) in events and events.index(("state_dict",)) > 0
+    sd = torch.load(utils.get_checkpoint_name(str(tmp_path), 5), map_location="cpu", weights_only=False)
+    assert sd["iteration"] == 5 and set(sd["module"]) == {"weight", "bias"}
+    assert open(utils.get_checkpoint_tracker_filename(str(tmp_path))).read() == "5"
