@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* logits, const int
 template <typename T>
 __global__ __launch_bounds__(256) void grad_stats_kernel(const T* grads, const int64_t* chunk_start,
                                                         const int32_t* chunk_len, const uint8_t* chunk_norm,
-                                                        int nchunks, double* stats) {
+                                                        int nchunks, double* stats, double* partial) {
   __shared__ float red[16];
   float sq = 0.f; bool bad = false;
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
@@ -104,9 +104,21 @@ __global__ __launch_bounds__(256) void grad_stats_kernel(const T* grads, const i
   const float bs = block_sum(sq, red);
   const bool any_bad = __syncthreads_or(bad);
   if (threadIdx.x == 0) {
-    if (bs != 0.f && bs == bs) atomicAdd(&stats[0], (double)bs);
+    // per-workgroup partial, summed in workgroup order by grad_stats_final_kernel: the global norm (and with it the clip
+    // coefficient of the fused AdamW) is the same bits run after run.  (Rounds 1-2 used atomicAdd on the double: the last
+    // floating-point atomic of the training step.)
+    partial[blockIdx.x] = (bs == bs) ? (double)bs : 0.0;
     if (any_bad || bs != bs) stats[1] = 1.0;
   }
+}
+// stats[0] += sum of the workgroups' partials in a fixed order (one wave: lane i takes partials i, i + 64, ...; DPP-free
+// butterfly over the 64 lane sums in double)
+__global__ __launch_bounds__(64) void grad_stats_final_kernel(const double* partial, int n, double* stats) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) stats[0] += s;
 }
 
 // ---------------------------------------------------------------------------------- fused AdamW step
@@ -243,8 +255,16 @@ extern "C" int cogv_grad_stats(int dtype, const void* grads, const int64_t* chun
   if ((uintptr_t)grads & 15) return COGV_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int g = nchunks < 2048 ? nchunks : 2048;
-  if (dtype == COGV_F16) hipLaunchKernelGGL((grad_stats_kernel<f16_t>), dim3(g), dim3(256), 0, st, (const f16_t*)grads, chunk_start, chunk_len, chunk_norm, nchunks, stats);
-  else hipLaunchKernelGGL((grad_stats_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)grads, chunk_start, chunk_len, chunk_norm, nchunks, stats);
+  // 16 KiB of per-workgroup partial sums, allocated by the library once per device (like the GEMM's work-queue counters):
+  // the statistics pass of one device runs on one stream at a time (the optimizer's), so the buffer is not contended
+  static double* partial_ws[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return COGV_ERR_LAUNCH;
+  if (!partial_ws[dev] && hipMalloc(reinterpret_cast<void**>(&partial_ws[dev]), 2048 * sizeof(double)) != hipSuccess) return COGV_ERR_LAUNCH;
+  double* partial = partial_ws[dev];
+  if (dtype == COGV_F16) hipLaunchKernelGGL((grad_stats_kernel<f16_t>), dim3(g), dim3(256), 0, st, (const f16_t*)grads, chunk_start, chunk_len, chunk_norm, nchunks, stats, partial);
+  else hipLaunchKernelGGL((grad_stats_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)grads, chunk_start, chunk_len, chunk_norm, nchunks, stats, partial);
+  hipLaunchKernelGGL(grad_stats_final_kernel, dim3(1), dim3(64), 0, st, partial, g, stats);
   return cogv_check_launch();
 }
 

@@ -5,20 +5,6 @@
 
 namespace {
 
-typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-typedef short s2_t __attribute__((ext_vector_type(2)));
-
-template <typename T> __device__ __forceinline__ void atomic_add_pk(T* addr, float lo, float hi);
-template <> __device__ __forceinline__ void atomic_add_pk<f16_t>(f16_t* addr, float lo, float hi) {
-  h2_t v; v[0] = (f16_t)lo; v[1] = (f16_t)hi;
-  __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2_t*)addr, v);
-}
-template <> __device__ __forceinline__ void atomic_add_pk<bf16_t>(bf16_t* addr, float lo, float hi) {
-  const uint32_t w = pack2<bf16_t>(lo, hi);
-  s2_t v; __builtin_memcpy(&v, &w, 4);
-  __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) s2_t*)addr, v);
-}
-
 inline int grid_for(size_t nvec) {
   size_t b = (nvec + 255) / 256;
   if (b > 2048) b = 2048;

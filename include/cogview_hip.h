@@ -96,7 +96,8 @@ int cogv_colsum_finalize(int dtype, const float* partial, int rows, int N, void*
  * kernel (M, N >= 256, K % 64 == 0): issue them one by one then.  Split-K as in cogv_gemm, per problem. */
 int cogv_gemm_grouped(const cogv_gemm_desc* descs, int count, void* stream);
 /* Note: the persistent GEMM kernel distributes tiles through per-XCD atomic work queues; the library keeps their
- * counters in 4 KiB of device memory per GPU that it allocates itself on the first GEMM call (its only allocation). */
+ * counters in 4 KiB of device memory per GPU that it allocates itself on the first GEMM call (its only allocations: this and
+ * the 16 KiB of partial sums of cogv_grad_stats). */
 int cogv_gemm_pick_splitk_tiles(int tiles_256x256, int K);
 
 /* Decode-step matrix-vector product with the layer's LayerNorms as prologue (M <= 8 rows, K = hidden size <= 4096,
@@ -276,7 +277,8 @@ int cogv_ce_bwd(int logits_dtype, const void* logits, const int64_t* target, int
  * group chunk_group[c] (< 8) and counts toward the norm iff chunk_norm[c] != 0 (model-parallel dedup of
  * mpu/grads.py:61).  chunk_start % 8 == 0.
  */
-/* stats[0] += sum of squares of grads in counted chunks (double), stats[1] = 1.0 if any grad is inf/nan */
+/* stats[0] += sum of squares of grads in counted chunks (double; per-workgroup partials summed in a fixed order: the same
+ * bits run after run -- the partials live in 16 KiB the library allocates once per device), stats[1] = 1.0 if any grad is inf/nan */
 int cogv_grad_stats(int dtype, const void* grads, const int64_t* chunk_start, const int32_t* chunk_len,
                     const uint8_t* chunk_norm, int nchunks, double* stats, void* stream);
 typedef struct cogv_adam_desc {

@@ -520,6 +520,29 @@ def test_grad_stats_and_adamw(ops, dtype):
     assert torch.equal(before, md)
 
 
+def test_grad_stats_is_run_to_run_deterministic(ops):
+    """The global sum of squares is per-workgroup partials summed in workgroup order (no floating-point atomics): identical
+    bits on every run, also with far more chunks than workgroups, and stats[0] accumulates across calls."""
+    g = torch.Generator().manual_seed(99)
+    n = 5000 * 4096 + 1234                                 # 5001 chunks > 2048 workgroups
+    grads = dev((torch.randn(n, generator=g) * 3.0).half())
+    cs = torch.arange(0, n, 4096, dtype=torch.int64)
+    cl = torch.full((len(cs),), 4096, dtype=torch.int32)
+    cl[-1] = n - int(cs[-1])
+    cn = torch.ones(len(cs), dtype=torch.uint8)
+    cs, cl, cn = dev(cs), dev(cl), dev(cn)
+    outs = []
+    for _ in range(5):
+        stats = torch.zeros(2, dtype=torch.float64, device="cuda")
+        ops.grad_stats(grads, cs, cl, cn, stats)
+        outs.append(stats.clone())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    ref = float((grads.double() ** 2).sum())
+    assert abs(outs[0][0].item() - ref) < 1e-6 * ref and outs[0][1].item() == 0.0
+    ops.grad_stats(grads, cs, cl, cn, stats)               # second call on the same stats: accumulates
+    assert stats[0].item() == 2.0 * outs[0][0].item()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_bwd_fused_qkv_bias_grad(ops, dtype):
     """colsum_out of cogv_attention_bwd == column sums of the stored dq | dk | dv (bias gradient of the QKV linear)."""
