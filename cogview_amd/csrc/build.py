@@ -101,6 +101,9 @@ def scan_asm_hazards(lines):
         if in_asm and op.startswith("global_load") and not op.startswith("global_load_lds"):
             flight["vmcnt"].append(regs(toks[0]))
             continue
+        if in_asm and op.startswith("global_atomic") and " sc0" in t:        # returning atomic: toks[0] is the destination
+            flight["vmcnt"].append(regs(toks[0]))
+            continue
         if in_asm and op.startswith("ds_read"):
             flight["lgkmcnt"].append(regs(toks[0]))
             continue

@@ -757,7 +757,8 @@ template <typename V> __device__ __forceinline__ void pin_s(V& x) { asm volatile
 
 template <typename T, int F>
 __device__ __forceinline__ void pp64_epilogue(const GemmArgs& pg, f32x4 (&acc)[8][4], float* strip, int m_base, int n_base,
-                                              int ksplit, int lane, uint32_t& amax_pk, int colsum_row) {
+                                              int ksplit, int lane, uint32_t& amax_pk, int colsum_row,
+                                              bool land_dma_first = false) {
   const int l15 = lane & 15, kb = lane >> 4;
   if ((COGV_EXP & 2048) && acc[0][0][0] != 12345.f) return;      // probe: no strip transposition either
   // the problem descriptor lives in the kernel-argument segment behind a run-time index: copy what this instance
@@ -818,6 +819,9 @@ __device__ __forceinline__ void pp64_epilogue(const GemmArgs& pg, f32x4 (&acc)[8
     int m = m_base + 8 * t + sr;
     if ((COGV_EXP & 64) && x0[0] != 12345.f) continue;      // probe: no epilogue
     if (COGV_EXP & 128) m &= 255;                           // probe: all tiles store to the same L2-resident rows
+    // (generation-4 kernel, -DCOGV_W4_PEEL) the next item's prologue DMAs, issued in front of this epilogue, are waited for
+    // in front of its FIRST store: behind it a vmcnt wait would also have to wait for stores
+    if (t == 0 && land_dma_first) wait_vmcnt<0>();
     if (m < p.M && n < p.N) {
       if (F == -2) {                                        // split-K partial: raw fp32 slab
         float* w = p.ws + ((size_t)ksplit * p.M + m) * p.N + n;
@@ -1513,6 +1517,9 @@ void gemm_w4_kernel(const GroupArgs ga) {
   if (threadIdx.x == 0) s_next = xq + 8 * atomicAdd(ga.sched + xq, 1);
   __syncthreads();
   Item cur;
+#if defined(COGV_W4_PEEL)
+  bool certified = false;
+#endif
   int item = __builtin_amdgcn_readfirstlane(s_next);     // wave-uniform by construction: keeps the DMA bases in SGPRs
   if (item < nitems) { setup(item, cur); prologue(cur); }
 #pragma unroll 1
@@ -1529,10 +1536,34 @@ void gemm_w4_kernel(const GroupArgs ga) {
 
     Frag fA, fI, fB0, fB1;
     // pre-step: the first A01 / B01 fragments (the only exposed LDS latency of the item)
+#if defined(COGV_W4_PEEL)
+    // `certified`: this item's 32 prologue DMAs were waited for (vmcnt(0)) in front of the previous epilogue's first C store
+    // (pp64_epilogue, land_dma_first) -- behind it a vmcnt wait would also wait for stores, the counter retires in order.
+    // The first three half-steps then run without vmcnt waits and the stores drain behind their MFMAs.
+    // MEASURED (profiles/r03_gemm_peel_ab_v2.log, three alternating runs): +1.2 to +2.1 % on the epilogues without a bias
+    // (plain dgrad, dGeLU + column sums), 0 +- 0.5 % on the bias epilogues -- there the compiler's own wait for the bias
+    // load (vmcnt(0) in front of the first store) already does the same thing; -1.4 .. +1 % at K = 1024.  ~ +0.5 % of the
+    // step's GEMM time: a build switch, off, until a full-suite run can carry it.
+    if (!certified) wait_vmcnt<24>();
+#else
     wait_vmcnt<24>();
+#endif
     __builtin_amdgcn_s_barrier();
+#if defined(COGV_W4_ASYNC_GRAB)
+    // the item after this one: asked for now, used after the k-loop.  Issued by hand and NOT awaited here: atomicAdd()
+    // makes the compiler wait for the returned value on the spot (s_waitcnt vmcnt(0) in wave 0) -- behind the 32 prologue
+    // DMAs and every C store of the previous epilogue, which all retire first (vmcnt is in order) -- and the other three
+    // waves then wait for wave 0 at the first half-step's barrier: the store drain plus an L2 atomic round trip per item,
+    // exposed.  The value is valid after the k-loop's vmcnt(0).
+    // MEASURED (profiles/r03_gemm_async_grab_peel_ab_v1.log): no change on any shape (+-1 %), so that wait is not what an
+    // item pays for; kept as a build switch, off.
+    uint32_t grabbed = 1u;                                 // in: the increment; out (thread 0): the queue position
+    if (threadIdx.x == 0)
+      asm volatile("global_atomic_add %0, %1, %0, %2 sc0" : "+v"(grabbed) : "v"(0u), "s"(ga.sched + xq) : "memory");
+#else
     int grabbed = 0;                                       // the item after this one: asked for now, used after the k-loop
     if (threadIdx.x == 0) grabbed = atomicAdd(ga.sched + xq, 1);
+#endif
     static_for<8>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       read1(fA, IC<G_A01>{}, IC<0>{}, IC<(r >> 2)>{}, IC<(r & 3)>{});
@@ -1570,36 +1601,56 @@ void gemm_w4_kernel(const GroupArgs ga) {
       land(fin, gin >= 2 ? BT : AT);
     };
     // one k-tile; fb01 holds B01(kt), fbx is free and ends up holding B01(kt + 1)
-    auto tile = [&](int kt, auto bufc, Frag& fb01, Frag& fbx) {
+    auto tile = [&](int kt, auto bufc, Frag& fb01, Frag& fbx, auto w0c, auto w1c) {
       constexpr int buf = decltype(bufc)::value;
+      constexpr bool W0 = decltype(w0c)::value != 0, W1 = decltype(w1c)::value != 0;   // vmcnt waits of the two half-steps
       const int t2 = min(kt + 2, nk - 1);
-      if (!(COGV_EXP & 8192)) wait_vmcnt<16>();
+      if (W0 && !(COGV_EXP & 8192)) wait_vmcnt<16>();
       __builtin_amdgcn_sched_barrier(0);
       if (!(COGV_EXP & 4096)) __builtin_amdgcn_s_barrier();      // probes: results are garbage without them
       __builtin_amdgcn_sched_barrier(0);
       quarter(IC<0>{}, IC<0>{}, fA, fb01, fbx, IC<G_B23>{}, IC<buf>{}, G_A01, t2, buf);
       quarter(IC<0>{}, IC<1>{}, fA, fbx, fI, IC<G_A23>{}, IC<buf>{}, G_B01, t2, buf);
-      if (!(COGV_EXP & 8192)) wait_vmcnt<16>();
+      if (W1 && !(COGV_EXP & 8192)) wait_vmcnt<16>();
       __builtin_amdgcn_sched_barrier(0);
       if (!(COGV_EXP & 4096)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       quarter(IC<1>{}, IC<1>{}, fI, fbx, fA, IC<G_A01>{}, IC<(buf ^ 1)>{}, G_B23, t2, buf);
       quarter(IC<1>{}, IC<0>{}, fI, fb01, fbx, IC<G_B01>{}, IC<(buf ^ 1)>{}, G_A23, t2, buf);
     };
-    for (int kt = 0; kt + 1 < nk; kt += 2) {               // two k-tiles per trip: the B register sets swap roles
-      tile(kt, IC<0>{}, fB0, fB1);
-      tile(kt + 1, IC<1>{}, fB1, fB0);
+    int kt = 0;
+#if defined(COGV_W4_PEEL)
+    // half-steps 0..2 read the prologue's granules (all certified above); half-step 3 reads what half-step 0 issued:
+    // its vmcnt(16) is the first wait that also covers the previous item's C stores, >= 2 us of MFMA work after the last one
+    if (certified && nk >= 2) {
+      tile(0, IC<0>{}, fB0, fB1, IC<0>{}, IC<0>{});
+      tile(1, IC<1>{}, fB1, fB0, IC<0>{}, IC<1>{});
+      kt = 2;
     }
-    if (nk & 1) tile(nk - 1, IC<0>{}, fB0, fB1);
+#endif
+    for (; kt + 1 < nk; kt += 2) {                         // two k-tiles per trip: the B register sets swap roles
+      tile(kt, IC<0>{}, fB0, fB1, IC<1>{}, IC<1>{});
+      tile(kt + 1, IC<1>{}, fB1, fB0, IC<1>{}, IC<1>{});
+    }
+    if (nk & 1) tile(nk - 1, IC<0>{}, fB0, fB1, IC<1>{}, IC<1>{});
     __builtin_amdgcn_sched_barrier(0);
     wait_vmcnt<0>();                                        // the (redundant) tail prefetches of this item
+#if defined(COGV_W4_ASYNC_GRAB)
+    asm volatile("" : "+v"(grabbed));                       // ... and the queue position asked for in the pre-step
+#endif
 
     // ---- next item's prologue goes out BEFORE this item's epilogue (the barrier also retires every wave's last reads)
-    if (threadIdx.x == 0) s_next = xq + 8 * grabbed;
+    if (threadIdx.x == 0) s_next = xq + 8 * (int)grabbed;
     __syncthreads();
     const int next = __builtin_amdgcn_readfirstlane(s_next);
     const Item done = cur;
     if (next < nitems) { setup(next, cur); prologue(cur); }
+#if defined(COGV_W4_PEEL)
+    certified = next < nitems;
+    const bool land_first = certified;
+#else
+    constexpr bool land_first = false;
+#endif
 
     uint32_t amax_pk = 0u;
     float* strip = reinterpret_cast<float*>(smem + 2 * BREG + wave * 2048);
@@ -1608,9 +1659,11 @@ void gemm_w4_kernel(const GroupArgs ga) {
 #if !defined(COGV_W4_SWAP_EPI)          // default: transposition through the wave's LDS strip
 #define W4_EPI(F_)                                                                                   \
   do {                                                                                               \
-    pp64_epilogue<T, F_>(p, acc[0], strip, mb, nb, done.ksplit, lane, amax_pk, csr);                 \
+    pp64_epilogue<T, F_>(p, acc[0], strip, mb, nb, done.ksplit, lane, amax_pk, csr, land_first);     \
     pp64_epilogue<T, F_>(p, acc[1], strip, mb, nb + 64, done.ksplit, lane, amax_pk, csr);            \
   } while (0)
+#elif defined(COGV_W4_PEEL)
+#error "COGV_W4_PEEL is written for the strip epilogue"
 #else                                   // -DCOGV_W4_SWAP_EPI: register exchange (v_permlane16_swap), no LDS.  Measured in round 3
                                         // (profiles/r03_gemm_swap_epilogue_ab.log): equal on plain / bias epilogues, +1.5 % on
                                         // GeLU + stored gelu', -2.3 % on the column-sum instance (16 per-lane column accumulators

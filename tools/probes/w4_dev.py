@@ -54,11 +54,19 @@ def run_one(tag):
         ("dgrad h<-4h plain (0)", 2.0 * M * 4 * h * h, lambda: ops.gemm(x4, w_1, trans_b=True)),
         ("dgrad h<-h  plain (0)", 2.0 * M * h * h, lambda: ops.gemm(x, w_d, trans_b=True)),
     ]
+    M2, h2 = 32640, 1024                                      # cogview-small-336M at b = 30 (K = 1024: 16 k-tiles per item)
+    y2, w2q, w21, b2q, b21 = rn(M2, h2), rn(3 * h2, h2) * 0.02, rn(4 * h2, h2) * 0.02, rn(3 * h2) * 0.02, rn(4 * h2) * 0.02
+    aux2 = torch.empty(M2, 4 * h2, device="cuda", dtype=dt)
+    cases += [
+        ("336M fwd qkv  bias (1)", 2.0 * M2 * 3 * h2 * h2, lambda: ops.gemm(y2, w2q, bias=b2q)),
+        ("336M fwd h->4h bias+gelu (epi 3)", 2.0 * M2 * 4 * h2 * h2, lambda: ops.gemm(y2, w21, bias=b21, gelu=True, gelu_aux=aux2)),
+        ("336M dgrad h<-h plain (0)", 2.0 * M2 * h2 * h2, lambda: ops.gemm(y2, w2q[:h2].contiguous(), trans_b=True)),
+    ]
     for nm, y, ref in (("NT", ops.gemm(x, w_d), x.float() @ w_d.float().t()), ("NN", ops.gemm(x, w_d, trans_b=True), x.float() @ w_d.float()),
                        ("TN", ops.gemm(x, x4[:, :h].contiguous(), trans_a=True, trans_b=True, splitk=1), x.float().t() @ x4[:, :h].float())):
         print(f"[{tag:10s}] check {nm}: rel-L2 {((y.float() - ref).norm() / ref.norm()).item():.2e}", flush=True)
     for name, fl, f in cases:
-        t = min(timeit(f, iters=10, warm=3) for _ in range(2))
+        t = min(timeit(f, iters=8, warm=2) for _ in range(2))
         print(f"[{tag:10s}] {name:34s} {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF", flush=True)
 
 
