@@ -136,7 +136,6 @@ SIGNATURES = {
     "cogv_dropout": (_i, [_i, _vp, _vp, _sz, _f, _u64, _u64, _vp, _vp]),
     "cogv_add": (_i, [_i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cogv_add_stream": (_i, [_i, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "cogv_prefetch": (_i, [_vp, _vp, _i, _i, _vp]),
     "cogv_scale": (_i, [_i, _vp, _vp, _sz, _f, _vp]),
     "cogv_absmax": (_i, [_i, _vp, _sz, _vp, _vp]),
     "cogv_colsum": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),

@@ -453,45 +453,6 @@ extern "C" int cogv_add_stream(int dtype, const float* a, const void* b, float* 
   return cogv_check_launch();
 }
 
-// ---- cache warming for the decode step: the weights a matrix-vector kernel will stream do not depend on the activations,
-//      so a side stream can pull the NEXT launch's weights through the memory-side cache while the current launch ramps up,
-//      runs and drains (a decode step is ~290 dependent launches whose ramp + tail leave HBM idle for about half the time).
-//      Pure reads: up to 4 byte ranges per launch, 16 bytes per lane per load, 8 loads in flight per lane; the xor of
-//      everything read is written only if it equals a value the caller cannot produce twice (keeps the loads alive).
-struct PrefetchArgs { const u32x4* ptr[4]; size_t n16[4]; int count; uint32_t* sink; };
-__global__ __launch_bounds__(1024) void prefetch_kernel(const PrefetchArgs a) {
-  u32x4 acc = {0u, 0u, 0u, 0u};
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (int r = 0; r < a.count; ++r) {
-    const u32x4* p = a.ptr[r];
-    const size_t n = a.n16[r];
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 7 * stride < n; i += 8 * stride) {
-      u32x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc ^= v[u];
-    }
-    for (; i < n; i += stride) acc ^= p[i];
-  }
-  const uint32_t x = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
-  if (a.sink && x == 0x9e3779b9u && a.n16[0] == (size_t)-1) *a.sink = x;
-}
-
-extern "C" int cogv_prefetch(const void* const* ptrs, const size_t* bytes, int count, int workgroups, void* stream) {
-  if (count < 1 || count > 4 || !ptrs || !bytes || workgroups < 1 || workgroups > 4096) return COGV_ERR_ARG;
-  PrefetchArgs a{};
-  a.count = count; a.sink = nullptr;
-  for (int r = 0; r < count; ++r) {
-    if (!ptrs[r] || ((uintptr_t)ptrs[r] & 15)) return COGV_ERR_ARG;
-    a.ptr[r] = reinterpret_cast<const u32x4*>(ptrs[r]);
-    a.n16[r] = bytes[r] >> 4;
-  }
-  hipLaunchKernelGGL(prefetch_kernel, dim3(workgroups), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), a);
-  return cogv_check_launch();
-}
-
 extern "C" int cogv_absmax(int dtype, const void* x, size_t n, float* out, void* stream) {
   if (dtype != COGV_F16 && dtype != COGV_BF16 && dtype != COGV_F32) return COGV_ERR_UNSUPPORTED;
   if (!x || !out || n == 0 || ((uintptr_t)x & 15)) return COGV_ERR_ARG;

@@ -709,37 +709,6 @@ def _decode_fuse_combine():
     return not torch.cuda.is_current_stream_capturing()
 
 
-# Cache warming on a side stream (round 3, experimental, off): COGV_DECODE_PREFETCH=<workgroups> makes every launch of the
-# chain fork a side-stream read of the weights the launch AFTER it will stream (ops.prefetch): a decode step is ~290
-# dependent launches whose ramp + tail leave HBM idle about half of the time, and the weights do not depend on the
-# activations.  The fork is an event edge (captured into the graph like any other dependency); the main chain never waits
-# for the side stream until the end of the step.
-_DECODE_PREFETCH = int(_os.environ.get("COGV_DECODE_PREFETCH", "0") or 0)
-_prefetch_streams = {}
-
-
-class _Warm:
-    def __init__(self, dev, workgroups):
-        self.wgs = workgroups
-        if workgroups:
-            self.main = torch.cuda.current_stream(dev)
-            self.side = _prefetch_streams.get((dev, self.main.cuda_stream))
-            if self.side is None:
-                self.side = _prefetch_streams[(dev, self.main.cuda_stream)] = torch.cuda.Stream(dev)
-
-    def ahead(self, *tensors):
-        """Call right before a launch on the main stream: the side stream waits for everything in front of that launch
-        and then reads `tensors` while it runs."""
-        if self.wgs:
-            self.side.wait_stream(self.main)
-            with torch.cuda.stream(self.side):
-                ops.prefetch(tensors, self.wgs)
-
-    def join(self):
-        if self.wgs:
-            self.main.wait_stream(self.side)
-
-
 def decode_chain_supported(tr, batch):
     """The fused decode chain (decode_chain) covers the dense, single-partition model in a 16-bit type at one token per
     row: what a captured decode step runs."""
@@ -760,20 +729,16 @@ def decode_chain(tr, h0, absmax0, slots, emb_weight):
     assert s == 1
     dev = h0.device
     z, z_absmax, post, res = h0.view(b, h), absmax0, None, None
-    warm = _Warm(dev, _DECODE_PREFETCH)
-    layers = list(tr.layers)
-    for li, (layer, slot) in enumerate(zip(layers, slots)):
+    for layer, slot in zip(tr.layers, slots):
         att_m, mlp_m = layer.attention, layer.mlp
         eps = layer.input_layernorm.eps
         npp = att_m.num_attention_heads_per_partition
         hp = npp * 64
-        warm.ahead(slot.cache, att_m.dense.weight)                      # while the QKV product runs
         qkv, x = ops.gemv_ln(z, att_m.query_key_value.weight, att_m.query_key_value.bias, layer.input_layernorm.weight,
                              layer.input_layernorm.bias, eps, z_absmax, post, res, want_t=post is not None)
         if x is None:
             x = z
         slot_ao = ops.new_absmax_slot(dev)
-        warm.ahead(mlp_m.dense_h_to_4h.weight)                           # while attention and its output projection run
         if hp % 512 == 0 and _decode_fuse_combine():
             # the key splits' partials are combined in the prologue of the attention-output GEMV (one launch less)
             parts = ops.attention_decode(qkv.view(b, 1, 3 * hp), slot.cache, slot.pos_index, npp, combine=False)
@@ -782,16 +747,12 @@ def decode_chain(tr, h0, absmax0, slots, emb_weight):
             att = ops.attention_decode(qkv.view(b, 1, 3 * hp), slot.cache, slot.pos_index, npp)
             ao = ops.gemm(att.view(b, hp), att_m.dense.weight, bias=att_m.dense.bias, absmax=slot_ao)
         slot.out = slot.cache
-        warm.ahead(mlp_m.dense_4h_to_h.weight)                           # while h -> 4h runs
         g, y = ops.gemv_ln(ao, mlp_m.dense_h_to_4h.weight, mlp_m.dense_h_to_4h.bias, layer.post_attention_layernorm.weight,
                            layer.post_attention_layernorm.bias, eps, slot_ao,
                            (layer.third_layernorm.weight, layer.third_layernorm.bias), x, want_t=True, gelu=True)
         slot_mo = ops.new_absmax_slot(dev)
-        if li + 1 < len(layers):
-            warm.ahead(layers[li + 1].attention.query_key_value.weight)  # while 4h -> h runs
         mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias, absmax=slot_mo)
         z, z_absmax, post, res = mo, slot_mo, (layer.fourth_layernorm.weight, layer.fourth_layernorm.bias), y
-    warm.join()
     fl = tr.final_layernorm
     logits, _ = ops.gemv_ln(z, emb_weight, None, fl.weight, fl.bias, fl.eps, z_absmax, post, res)
     return logits.view(b, 1, emb_weight.shape[0])

@@ -694,18 +694,6 @@ def dropout(x, p, seed, stream_id, absmax_out=None):
     return y
 
 
-def prefetch(tensors, workgroups=32):
-    """Read up to four contiguous tensors on the current stream and discard them (cogv_prefetch): cache warming for the next
-    matrix-vector launch of a decode step, issued on a side stream."""
-    import ctypes as C
-    ts = [t for t in tensors if t is not None]
-    _need_gpu(*ts)
-    assert 1 <= len(ts) <= 4 and all(t.is_contiguous() for t in ts)
-    ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-    sizes = (C.c_size_t * len(ts))(*[t.numel() * t.element_size() for t in ts])
-    L.check(L.lib().cogv_prefetch(ptrs, sizes, len(ts), int(workgroups), _stream()), "cogv_prefetch")
-
-
 def add(a, b, absmax_out=None):
     """a + b.  An fp32 `a` is the residual stream joined by the 16-bit branch output `b` (fp32 result)."""
     _need_gpu(a, b)

@@ -252,10 +252,6 @@ int cogv_absmax(int dtype, const void* x, size_t n, float* out, void* stream);  
 /* out(fp32) = a(fp32) + b(T): a branch output joins the fp32 residual stream (the residual adds of
  * mpu/sparse_transformer.py:329,:340 when the layer is composed op by op); abs-max of out like cogv_add */
 int cogv_add_stream(int dtype, const float* a, const void* b, float* out, size_t n, float* absmax_out, void* stream);
-/* Cache warming (incremental decoding, generation/sampling.py:64-186 through GraphDecoder): read `count` (1..4) 16-byte
- * aligned byte ranges with `workgroups` x 1024 lanes and discard them -- on a side stream, while the current matrix-vector
- * launch runs, so that the next launch finds its weights in the memory-side cache.  No output; never needed for correctness. */
-int cogv_prefetch(const void* const* ptrs, const size_t* bytes, int count, int workgroups, void* stream);
 /* out[n] (+)= sum_m dy[m][n]  -- bias gradients of the Linear layers */
 int cogv_colsum(int dtype, const void* dy, int M, int N, int ld, void* out, int accumulate, void* workspace,
                 size_t workspace_bytes, void* stream);
