@@ -263,6 +263,10 @@ class FP16_Optimizer(object):
                 # other norms (fp16/fp16.py:312-334 hands norm_type through to clip_grad_norm): the unfused way -- the norm
                 # of the unscaled gradients by mpu.clip_grad_norm's rule, the coefficient folded into the 16-bit gradients;
                 # the fused step then runs without its own (2-norm) clipping
+                if self._shard is not None:
+                    # after the reduce-scatter only the owned slices hold mean gradients: a per-tensor norm would read
+                    # partial sums.  (The fused 2-norm path restricts its chunk table to the owned ranges instead.)
+                    raise NotImplementedError("norm_type != 2 is not available with the sharded optimizer exchange")
                 self._arena.finish_lazy()
                 params = [p for p in self._arena.params if p.grad is not None]      # the 16-bit model parameters (arena views)
                 total = mpu.clip_grad_norm(params, float(max_norm) * self.loss_scale, norm_type) / self.loss_scale
