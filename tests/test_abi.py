@@ -87,3 +87,11 @@ def test_build_flags_reads_of_in_flight_asm_loads():
     # using an in-flight destination as a STORE source is a read too; writing an unrelated register is fine
     st = asm(*load("v[2:5]", "v[20:21]"), "ds_write_b128 v70, v[2:5]", "v_mov_b32_e32 v80, v81", *wait(0))
     assert [h[2] for h in scan_asm_hazards(st)] == ["ds_write_b128 v70, v[2:5]"]
+    # a RETURNING atomic issued through asm (the generation-4 GEMM's hand-issued work-queue grab, -DCOGV_W4_ASYNC_GRAB) is a
+    # load of its destination register; without sc0 nothing comes back and nothing is tracked
+    grab = [";;#ASMSTART", "global_atomic_add v135, v168, v135, s[68:69] sc0", ";;#ASMEND"]
+    early = asm(*grab, "v_lshl_or_b32 v0, v135, 3, s81", *wait(0))
+    assert [h[2] for h in scan_asm_hazards(early)] == ["v_lshl_or_b32 v0, v135, 3, s81"]
+    assert scan_asm_hazards(asm(*grab, *wait(0), "v_lshl_or_b32 v0, v135, 3, s81")) == []
+    noret = asm(";;#ASMSTART", "global_atomic_add v168, v135, s[68:69]", ";;#ASMEND", "v_mov_b32_e32 v1, v135", *wait(0))
+    assert scan_asm_hazards(noret) == []
