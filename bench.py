@@ -14,9 +14,11 @@ Adam moments and gradients = 64 GB, so the whole model fits one 288-GB MI355X an
 replica, BASELINE.json configs[3]) -- rows of 1089 random tokens (1088 model positions), vocab 58240, weak scaling
 (per-GPU micro-batch fixed).  `--config cogview-small-336M` runs configs[1]; `--model-parallel 2` runs configs[2] (the
 4B model split column/row-wise over adjacent rank pairs, vocab 58368); `--config vqvae` runs configs[4] (VQ-VAE
-tokenizer: img2code + code2img of 256 images of 256x256 per step, replicas only).  Without `--dtype` the N=1 default
-run measures bf16 (BASELINE configs[3]: the headline `value`) and then the same step in fp16 -- the reference's own
-dtype and the one that meets the 1e-3 logits bar -- reported under "fp16_leg".  Prints ONE JSON line (rank 0).
+tokenizer: img2code + code2img of 256 images of 256x256 per step, replicas only); `--config cogview-tiny-18M` runs
+configs[0] (4 L / 256 h / 4 heads, rows of 256 -- the case the reference itself runs on a CPU).  Without `--dtype` the
+run measures fp16 -- the reference's own storage type (fp16/fp16.py) and the one whose logits meet north_star's 1e-3 bar
+at 48 layers: it is the headline `value` / `dtype` -- and, at N = 1, the same step in bf16 (BASELINE configs[3]'s
+extension; logits 2e-3..5e-3, above the bar) reported under "bf16_leg".  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -35,13 +37,16 @@ CONFIGS = {
     # name: (layers, hidden, heads)           BASELINE.json configs[1] / configs[3]
     "cogview-small-336M": (24, 1024, 16),
     "cogview-base-4B": (48, 2560, 40),
+    "cogview-tiny-18M": (4, 256, 4),          # BASELINE.json configs[0]: rows of 256 tokens (s = 255), b = 4
 }
+ROW_LEN = {"cogview-tiny-18M": 256}            # tokens per data row (default ROW = 1089)
 # per-GPU micro-batch (sequences): b x 1088 rows must fill whole rounds of 256-row GEMM tiles on 256 CUs.
 #   336M: 30 x 1088 = 127.5 -> 128 row tiles;  4B: 24 x 1088 = 102 row tiles exactly, and 102 x {10, 30, 40}
 #   column tiles of 256 are 3.98 / 11.95 / 15.94 rounds (activations 129 GB + 64 GB of model state < 288 GB)
-DEFAULT_BATCH = {"cogview-small-336M": 30, "cogview-base-4B": 24}
+DEFAULT_BATCH = {"cogview-small-336M": 30, "cogview-base-4B": 24, "cogview-tiny-18M": 4}
 METRIC = {"cogview-base-4B": "train tokens/sec/node (seq1089, 4B GPT) at 1/2/4/8 MI355X; % MFMA roofline",
-          "cogview-small-336M": "train tokens/sec/node (seq1089, 336M GPT) at 1/2/4/8 MI355X; % MFMA roofline"}
+          "cogview-small-336M": "train tokens/sec/node (seq1089, 336M GPT) at 1/2/4/8 MI355X; % MFMA roofline",
+          "cogview-tiny-18M": "train tokens/sec/node (seq256, 18M GPT, BASELINE configs[0]) at 1/2/4/8 MI355X; % MFMA roofline"}
 N_TOKEN_IDS = 58219
 
 
@@ -74,16 +79,17 @@ def gemm_flops(M, N, K):
     return 2.0 * M * N * K
 
 
-def cpu_baseline(L, h, heads, sample_layers=4):
+def cpu_baseline(L, h, heads, sample_layers=4, row=ROW):
     """The CPU oracle (oracle/cogview_oracle.py, fp32, torch CPU threads) timed on a bounded sample of the same
     workload: ONE 1088-token sequence through the embedding, `sample_layers` of the L layers, the tied LM head and
     the cross entropy, forward + backward; the layer part is scaled by L / sample_layers."""
     from oracle import cogview_oracle as O
     torch.manual_seed(0)
-    s = ROW - 1
+    s = row - 1
+    sample_layers = min(sample_layers, L)
     g = torch.Generator().manual_seed(1)
     p = {"word_embeddings.weight": torch.randn(VOCAB, h, generator=g) * 0.02,
-         "transformer.position_embeddings.weight": torch.randn(ROW, h, generator=g) * 0.02,
+         "transformer.position_embeddings.weight": torch.randn(row, h, generator=g) * 0.02,
          "transformer.final_layernorm.weight": torch.ones(h), "transformer.final_layernorm.bias": torch.zeros(h)}
     for l in range(sample_layers):
         pre = f"transformer.layers.{l}."
@@ -95,7 +101,7 @@ def cpu_baseline(L, h, heads, sample_layers=4):
             p[pre + name + ".bias"] = torch.zeros(o)
     for t in p.values():
         t.requires_grad_(True)
-    ids = torch.randint(0, N_TOKEN_IDS, (1, ROW), generator=g)
+    ids = torch.randint(0, N_TOKEN_IDS, (1, row), generator=g)
     tokens, labels = ids[:, :-1], ids[:, 1:]
     pos = torch.arange(s).unsqueeze(0)
     mask = O.build_mask(s, s)
@@ -112,23 +118,23 @@ def cpu_baseline(L, h, heads, sample_layers=4):
     t_full = run(sample_layers)
     t_layers = max(t_full - t_head, 1e-9) * (L / sample_layers)
     return {"value": s / (t_head + t_layers), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 sequence x 1088 positions, fp32 oracle fwd+bwd: embedding + {sample_layers} of {L} layers "
+            "sample": f"1 sequence x {s} positions, fp32 oracle fwd+bwd: embedding + {sample_layers} of {L} layers "
                       f"(scaled x{L / sample_layers:g}) + tied LM head + CE; head {t_head:.2f}s, "
                       f"{sample_layers} layers {t_full - t_head:.2f}s"}
 
 
-def measure_parity(inner, L, heads):
+def measure_parity(inner, L, heads, row=ROW):
     """The CPU oracle as the CHECKER of the model this run just timed (part of the cpu_baseline leg: rank 0, N = 1):
     one 1088-position sequence through ALL layers of the timed model's current weights (as stored, widened to fp32) on
     the CPU in fp32, against the HIP forward of the same sequence -- relative L2 of the logits and of the residual stream
     after 1, 2, 4, ... layers (oracle/depth_check.py).  The oracle forward is also a CPU timing sample (forward only)."""
     from oracle import depth_check as D
-    ids = torch.randint(0, N_TOKEN_IDS, (1, ROW - 1), generator=torch.Generator().manual_seed(4321)).cuda()
+    ids = torch.randint(0, N_TOKEN_IDS, (1, row - 1), generator=torch.Generator().manual_seed(4321)).cuda()
     rep = D.depth_report(inner, ids, L, heads)
     return {"logits_rel_l2": rep["logits"],
             "residual_stream_rel_l2_after_n_layers": {str(n): e for n, e in rep["stream"].items()},
             "against": "oracle/cogview_oracle.py fp32 on the CPU, all %d layers, the timed model's weights as stored, "
-                       "1 sequence x 1088 positions, dropout off" % L,
+                       "1 sequence x %d positions, dropout off" % (L, row - 1),
             "oracle_forward_seconds": rep["oracle_seconds"],
             "oracle_forward_tokens_per_s": rep["tokens"] / rep["oracle_seconds"]}
 
@@ -249,11 +255,12 @@ def run_gpt(args, dtype_name, world, rank, mp, parity=False):
     torch.manual_seed(1234)
     mpu.model_parallel_cuda_manual_seed(1234)
     L, h, heads = CONFIGS[args.config]
+    row = ROW_LEN.get(args.config, ROW)
     vocab = padded_vocab(mp)
     dp_world = world // mp
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
     t0 = time.perf_counter()
-    model = GPT2Model(L, vocab, h, heads, args.dropout, args.dropout, args.dropout, ROW, 0, args.checkpoint_activations)
+    model = GPT2Model(L, vocab, h, heads, args.dropout, args.dropout, args.dropout, row, 0, args.checkpoint_activations)
     n_params = sum(p.numel() for p in model.parameters())          # per rank (a shard when mp > 1)
     model = FP16_Module(model.cuda(), dtype=dtype, keep_half_outputs=True)
     ddp = None
@@ -280,8 +287,8 @@ def run_gpt(args, dtype_name, world, rank, mp, parity=False):
         f"dropout {args.dropout}, recompute {args.checkpoint_activations}")
 
     gen = torch.Generator().manual_seed(1234 + mpu.get_data_parallel_rank())     # one batch per model-parallel group
-    text = torch.randint(0, N_TOKEN_IDS, (args.batch, ROW), generator=gen).cuda()      # resident in HBM
-    loss_mask = torch.ones(args.batch, ROW, device="cuda")
+    text = torch.randint(0, N_TOKEN_IDS, (args.batch, row), generator=gen).cuda()      # resident in HBM
+    loss_mask = torch.ones(args.batch, row, device="cuda")
     batch = training.get_batch(text, loss_mask)
 
     def step():
@@ -291,17 +298,17 @@ def run_gpt(args, dtype_name, world, rank, mp, parity=False):
     final_loss = loss.item()
     assert final_loss == final_loss, "loss is NaN"
 
-    tokens_per_step = dp_world * args.batch * (ROW - 1)
+    tokens_per_step = dp_world * args.batch * (row - 1)
     value = tokens_per_step * args.steps / elapsed
-    fpt = flops_per_token(L, h, vocab)
+    fpt = flops_per_token(L, h, vocab, s=row - 1)
     out = {
         "metric": METRIC[args.config], "value": value, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": f"{args.config} ({L}L/{h}h/{heads} heads, {n_params / 1e6:.1f}M params per rank), rows of "
-                               f"1089 random token ids -> 1088 model positions, vocab {vocab}, full train step "
+                               f"{row} random token ids -> {row - 1} model positions, vocab {vocab}, full train step "
                                f"(fwd+CE+nan guard+bwd+grad all-reduce+clip+AdamW)",
-                   "global_batch": dp_world * args.batch, "seq_len": ROW, "model_positions": ROW - 1,
+                   "global_batch": dp_world * args.batch, "seq_len": row, "model_positions": row - 1,
                    "parallelism": f"dp{dp_world}" + (f"-mp{mp}" if mp > 1 else "") + ("-sharded-optimizer" if (ddp is not None and ddp.shard is not None) else ""),
                    "dropout": args.dropout,
                    "activation_recompute": bool(args.checkpoint_activations), "loss": final_loss,
@@ -322,9 +329,9 @@ def run_gpt(args, dtype_name, world, rank, mp, parity=False):
         for k, v in gemm_stats["by_shape"].items():
             log(f"    {k:44s} {v['tflops']:8.1f} {v['launches']:6d} {v['avg_ms']:9.4f}")
         # HBM-side traffic of the dominant kernel: measured off-line with rocprofv3 PMC passes (tools/collect_traffic.sh,
-        # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read correction) for the bf16 single-GPU workloads.
+        # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read correction) for the single-GPU workloads (collected on the bf16 build).
         tpath = latest_profile("gemm_hbm_traffic_pmc_%s_b%d.json" % (args.config.split("-")[-1], args.batch))
-        if tpath is not None and mp == 1 and dtype_name == "bf16":
+        if tpath is not None and mp == 1:            # both 16-bit storage types move the same bytes
             t = json.load(open(tpath))
             algo = gemm_stats["algo_bytes"] / max(gemm_stats["launches"], 1)
             out["roofline"]["traffic"] = t["gemm_hbm_bytes_per_launch_corrected"]
@@ -333,7 +340,7 @@ def run_gpt(args, dtype_name, world, rank, mp, parity=False):
             out["roofline"]["algorithmic_bytes_per_launch"] = algo
     if parity:
         t0 = time.perf_counter()
-        par = measure_parity(inner, L, heads)
+        par = measure_parity(inner, L, heads, row)
         out["config"]["logits_rel_l2_vs_fp32_reference"].update(
             measured=par["logits_rel_l2"], measured_by="this run, on the model it timed (after its %d steps)" % (args.steps + args.warmup),
             detail=par)
@@ -407,7 +414,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="micro-batch per GPU (sequences of 1089 tokens / images); default per config")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16"],
-                    help="default: bf16 as the headline value, plus an fp16 leg in the same line when N=1")
+                    help="default: fp16 (the reference's dtype; meets the 1e-3 logits bar) as the headline value, plus a bf16 leg "
+                         "in the same line when N=1")
     ap.add_argument("--model-parallel", type=int, default=1,
                     help="model-parallel size (BASELINE configs[2]: 2); ranks r, r+1 form a group (mpu/initialize.py)")
     ap.add_argument("--shard-optimizer", action="store_true",
@@ -418,7 +426,7 @@ def main():
                     help="recompute each layer in backward (the reference's scripts do; 288 GB HBM makes it unnecessary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--no-second-dtype", action="store_true", help="skip the fp16 leg of the default run")
+    ap.add_argument("--no-second-dtype", action="store_true", help="skip the bf16 leg of the default run")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the full-depth logits check of the timed model against the CPU oracle (about one CPU "
                          "minute per dtype at 4B; part of the cpu_baseline leg, so --no-cpu-baseline skips it too)")
@@ -441,19 +449,19 @@ def main():
         mpu.initialize_model_parallel(mp)
         L, h, heads = CONFIGS[args.config]
         parity = world == 1 and mp == 1 and not args.no_cpu_baseline and not args.no_parity
-        out = run_gpt(args, args.dtype or "bf16", world, rank, mp, parity=parity)
+        out = run_gpt(args, args.dtype or "fp16", world, rank, mp, parity=parity)
         if args.dtype is None and world == 1 and not args.no_second_dtype:
-            leg = run_gpt(args, "fp16", world, rank, mp, parity=parity)
-            out["fp16_leg"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "dtype", "model_tflops_per_gpu",
+            leg = run_gpt(args, "bf16", world, rank, mp, parity=parity)
+            out["bf16_leg"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "dtype", "model_tflops_per_gpu",
                                                    "mfma_roofline_frac_end_to_end")}
-            out["fp16_leg"]["loss"] = leg["config"]["loss"]
-            out["fp16_leg"]["loss_scale"] = leg["config"]["loss_scale"]
-            out["fp16_leg"]["logits_rel_l2_vs_fp32_reference"] = leg["config"]["logits_rel_l2_vs_fp32_reference"]
+            out["bf16_leg"]["loss"] = leg["config"]["loss"]
+            out["bf16_leg"]["loss_scale"] = leg["config"]["loss_scale"]
+            out["bf16_leg"]["logits_rel_l2_vs_fp32_reference"] = leg["config"]["logits_rel_l2_vs_fp32_reference"]
             if "roofline" in leg:
-                out["fp16_leg"]["roofline"] = {k: leg["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "launches",
+                out["bf16_leg"]["roofline"] = {k: leg["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "launches",
                                                                                "avg_launch_ms", "share_of_step_time")}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(L, h, heads)
+            out["cpu_baseline"] = cpu_baseline(L, h, heads, row=ROW_LEN.get(args.config, ROW))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

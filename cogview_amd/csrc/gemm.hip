@@ -819,7 +819,7 @@ __device__ __forceinline__ void pp64_epilogue(const GemmArgs& pg, f32x4 (&acc)[8
     int m = m_base + 8 * t + sr;
     if ((COGV_EXP & 64) && x0[0] != 12345.f) continue;      // probe: no epilogue
     if (COGV_EXP & 128) m &= 255;                           // probe: all tiles store to the same L2-resident rows
-    // (generation-4 kernel, -DCOGV_W4_PEEL) the next item's prologue DMAs, issued in front of this epilogue, are waited for
+    // (generation-4 kernel) the next item's prologue DMAs, issued in front of this epilogue, are waited for
     // in front of its FIRST store: behind it a vmcnt wait would also have to wait for stores
     if (t == 0 && land_dma_first) wait_vmcnt<0>();
     if (m < p.M && n < p.N) {
@@ -851,104 +851,6 @@ __device__ __forceinline__ void pp64_epilogue(const GemmArgs& pg, f32x4 (&acc)[8
       float* w = pg.colsum_ws + (size_t)colsum_row * p.N + n;
       gstore16(w, f32x4{cs[0], cs[1], cs[2], cs[3]});
       gstore16(w + 4, f32x4{cs[4], cs[5], cs[6], cs[7]});
-    }
-  }
-}
-
-// ---- the same epilogue WITHOUT the LDS transposition (round 3, generation-4 kernel): the MFMA layout leaves a lane with 4
-//      consecutive columns of one row per 16x16 block (lane = row l & 15, columns 4 (l >> 4) .. +3).  v_permlane16_swap
-//      exchanges registers between the lane rows l >> 4 = (0, 1) and (2, 3): one swap per accumulator register of a pair of
-//      neighbouring blocks (j, j + 1) hands every lane 8 consecutive columns of its row --
-//          lane row kb = 0: block j, columns 0..7      kb = 1: block j + 1, columns 0..7
-//                   kb = 2: block j, columns 8..15     kb = 3: block j + 1, columns 8..15
-//      -- i.e. 16 rows x 64 contiguous bytes per store instruction.  Measured (tools/probes/store_pattern.hip, round 3):
-//      that pattern streams at the rate of the 8 rows x 128 B of the strip form (5.2-5.4 TB/s both), and the 32 dependent LDS
-//      round trips per tile (write 8 rows, read them back transposed, wait) disappear; nothing else changes: the fused
-//      element-wise chain is the same epilogue8 on 8 consecutive columns.
-template <typename T, int F>
-__device__ __forceinline__ void w4_epilogue_swap(const GemmArgs& pg, f32x4 (&acc)[8][4], int m_base, int n_base, int ksplit,
-                                                 int lane, uint32_t& amax_pk, int colsum_row) {
-  const int l15 = lane & 15, kb = lane >> 4;
-  if ((COGV_EXP & 2048) && acc[0][0][0] != 12345.f) return;      // probe: no epilogue at all
-  GemmArgs p = pg;
-  pin_s(p.C); pin_s(p.M); pin_s(p.N); pin_s(p.ldc);
-  if (F < 0 || (F & (COGV_EPI_GELU | COGV_EPI_DGELU | COGV_EPI_MULAUX))) { pin_s(p.aux); pin_s(p.ldaux); }
-  if (F < 0 || (F & COGV_EPI_DROPOUT)) { pin_s(p.seed); pin_s(p.stream_id); pin_s(p.thr16); pin_s(p.keep_scale); }
-  if (F < 0) { pin_s(p.flags); pin_s(p.out_f32); pin_s(p.bias); }
-  if (F == -2) pin_s(p.ws);
-  const bool want_cs = (F == -1) ? ((p.flags & COGV_EPI_COLSUM) != 0 && !p.out_f32) : (F >= 0 && (F & COGV_EPI_COLSUM));
-  float cs[2][8];
-#pragma unroll
-  for (int jp = 0; jp < 2; ++jp)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cs[jp][e] = 0.f;
-  const int ncol = n_base + 16 * (kb & 1) + 8 * (kb >> 1);        // the lane's 8 columns inside block pair jp: ncol + 32 jp
-  constexpr bool PRE_BIAS = F >= 0 && (F & COGV_EPI_BIAS), PRE_AUX = F >= 0 && (F & (COGV_EPI_DGELU | COGV_EPI_MULAUX)), PRE_C = F >= 0 && (F & COGV_EPI_ACCUM);
-  u32x4 bias_v[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, aux_v[PRE_AUX ? 16 : 1], c_v[PRE_C ? 16 : 1];
-  if (PRE_BIAS) {
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp)
-      if (ncol + 32 * jp < p.N) bias_v[jp] = gload16(reinterpret_cast<const T*>(pg.bias) + ncol + 32 * jp);
-  }
-  if (PRE_AUX || PRE_C) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int m = m_base + 16 * (q >> 1) + l15, n = ncol + 32 * (q & 1);
-      const bool ok = m < p.M && n < p.N;
-      if (PRE_AUX) aux_v[q] = ok ? gload16(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n) : u32x4{0u, 0u, 0u, 0u};
-      if (PRE_C) c_v[q] = ok ? gload16(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n) : u32x4{0u, 0u, 0u, 0u};
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int t2 = q >> 1, jp = q & 1;
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[t2][2 * jp][i]), __float_as_uint(acc[t2][2 * jp + 1][i]), false, false);
-      v[i] = __uint_as_float(r[0]); v[4 + i] = __uint_as_float(r[1]);
-    }
-    int m = m_base + 16 * t2 + l15;
-    const int n = ncol + 32 * jp;
-    if (COGV_EXP & 128) m &= 255;                             // probe: every tile stores to the same L2-resident rows
-    if (m < p.M && n < p.N) {
-      if (F == -2) {                                          // split-K partial: raw fp32 slab
-        float* w = p.ws + ((size_t)ksplit * p.M + m) * p.N + n;
-        gstore16(w, f32x4{v[0], v[1], v[2], v[3]});
-        gstore16(w + 4, f32x4{v[4], v[5], v[6], v[7]});
-      } else {
-        float rv[8];
-        amax_pk = absmax_pk(amax_pk, epilogue8<T, (F < 0 ? -1 : F)>(p, m, n, v, PRE_BIAS ? &bias_v[jp] : nullptr,
-                                                                     PRE_AUX ? &aux_v[q] : nullptr,
-                                                                     PRE_C ? &c_v[q] : nullptr, want_cs ? rv : nullptr));
-        if (want_cs) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) cs[jp][e] += rv[e];
-        }
-      }
-    }
-  }
-  if (want_cs) {     // the 16 lanes of a lane row hold the same columns: fold them, lane l15 = 0 of each row writes
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        // sum over the 16 lanes of the lane row through DPP only (quad butterflies, half-row and row mirrors: four
-        // v_add_f32_dpp; __shfl_xor would be a ds_bpermute round trip each -- 64 of them per sub-tile measured -3.6 % on
-        // the dgrad launch that carries the bias-gradient column sums)
-        float t = cs[jp][e];
-        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false));
-        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, false));
-        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xf, 0xf, false));
-        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x140, 0xf, 0xf, false));
-        cs[jp][e] = t;
-      }
-      const int n = ncol + 32 * jp;
-      if (l15 == 0 && n < p.N) {
-        float* w = pg.colsum_ws + (size_t)colsum_row * p.N + n;
-        gstore16(w, f32x4{cs[jp][0], cs[jp][1], cs[jp][2], cs[jp][3]});
-        gstore16(w + 4, f32x4{cs[jp][4], cs[jp][5], cs[jp][6], cs[jp][7]});
-      }
     }
   }
 }
@@ -1376,6 +1278,17 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// Probe builds only (-DCOGV_W4_TS, tools/probes/w4_ts.py): per-wave wall time (s_memrealtime, 100 MHz) of the phases of an
+// item, summed over the wave's items and written over the first 32 KiB of problem 0's C when the workgroup exits -- the
+// output of such a build is garbage there by design.  Phases: 0 first wait + barrier, 1 pre-step (queue atomic, first
+// fragments), 2 k-loop, 3 drain wait + item hand-over barrier, 4 next item's setup + prologue issue, 5 / 6 the two epilogue
+// halves; slot 7 counts items, slots 8 / 9 are the kernel's total in s_memrealtime / s_memtime ticks (-> shader clock).
+#if defined(COGV_W4_TS)
+#define W4_TS(k_) do { const uint64_t t_ = __builtin_amdgcn_s_memrealtime(); ts_acc[k_] += (uint32_t)(t_ - ts_last); ts_last = t_; } while (0)
+#else
+#define W4_TS(k_) do { } while (0)
+#endif
+
 template <typename T, bool AT, bool BT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemm_w4_kernel(const GroupArgs ga) {
@@ -1517,11 +1430,14 @@ void gemm_w4_kernel(const GroupArgs ga) {
   if (threadIdx.x == 0) s_next = xq + 8 * atomicAdd(ga.sched + xq, 1);
   __syncthreads();
   Item cur;
-#if defined(COGV_W4_PEEL)
   bool certified = false;
-#endif
   int item = __builtin_amdgcn_readfirstlane(s_next);     // wave-uniform by construction: keeps the DMA bases in SGPRs
   if (item < nitems) { setup(item, cur); prologue(cur); }
+#if defined(COGV_W4_TS)
+  uint32_t ts_acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  const uint64_t ts_begin = __builtin_amdgcn_s_memrealtime(), ts_clk0 = __builtin_readcyclecounter();
+  uint64_t ts_last = ts_begin;
+#endif
 #pragma unroll 1
   while (item < nitems) {
     const GemmArgs& p = ga.g[cur.pi];
@@ -1536,40 +1452,26 @@ void gemm_w4_kernel(const GroupArgs ga) {
 
     Frag fA, fI, fB0, fB1;
     // pre-step: the first A01 / B01 fragments (the only exposed LDS latency of the item)
-#if defined(COGV_W4_PEEL)
     // `certified`: this item's 32 prologue DMAs were waited for (vmcnt(0)) in front of the previous epilogue's first C store
     // (pp64_epilogue, land_dma_first) -- behind it a vmcnt wait would also wait for stores, the counter retires in order.
     // The first three half-steps then run without vmcnt waits and the stores drain behind their MFMAs.
     // MEASURED (profiles/r03_gemm_peel_ab_v2.log, three alternating runs): +1.2 to +2.1 % on the epilogues without a bias
     // (plain dgrad, dGeLU + column sums), 0 +- 0.5 % on the bias epilogues -- there the compiler's own wait for the bias
-    // load (vmcnt(0) in front of the first store) already does the same thing; -1.4 .. +1 % at K = 1024.  ~ +0.5 % of the
-    // step's GEMM time: a build switch, off, until a full-suite run can carry it.
+    // load (vmcnt(0) in front of the first store) already does the same thing; -1.4 .. +1 % at K = 1024.
+    // (Also measured in round 3, removed: issuing the work-queue atomic by hand and reading it after the k-loop -- no
+    //  change, profiles/r03_gemm_async_grab_peel_ab_v1.log.)
     if (!certified) wait_vmcnt<24>();
-#else
-    wait_vmcnt<24>();
-#endif
     __builtin_amdgcn_s_barrier();
-#if defined(COGV_W4_ASYNC_GRAB)
-    // the item after this one: asked for now, used after the k-loop.  Issued by hand and NOT awaited here: atomicAdd()
-    // makes the compiler wait for the returned value on the spot (s_waitcnt vmcnt(0) in wave 0) -- behind the 32 prologue
-    // DMAs and every C store of the previous epilogue, which all retire first (vmcnt is in order) -- and the other three
-    // waves then wait for wave 0 at the first half-step's barrier: the store drain plus an L2 atomic round trip per item,
-    // exposed.  The value is valid after the k-loop's vmcnt(0).
-    // MEASURED (profiles/r03_gemm_async_grab_peel_ab_v1.log): no change on any shape (+-1 %), so that wait is not what an
-    // item pays for; kept as a build switch, off.
-    uint32_t grabbed = 1u;                                 // in: the increment; out (thread 0): the queue position
-    if (threadIdx.x == 0)
-      asm volatile("global_atomic_add %0, %1, %0, %2 sc0" : "+v"(grabbed) : "v"(0u), "s"(ga.sched + xq) : "memory");
-#else
+    W4_TS(0);
     int grabbed = 0;                                       // the item after this one: asked for now, used after the k-loop
     if (threadIdx.x == 0) grabbed = atomicAdd(ga.sched + xq, 1);
-#endif
     static_for<8>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       read1(fA, IC<G_A01>{}, IC<0>{}, IC<(r >> 2)>{}, IC<(r & 3)>{});
       read1(fB0, IC<G_B01>{}, IC<0>{}, IC<(r >> 2)>{}, IC<(r & 3)>{});
     });
     land(fA, AT); land(fB0, BT);
+    W4_TS(1);
 
     // one quarter-step: acc[bh][4 ah + i][j] += A(fa) x B(fb) while granule gin of buffer bin is read into fin and
     // granule gd of k-tile ktd is DMA'd into buffer bd
@@ -1619,7 +1521,6 @@ void gemm_w4_kernel(const GroupArgs ga) {
       quarter(IC<1>{}, IC<0>{}, fI, fb01, fbx, IC<G_B01>{}, IC<(buf ^ 1)>{}, G_A23, t2, buf);
     };
     int kt = 0;
-#if defined(COGV_W4_PEEL)
     // half-steps 0..2 read the prologue's granules (all certified above); half-step 3 reads what half-step 0 issued:
     // its vmcnt(16) is the first wait that also covers the previous item's C stores, >= 2 us of MFMA work after the last one
     if (certified && nk >= 2) {
@@ -1627,55 +1528,39 @@ void gemm_w4_kernel(const GroupArgs ga) {
       tile(1, IC<1>{}, fB1, fB0, IC<0>{}, IC<1>{});
       kt = 2;
     }
-#endif
     for (; kt + 1 < nk; kt += 2) {                         // two k-tiles per trip: the B register sets swap roles
       tile(kt, IC<0>{}, fB0, fB1, IC<1>{}, IC<1>{});
       tile(kt + 1, IC<1>{}, fB1, fB0, IC<1>{}, IC<1>{});
     }
     if (nk & 1) tile(nk - 1, IC<0>{}, fB0, fB1, IC<1>{}, IC<1>{});
     __builtin_amdgcn_sched_barrier(0);
+    W4_TS(2);
     wait_vmcnt<0>();                                        // the (redundant) tail prefetches of this item
-#if defined(COGV_W4_ASYNC_GRAB)
-    asm volatile("" : "+v"(grabbed));                       // ... and the queue position asked for in the pre-step
-#endif
 
     // ---- next item's prologue goes out BEFORE this item's epilogue (the barrier also retires every wave's last reads)
     if (threadIdx.x == 0) s_next = xq + 8 * (int)grabbed;
     __syncthreads();
     const int next = __builtin_amdgcn_readfirstlane(s_next);
+    W4_TS(3);
     const Item done = cur;
     if (next < nitems) { setup(next, cur); prologue(cur); }
-#if defined(COGV_W4_PEEL)
+    W4_TS(4);
     certified = next < nitems;
     const bool land_first = certified;
-#else
-    constexpr bool land_first = false;
-#endif
 
     uint32_t amax_pk = 0u;
     float* strip = reinterpret_cast<float*>(smem + 2 * BREG + wave * 2048);
     constexpr int F_FWD_DROP = COGV_EPI_BIAS | COGV_EPI_DROPOUT | COGV_EPI_ABSMAX, F_FWD_GELU = COGV_EPI_BIAS | COGV_EPI_GELU;
     const int mb = done.m0 + wr * 128, nb = done.n0 + wc * 128, csr = (done.m0 >> 7) + wr;
-#if !defined(COGV_W4_SWAP_EPI)          // default: transposition through the wave's LDS strip
+    // transposition through the wave's LDS strip.  (Round 3 also measured a register-exchange form -- v_permlane16_swap,
+    // no LDS: equal on plain / bias epilogues, +1.5 % GeLU, -2.3 % column sums, profiles/r03_gemm_swap_epilogue_ab.log; removed.)
 #define W4_EPI(F_)                                                                                   \
   do {                                                                                               \
     pp64_epilogue<T, F_>(p, acc[0], strip, mb, nb, done.ksplit, lane, amax_pk, csr, land_first);     \
+    W4_TS(5);                                                                                        \
     pp64_epilogue<T, F_>(p, acc[1], strip, mb, nb + 64, done.ksplit, lane, amax_pk, csr);            \
+    W4_TS(6);                                                                                        \
   } while (0)
-#elif defined(COGV_W4_PEEL)
-#error "COGV_W4_PEEL is written for the strip epilogue"
-#else                                   // -DCOGV_W4_SWAP_EPI: register exchange (v_permlane16_swap), no LDS.  Measured in round 3
-                                        // (profiles/r03_gemm_swap_epilogue_ab.log): equal on plain / bias epilogues, +1.5 % on
-                                        // GeLU + stored gelu', -2.3 % on the column-sum instance (16 per-lane column accumulators
-                                        // instead of 8), all 256 VGPRs in use; instantiating BOTH forms in one kernel made the
-                                        // register allocator spill 816 bytes and cost 30-40 % -- hence a build switch, off.
-#define W4_EPI(F_)                                                                                   \
-  do {                                                                                               \
-    (void)strip;                                                                                     \
-    w4_epilogue_swap<T, F_>(p, acc[0], mb, nb, done.ksplit, lane, amax_pk, csr);                     \
-    w4_epilogue_swap<T, F_>(p, acc[1], mb, nb + 64, done.ksplit, lane, amax_pk, csr);                \
-  } while (0)
-#endif
     if (p.splitk > 1) W4_EPI(-2);
     else if (p.out_f32) W4_EPI(-1);
     else if (p.flags == 0) W4_EPI(0);
@@ -1696,7 +1581,19 @@ void gemm_w4_kernel(const GroupArgs ga) {
       if (lane == 0) atomic_max_nonneg(p.absmax, bits_to_f<T>((uint16_t)wv));
     }
     item = next;
+#if defined(COGV_W4_TS)
+    ts_acc[7] += 1u;
+#endif
   }
+#if defined(COGV_W4_TS)
+  if (lane == 0) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(ga.g[0].C) + ((size_t)blockIdx.x * NW + wave) * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = ts_acc[k];
+    o[8] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - ts_begin);
+    o[9] = (uint32_t)(__builtin_readcyclecounter() - ts_clk0);
+  }
+#endif
   if (threadIdx.x == 0) {
     __threadfence();
     if (atomicAdd(ga.sched + 8, 1) == (int)gridDim.x - 1) {

@@ -80,3 +80,44 @@ def depth_report(module, ids, n_layers, n_heads, report_layers=REPORT_LAYERS):
     return {"logits": rel_l2(logits, ref_logits),
             "stream": {n: rel_l2(mems[n], ref_streams[n]) for n in keep},
             "oracle_seconds": secs, "tokens": int(ids.numel())}
+
+
+def host_mem_available_gb():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+def oracle_loss_and_grads(tokens, labels, loss_mask, params, n_layers, n_heads, eps=1e-5, recompute=None):
+    """fp32 oracle forward + backward of the whole model on one batch (dropout off): -> (loss, {name: gradient}, seconds).
+    `params`: name -> fp32 CPU tensor (storage-rounded weights, oracle_streams() naming); they are not modified.
+    Restates the reference's reverse pass by autograd through the oracle's forward -- mpu/random.py:332-372 (per-layer
+    recompute) and fp16/fp16.py:494-567 only change WHEN tensors are produced, not their values, so with `recompute` each
+    layer is re-run in backward exactly as the reference's --checkpoint-activations does (torch.utils.checkpoint): the
+    48-layer / 2560-wide model then needs ~35 GB of host memory (weights + gradients) instead of ~80 GB.
+    recompute=None: decide from /proc/meminfo (plain autograd when the activations fit with room to spare)."""
+    from torch.utils.checkpoint import checkpoint
+    t0 = time.perf_counter()
+    pr = {n: p.detach().clone().requires_grad_(True) for n, p in params.items()}
+    b, s = tokens.shape
+    if recompute is None:
+        h = pr["transformer.final_layernorm.weight"].numel()
+        act_gb = n_layers * b * s * (60.0 * h + 12.0 * n_heads * s) * 4 / 2 ** 30
+        recompute = host_mem_available_gb() < 3.0 * act_gb + 64.0
+    pos = torch.arange(s).unsqueeze(0).expand(b, -1)
+    mask = O.build_mask(s, s)
+    x = F.embedding(tokens, pr["word_embeddings.weight"]) + F.embedding(pos, pr["transformer.position_embeddings.weight"])
+    for l in range(n_layers):
+        pre = f"transformer.layers.{l}."
+        if recompute:
+            x = checkpoint(lambda t, pre=pre: O.transformer_layer(t, mask, pr, pre, n_heads, eps), x, use_reentrant=False)
+        else:
+            x = O.transformer_layer(x, mask, pr, pre, n_heads, eps)
+    xf = O.sandwich_layernorm(x, pr["transformer.final_layernorm.weight"], pr["transformer.final_layernorm.bias"], eps)
+    loss = O.lm_loss(O.linear(xf, pr["word_embeddings.weight"]), labels, loss_mask)
+    loss.backward()
+    return loss.detach(), {n: p.grad for n, p in pr.items()}, time.perf_counter() - t0

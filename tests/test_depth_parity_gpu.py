@@ -7,7 +7,8 @@ Bars (relative L2 of the logits against the fp32 oracle): fp16 < 1e-3 -- BASELIN
 the depth it is quoted for; bf16 < 8e-3 (8 significant bits: 2^-9 per rounding point).  The residual stream after 1, 2,
 4, 8, 16, 24, 32, 48 layers is compared too and the growth printed: with the stream held in fp32 the error no longer
 accumulates with depth (round 2, 16-bit stream: 5.6e-4 after one layer -> 1.8e-3 after 48 in fp16, 1.4e-2 in bf16).
-cfg 2 also runs the oracle's BACKWARD pass: loss and every parameter gradient of the 24-layer model.
+Both configurations also run the oracle's BACKWARD pass: loss and every parameter gradient through all 24 / 48 layers,
+and cfg 2 split over two model-parallel ranks compares every gradient SHARD with the matching slice of the unsharded gradient.
 Reference: layer loop mpu/sparse_transformer.py:571-613, logits model/gpt2_modeling.py:106-123.
 """
 import os
@@ -56,16 +57,22 @@ def test_logits_and_residual_stream_at_full_depth(cfg, dtype):
     assert rep["stream"][0] < 1e-6          # the embedding sum is exact in the fp32 stream
 
 
+def _row(seed=99):
+    row = torch.randint(0, N_IDS, (1, S + 1), generator=torch.Generator().manual_seed(seed))
+    return row[:, :-1].contiguous(), row[:, 1:].contiguous()
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_gradients_of_the_24_layer_model_vs_oracle(dtype):
-    """cfg 2, full depth: loss and every parameter gradient against the oracle's autograd (fp32, same rounded weights)."""
+@pytest.mark.parametrize("cfg", ["cogview-small-336M", "cogview-base-4B"])
+def test_gradients_at_full_depth_vs_oracle(cfg, dtype):
+    """Loss and EVERY parameter gradient of cfg 2 (24 layers) and of cfg 3/4 -- the 48-layer / 2560-wide model the metric
+    is quoted on -- against the oracle's autograd through all layers (fp32, the same storage-rounded weights, one sequence
+    of 1088 positions, dropout off: parity protocol of SURVEY section 8c).  The reference's backward runs through all 48
+    layers (mpu/random.py:332-372, fp16/fp16.py:494-567): a dgrad wrong by a constant in layer 40 fails here."""
     from cogview_amd import training
-    cfg = "cogview-small-336M"
     model, L, heads = _build(cfg, dtype)
-    model.eval()                                            # dropout off (parity protocol, SURVEY section 8c)
-    g = torch.Generator().manual_seed(99)
-    row = torch.randint(0, N_IDS, (1, S + 1), generator=g)
-    tokens, labels = row[:, :-1], row[:, 1:]
+    model.eval()
+    tokens, labels = _row()
     lmask = torch.ones(1, S)
     pos = torch.arange(S).unsqueeze(0)
     batch = (tokens.cuda(), labels.cuda(), lmask.cuda(), 0, pos.cuda())
@@ -74,24 +81,23 @@ def test_gradients_of_the_24_layer_model_vs_oracle(dtype):
     # below fp16's smallest subnormal.  A power of two, so unscaling is exact.
     scale = 2.0 ** 14 if dtype == torch.float16 else 1.0
     (loss * scale).backward()
-    pr = {n: p.detach().float().cpu().requires_grad_(True) for n, p in model.module.named_parameters()}
-    l_ref = O.lm_loss(O.gpt2_forward(tokens, pos, O.build_mask(S, S), pr, L, heads), labels, lmask)
-    l_ref.backward()
+    l_ref, g_ref, secs = D.oracle_loss_and_grads(tokens, labels, lmask, D.storage_rounded_params(model.module), L, heads)
     assert abs(loss.item() - l_ref.item()) < 2e-3 * abs(l_ref.item()), (loss.item(), l_ref.item())
     worst, worst_n, by_layer = 0.0, "", {}
     for n, p in model.module.named_parameters():
-        e = D.rel_l2(p.grad.float() / scale, pr[n].grad)
+        e = D.rel_l2(p.grad.float() / scale, g_ref[n])
         if n.startswith("transformer.layers."):
             li = int(n.split(".")[2])
             by_layer[li] = max(by_layer.get(li, 0.0), e)
         if e > worst:
             worst, worst_n = e, n
-    print(f"\n[{cfg} {dtype}] loss {loss.item():.5f} (oracle {l_ref.item():.5f}); worst gradient rel-L2 {worst:.2e} ({worst_n}); "
-          "worst per layer: " + " ".join(f"{li}:{by_layer[li]:.1e}" for li in (0, 1, 3, 7, 15, 23)))
+    print(f"\n[{cfg} {dtype}] loss {loss.item():.5f} (oracle {l_ref.item():.5f}, {secs:.0f}s); worst gradient rel-L2 {worst:.2e} "
+          f"({worst_n}); worst per layer: " + " ".join(f"{li}:{by_layer[li]:.1e}" for li in (0, 1, 3, 7, 15, 23, 31, 39, 47) if li in by_layer))
     assert worst < GRAD_TOL[dtype], (worst, worst_n)
 
 
 # ------------------------------------------------------------------------------------------------ cfg 3: model parallel = 2
+GRAD_SCALE = 2.0 ** 14               # fp16: the loss scale of the training step (a power of two, exact to undo)
 MP_VOCAB = 58368                     # 58219 padded to a multiple of 128 x 2 (arguments.py --make-vocab-size-divisible-by)
 
 
@@ -105,7 +111,7 @@ def _perturb_replicated(module, seed=77):
                 p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(seed + k)).to(p.device, p.dtype))
 
 
-def _mp2_worker(rank, world, port, cfg, out_dir, ret):
+def _mp2_worker(rank, world, port, cfg, out_dir, ret, grads=False):
     import sys
     import traceback
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -123,12 +129,23 @@ def _mp2_worker(rank, world, port, cfg, out_dir, ret):
         m = GPT2Model(L, MP_VOCAB, h, heads, 0.1, 0.1, 0.1, S + 1, 0, False)
         _perturb_replicated(m)
         model = FP16_Module(m.cuda(), dtype=torch.float16, keep_half_outputs=True).eval()
-        ids = _ids().cuda()
         pos = torch.arange(S, device="cuda").unsqueeze(0)
-        with torch.no_grad():
-            logits, = model(ids, pos, 0, None, None, 0)
-        assert logits.shape == (1, S, MP_VOCAB // world)
-        torch.save(logits.float().cpu(), os.path.join(out_dir, f"logits_{rank}.pt"))
+        if grads:
+            # loss through the vocab-parallel cross entropy (mpu/cross_entropy.py:25-104) and the whole reverse pass:
+            # dgrad all-reduces of the column-parallel layers, identity backward of the row-parallel ones
+            from cogview_amd import training
+            tokens, labels = _row()
+            batch = (tokens.cuda(), labels.cuda(), torch.ones(1, S, device="cuda"), 0, pos)
+            loss, _, _, _ = training.forward_step(batch, model, log=False)
+            (loss * GRAD_SCALE).backward()
+            torch.save({"loss": loss.item(),
+                        "grads": {n: (p.grad.detach().float() / GRAD_SCALE).cpu() for n, p in model.module.named_parameters()}},
+                       os.path.join(out_dir, f"grads_{rank}.pt"))
+        else:
+            with torch.no_grad():
+                logits, = model(_ids().cuda(), pos, 0, None, None, 0)
+            assert logits.shape == (1, S, MP_VOCAB // world)
+            torch.save(logits.float().cpu(), os.path.join(out_dir, f"logits_{rank}.pt"))
         ret[rank] = "ok"
         dist.barrier()
         dist.destroy_process_group()
@@ -169,3 +186,61 @@ def test_model_parallel_2_logits_at_full_depth(cfg, tmp_path):
     e = D.rel_l2(got, ref)
     print(f"\n[{cfg} fp16, model parallel 2] logits rel-L2 vs the oracle on the unsharded weights {e:.3e} (oracle {secs:.0f}s)")
     assert e < LOGIT_TOL[torch.float16], e
+
+
+def _mp_slice(name, t, rank, world):
+    """The shard of the full tensor `t` model-parallel rank `rank` owns (mpu/layers.py:42-74: column-parallel weights and
+    biases split along dim 0 -- QKV with stride 3 --, row-parallel weights along dim 1, vocabulary rows of the embedding);
+    None: replicated."""
+    if name.endswith("word_embeddings.weight") or "dense_h_to_4h" in name:
+        return t.chunk(world, 0)[rank]
+    if "query_key_value" in name:
+        slabs = t.chunk(3 * world, 0)
+        return torch.cat([slabs[rank], slabs[rank + world], slabs[rank + 2 * world]], 0)
+    if name.endswith("attention.dense.weight") or name.endswith("dense_4h_to_h.weight"):
+        return t.chunk(world, 1)[rank]
+    return None
+
+
+def test_model_parallel_2_gradients_at_full_depth(tmp_path):
+    """cfg 2 (24 layers / 1024 hidden) split over TWO model-parallel ranks, fp16: loss and every gradient SHARD of both
+    ranks against the matching slice of the oracle's gradient on the UNSHARDED weights (autograd through all layers);
+    replicated parameters (LayerNorms, row-parallel biases, position table) against the whole tensor on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    cfg = "cogview-small-336M"
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_mp2_worker, args=(r, 2, port, cfg, str(tmp_path), ret, True)) for r in range(2)]
+        for p in procs:
+            p.start()
+        from cogview_amd.model import GPT2Model
+        L, h, heads = CFG[cfg]
+        torch.manual_seed(1234)
+        full = GPT2Model(L, MP_VOCAB, h, heads, 0.1, 0.1, 0.1, S + 1, 0, False)
+        _perturb_replicated(full)
+        params = {n: p.detach().to(torch.float16).float() for n, p in full.named_parameters()}
+        del full
+        tokens, labels = _row()
+        l_ref, g_ref, secs = D.oracle_loss_and_grads(tokens, labels, torch.ones(1, S), params, L, heads)
+        for p in procs:
+            p.join(900)
+        for r in range(2):
+            assert ret.get(r) == "ok", f"rank {r}: {ret.get(r)}"
+    worst, worst_n = 0.0, ""
+    for r in range(2):
+        got = torch.load(os.path.join(str(tmp_path), f"grads_{r}.pt"))
+        assert abs(got["loss"] - l_ref.item()) < 2e-3 * abs(l_ref.item()), (r, got["loss"], l_ref.item())
+        assert set(got["grads"]) == set(g_ref)
+        for n, g in got["grads"].items():
+            want = _mp_slice(n, g_ref[n], r, 2)
+            want = g_ref[n] if want is None else want
+            assert g.shape == want.shape, (n, g.shape, want.shape)
+            e = D.rel_l2(g, want)
+            if e > worst:
+                worst, worst_n = e, f"{n} (rank {r})"
+    print(f"\n[{cfg} fp16, model parallel 2] loss {got['loss']:.5f} (oracle {l_ref.item():.5f}, {secs:.0f}s); worst gradient-shard "
+          f"rel-L2 vs the slice of the unsharded oracle gradient {worst:.2e} ({worst_n})")
+    assert worst < GRAD_TOL[torch.float16], (worst, worst_n)
