@@ -53,6 +53,7 @@ class AttnDesc(C.Structure):
         ("colsum_partial", C.c_void_p),
         ("kv_index", C.c_void_p), ("kv_index_bs", C.c_longlong),
         ("kv_index_gs", C.c_longlong), ("sparse_window", C.c_int), ("sparse_pivots", C.c_int), ("sparse_pivot_bias", C.c_float),
+        ("keep_bits", C.c_void_p),
     ]
 
 
@@ -127,6 +128,7 @@ SIGNATURES = {
     "cogv_gemv_attn": (_i, [C.POINTER(GemmDesc), _vp, _i, _i, _vp]),
     "cogv_attention_decode": (_i, [C.POINTER(AttnDecodeDesc), _vp]),
     "cogv_attention_decode_workspace_bytes": (_sz, [_i, _i, _i]),
+    "cogv_attention_keep_bits_bytes": (_sz, [_i, _i, _i, _i]),
     "cogv_sparse_slot_reduce": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cogv_embedding_fwd": (_i, [_i, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _f, _u64, _u64, _i, _vp]),
     "cogv_embedding_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _i, _f, _u64, _u64, _vp, _sz, _i, _vp]),

@@ -43,6 +43,11 @@ struct AttnArgs {
   const void* dout; void* dq; void* dk; void* dv;              // backward
   float* lse; float* dvec;                                     // [b][H][s_q]; dvec: [2][b][H][s_q] (D, dropout row keys)
   float* colsum_ws;                                            // optional [B * nblk][3 * H * 64]: sums of dq | dk | dv
+  // optional (dense kernels, DROP == 2): the dropout keep bits of the forward pass, one 32-bit word per (query, 64-key block,
+  // key half fg): word [(b * H + head)][kb][fg][q], bit 31 - n <-> key 64 kb + 32 (n >> 4) + 8 ((n & 15) >> 2) + 4 fg + (n & 3).
+  // The forward kernel writes them (its lane = query layout holds exactly these 32 keys per lane and block), the backward
+  // kernels read them instead of regenerating the draws (4 to 4.5 of ~14.5 VALU slots per score element in each of them).
+  uint32_t* keepbits;
   const int* kv_index; long long kv_index_bs;                  // optional: key slot j reads K/V row kv_index[b][j] & 0x7fffffff
   // sparse TRAINING form in slot space (sp_w > 0): one index row per query block g = q / sp_w (kv_index_gs apart);
   // bit 31 of an entry = slot masked (-10000); the first sp_npiv slots are pivots and take sp_bias (added to the
@@ -279,7 +284,8 @@ __device__ __forceinline__ void tile_colsum(const float (&vals)[2][16], float* l
 // =====================================================================================================
 // forward: grid (ceil(s_q/128), H, B); wave w owns queries q0 + 32w .. +31.  Ring stage = K tile | V tile.
 // =====================================================================================================
-template <typename T, bool IDX, int DROP>       // DROP: 1 / 0 = dropout on / off at compile time, -1 = decided by p.thr16
+template <typename T, bool IDX, int DROP>       // DROP: 1 / 0 = dropout on / off at compile time, -1 = decided by p.thr16,
+                                                //       2 = on, and the keep bits are stored in p.keepbits for the backward pass
 __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   const bool drop = DROP < 0 ? (p.thr16 != 0u) : (DROP != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 stages x 16 KiB
@@ -424,15 +430,25 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
         for (int e = 0; e < 16; ++e) { const float pv = fast_exp2(fmaf(sacc[sb][e], sl2, kofs - m_run)); sacc[sb][e] = pv; ls += pv; }
       l_run += ls;
       if (drop) {
+        uint32_t kw = 0u;                          // DROP == 2: the 32 keep bits of this lane's keys, first element in bit 31
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
             const u32x2 r = attn_bits_at(cb, (uint32_t)((kb * 64 + sb * 32 + 8 * gq + 4 * fg) >> 2));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              sacc[sb][4 * gq + i] = keep_of(r, i, p.thr16) ? sacc[sb][4 * gq + i] : 0.f;
+            for (int i = 0; i < 4; ++i) {
+              const bool kp = keep_of(r, i, p.thr16);
+              sacc[sb][4 * gq + i] = kp ? sacc[sb][4 * gq + i] : 0.f;
+              if (DROP == 2) {       // kw = 2 kw + keep as ONE v_addc_co_u32: the compare's lane mask is the carry-in (left to
+                                     // itself the compiler builds the word with two selects, an or and a shift per pair)
+                unsigned long long cm = __ballot(kp);
+                asm("v_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(kw), "+s"(cm));
+              }
+            }
           }
+        if (DROP == 2 && myq < p.s_q)
+          p.keepbits[((((long long)b * p.H + head) * ((p.s_k + 63) >> 6) + kb) * 2 + fg) * p.s_q + myq] = kw;
       }
       // O^T[d][query] += V^T[d][key] . P^T[key][query]
       TrRaw vr2[2][2];
@@ -482,11 +498,15 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
 // dQ: grid (ceil(s_q/128), H, B); lane = query.   dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q]
 // Ring stage = K tile | V tile (K serves both S^T (natural read) and dQ^T (transposing read)).
 // =====================================================================================================
+// DROP == 2: the keep bits come from p.keepbits (written by the forward kernel): every wave DMAs the 64 words of its 32
+// queries x 2 key halves for the stage's key block into 256 bytes behind the stage's tiles (one more LDS-DMA per stage and wave,
+// certified by the same counted wait) and each lane reads its own word back.
 template <typename T, bool IDX, int DROP>
 __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const bool drop = DROP < 0 ? (p.thr16 != 0u) : (DROP != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = 2 * TILE, LPT = 4;
+  constexpr bool KB = DROP == 2;
+  constexpr int STAGE = 2 * TILE + (KB ? 1024 : 0), LPT = KB ? 5 : 4;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 31, fg = lane >> 5;
@@ -531,8 +551,8 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     if (qvalid && fg == 0) {
       p.dvec[arow] = dv;
       // second plane of the workspace: the row's dropout key, so the dK/dV kernel (lane = key, 16 query rows per lane)
-      // reads it instead of re-hashing the row for every draw
-      reinterpret_cast<uint32_t*>(p.dvec)[(long long)p.B * p.H * p.s_q + arow] = cb.rk;
+      // reads it instead of re-hashing the row for every draw (not needed when the keep bits are stored)
+      if (!KB) reinterpret_cast<uint32_t*>(p.dvec)[(long long)p.B * p.H * p.s_q + arow] = cb.rk;
     }
   }
   const float sl2 = p.scale * 1.4426950408889634f;
@@ -560,9 +580,13 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     __syncthreads();
   }
   const float sp_bias_raw = spw ? p.sp_bias / p.scale : 0.f;
+  const uint32_t* KWQ = KB ? p.keepbits + ((long long)b * p.H + head) * ((p.s_k + 63) >> 6) * 2 * p.s_q + (long long)fg * p.s_q + min(myq, p.s_q - 1)
+                           : nullptr;
   auto issue = [&](int kb, int st) {
     dma_tile<T>(K, p.k_rs, kb * 64, p.s_k, smem + st * STAGE, wave, lane, lidx);
     dma_tile<T>(V, p.v_rs, kb * 64, p.s_k, smem + st * STAGE + TILE, wave, lane, lidx);
+    if (KB) __builtin_amdgcn_global_load_lds((gbl_void_t*)(KWQ + (long long)kb * 2 * p.s_q),
+                                             (lds_void_t*)(smem + st * STAGE + 2 * TILE + wave * 256), 4, 0, 0);
   };
   if (nkb > 0) { issue(0, 0); issue(nkb > 1 ? 1 : 0, 1); }
   int st = 0;
@@ -573,6 +597,11 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     if (kb * 64 < kend_w) {
       const char* lk = smem + st * STAGE; const char* lv = lk + TILE;
       const uint32_t lkt = smem_addr + st * STAGE;
+      uint32_t kwv = 0u;                                    // this lane's 32 keep bits of the block (forward's order)
+      if (KB) {
+        const uint32_t ka = lkt + 2 * TILE + wave * 256 + lane * 4;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(kwv) : "v"(ka) : "memory");
+      }
       unsigned long long mflag = 0ull, mpiv = 0ull;         // slot attributes of this block (sparse training form)
       if (spw) {
         int raw;
@@ -613,13 +642,19 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           u32x2 r = {0u, 0u};
-          if (drop) r = attn_bits_at(cb, (uint32_t)((kfirst + 8 * gq + 4 * fg) >> 2));
+          if (drop && !KB) r = attn_bits_at(cb, (uint32_t)((kfirst + 8 * gq + 4 * fg) >> 2));
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int e = 4 * gq + i;
             const float pr = fast_exp2(fmaf(sacc[e], sl2, -lse2));
             float dp = pacc[e];
-            if (drop) dp = keep_of(r, i, p.thr16) ? dp : 0.f;
+            if (KB) {         // keep bit sign-extended over the float's bit pattern: v_bfe_i32 + v_and (through asm: with a
+                              // constant position the compiler prefers and + compare + select, three instructions and a VCC chain)
+              uint32_t sx;
+              asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sx) : "v"(kwv), "n"(31 - (sb * 16 + e)));
+              dp = __uint_as_float(sx & __float_as_uint(dp));
+            }
+            else if (drop) dp = keep_of(r, i, p.thr16) ? dp : 0.f;
             ds[e] = pr * fmaf(dp, kscale, -dv);                  // kscale = 1 / (1 - p) (1 without dropout)
           }
         }
@@ -666,11 +701,16 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 // Ring stage = Q tile | dO tile | LSE[64] | D[64]  (64 queries per stage; Q and dO each serve a natural and a
 // transposing read).
 // =====================================================================================================
+// DROP == 2: keep bits from p.keepbits.  The workgroup's 128 keys are two 64-key blocks x two key halves = four segments of
+// 64 words (one per query of the stage); wave w DMAs segment w in place of the row-key statistics row (same count of
+// DMAs per stage), and a lane (= key) picks ITS bit out of the word of each of its 16 queries: four ds_read_b128 +
+// 16 x (v_bfe_i32, v_and) per 32 x 32 tile where the regenerating form hashes four draws and shares them through DPP.
 template <typename T, bool IDX, int DROP>
 __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) {
   const bool drop = DROP < 0 ? (p.thr16 != 0u) : (DROP != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = 2 * TILE + 768, LPT = 7;
+  constexpr bool KB = DROP == 2;
+  constexpr int STAGE = 2 * TILE + (KB ? 512 + 1024 : 768), LPT = 7;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 31, fg = lane >> 5;
@@ -729,14 +769,24 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   const uint32_t loff[2] = {tr_lane_off(0, lane) ^ tr_lane_fix(lane), tr_lane_off(1, lane) ^ tr_lane_fix(lane)};
   const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
 
+  // keep-bit segment of this wave: key block k0 / 64 + (wave >> 1), key half wave & 1 (clamped: words of key blocks past
+  // the end are never used)
+  const int nkbt = (p.s_k + 63) >> 6;
+  const uint32_t* KWS = KB ? p.keepbits + ((((long long)b * p.H + head) * nkbt + min((k0 >> 6) + (wave >> 1), nkbt - 1)) * 2 + (wave & 1)) * p.s_q
+                           : nullptr;
   auto issue = [&](int qb, int st) {
     char* base = smem + st * STAGE;
     dma_tile<T>(Q, p.q_rs, qb * 64, p.s_q, base, wave, lane);
     dma_tile<T>(DO, p.do_rs, qb * 64, p.s_q, base + TILE, wave, lane);
     dma_stat(LSE, qb * 64, p.s_q, base + 2 * TILE, lane);
     dma_stat(DV, qb * 64, p.s_q, base + 2 * TILE + 256, lane);
-    dma_stat(RK, qb * 64, p.s_q, base + 2 * TILE + 512, lane);
+    if (KB) dma_stat(reinterpret_cast<const float*>(KWS), qb * 64, p.s_q, base + 2 * TILE + 512 + wave * 256, lane);
+    else dma_stat(RK, qb * 64, p.s_q, base + 2 * TILE + 512, lane);
   };
+  // the lane's key inside its 64-key block: half (wave & 1 -- the wave's 32 keys), key half fg' = bit 2, element 4 (r >> 3) + (r & 3)
+  const int kr = mykey & 31;
+  const uint32_t kw_seg = (uint32_t)(((wave >> 1) * 2 + ((kr >> 2) & 1)) * 64);               // word offset of the lane's segment
+  const uint32_t kw_bit = 31u - (uint32_t)((wave & 1) * 16 + 4 * (kr >> 3) + (kr & 3));
   if (qb0 < nqb) { issue(qb0, 0); issue(min(qb0 + 1, nqb - 1), 1); }
   int st = 0;
   for (int qb = qb0; qb < nqb; ++qb) {
@@ -782,7 +832,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
           for (int e = 0; e < 16; ++e) sacc[e] = (kflag ? masked_raw : sacc[e]) + sp_add;
         }
         uint32_t kmask[4] = {0u, 0u, 0u, 0u};
-        if (drop) {
+        if (drop && !KB) {
           const int c = lane & 3;
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
@@ -804,7 +854,10 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + ql);
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + 64 + ql);
           uint32_t km[4];
-          if (drop) {                                           // quad_perm(i,i,i,i): value held by quad lane i
+          if (KB) {                                             // the words of the 4 queries of this group: one b128 read
+            const u32x4 w4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(stat) + 128 + kw_seg + ql);
+            km[0] = w4[0]; km[1] = w4[1]; km[2] = w4[2]; km[3] = w4[3];
+          } else if (drop) {                                    // quad_perm(i,i,i,i): value held by quad lane i
             km[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)kmask[gq], 0x00, 0xf, 0xf, true);
             km[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)kmask[gq], 0x55, 0xf, 0xf, true);
             km[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)kmask[gq], 0xaa, 0xf, 0xf, true);
@@ -818,7 +871,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
             // multiplier 1/(1-p) or 0 by sign-extending it over the float's bit pattern (v_bfe_i32 + v_and): two
             // instructions where compare + two selects (on Pd and dS) took five
             float keepf = kscale;
-            if (drop) keepf = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)km[i], (uint32_t)kbit, 1u) & __float_as_uint(kscale));
+            if (drop) keepf = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)km[i], KB ? kw_bit : (uint32_t)kbit, 1u) & __float_as_uint(kscale));
             pd[e] = pr * keepf;
             ds[e] = fmaf(pd[e], pacc[e], -(pr * d4[i]));
           }
@@ -1040,6 +1093,7 @@ int fill_args(const cogv_attn_desc* d, AttnArgs& a) {
   if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return COGV_ERR_ARG;
   a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o; a.dout = d->dout; a.dq = d->dq; a.dk = d->dk; a.dv = d->dv;
   a.lse = d->lse; a.dvec = d->dvec; a.colsum_ws = nullptr; a.kv_index = nullptr; a.kv_index_bs = 0;
+  a.keepbits = nullptr;
   a.kv_index_gs = 0; a.sp_w = 0; a.sp_npiv = 0; a.sp_bias = 0.f;
   a.q_bs = d->q_bs; a.k_bs = d->k_bs; a.v_bs = d->v_bs; a.o_bs = d->o_bs; a.do_bs = d->do_bs;
   a.dq_bs = d->dq_bs; a.dk_bs = d->dk_bs; a.dv_bs = d->dv_bs;
@@ -1095,6 +1149,13 @@ extern "C" int cogv_attention_fwd(const cogv_attn_desc* d, void* stream) {
   // dense kernels: dropout on / off are separate instantiations (no wave-uniform branches and register copies at their
   // joins inside the softmax); the gathered / sparse forms decide at run time
   const bool drop = a.thr16 != 0u;
+  if (d->keep_bits && drop && !a.kv_index) {      // dense, dropout on, the caller keeps the bits for the backward pass
+    if ((uintptr_t)d->keep_bits & 3) return COGV_ERR_ARG;
+    a.keepbits = reinterpret_cast<uint32_t*>(d->keep_bits);
+    if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t, false, 2>), grid, dim3(NT), sh, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, false, 2>), grid, dim3(NT), sh, st, a);
+    return cogv_check_launch();
+  }
   if (a.kv_index) {
     if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t, true, -1>), grid, dim3(NT), sh, st, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, true, -1>), grid, dim3(NT), sh, st, a);
@@ -1140,6 +1201,8 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
     set_smem(&attn_bwd_dkdv_kernel<f16_t, true, -1>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t, true, -1>, sh_k);
     set_smem(&attn_bwd_dq_kernel<f16_t, false, 0>, 3 * 2 * TILE); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 0>, 3 * 2 * TILE);
     set_smem(&attn_bwd_dq_kernel<f16_t, false, 1>, 3 * 2 * TILE); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 1>, 3 * 2 * TILE);
+    set_smem(&attn_bwd_dq_kernel<f16_t, false, 2>, 3 * (2 * TILE + 1024)); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 2>, 3 * (2 * TILE + 1024));
+    set_smem(&attn_bwd_dkdv_kernel<f16_t, false, 2>, 3 * (2 * TILE + 1536)); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false, 2>, 3 * (2 * TILE + 1536));
     attr = true;
   }
   if (a.kv_index && sh_q > attr_q) {
@@ -1147,6 +1210,19 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
     attr_q = sh_q;
   }
   const bool drop = a.thr16 != 0u;
+  if (d->keep_bits && drop && !a.kv_index) {      // the keep bits the forward call stored (same dropout_p / seed / stream)
+    if ((uintptr_t)d->keep_bits & 3) return COGV_ERR_ARG;
+    a.keepbits = reinterpret_cast<uint32_t*>(d->keep_bits);
+    const int shq2 = 3 * (2 * TILE + 1024), shk2 = 3 * (2 * TILE + 1536);
+    if (d->dtype == COGV_F16) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, false, 2>), gq, dim3(NT), shq2, st, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t, false, 2>), gk, dim3(NT), shk2, st, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, false, 2>), gq, dim3(NT), shq2, st, a);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t, false, 2>), gk, dim3(NT), shk2, st, a);
+    }
+    return cogv_check_launch();
+  }
 #define ATTN_BWD_LAUNCH(T_, IDX_, DROP_)                                                             \
   do {                                                                                               \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T_, IDX_, DROP_>), gq, dim3(NT), sh_q, st, a);            \
@@ -1161,6 +1237,11 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   }
 #undef ATTN_BWD_LAUNCH
   return cogv_check_launch();
+}
+
+extern "C" size_t cogv_attention_keep_bits_bytes(int B, int H, int s_q, int s_k) {
+  if (B <= 0 || H <= 0 || s_q <= 0 || s_k <= 0) return 0;
+  return (size_t)B * H * ((size_t)(s_k + 63) / 64) * 2 * (size_t)s_q * sizeof(uint32_t);
 }
 
 extern "C" size_t cogv_attention_decode_workspace_bytes(int B, int H, int capacity) {

@@ -150,16 +150,17 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, sep, dropout):
-        o, lse = ops.attention_fwd(q, k, v, sep=sep, dropout=dropout)
+        o, lse, bits = ops.attention_fwd(q, k, v, sep=sep, dropout=dropout, keep_bits=True)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.sep, ctx.dropout = sep, dropout
+        ctx.sep, ctx.dropout, ctx.keep_bits = sep, dropout, bits
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
         doc = do if do.is_contiguous() else do.contiguous()
-        dq, dk, dv = ops.attention_bwd(doc, q, k, v, o, lse, sep=ctx.sep, dropout=ctx.dropout)
+        dq, dk, dv = ops.attention_bwd(doc, q, k, v, o, lse, sep=ctx.sep, dropout=ctx.dropout, keep_bits=ctx.keep_bits)
+        ctx.keep_bits = None
         return dq, dk, dv, None, None
 
 
@@ -483,8 +484,11 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
     q = qkv[:, :, 0:hp].view(b, s, npp, 64)
     k = qkv[:, :, hp:2 * hp].view(b, s, npp, 64)
     v = qkv[:, :, 2 * hp:].view(b, s, npp, 64)
+    kbits = None
     if kv_slot is None:
-        att, lse = ops.attention_fwd(q, k, v, sep=sep, dropout=d_attn)
+        # keep is not None: a backward pass will follow -- the forward kernel stores its dropout keep bits for it
+        res = ops.attention_fwd(q, k, v, sep=sep, dropout=d_attn, keep_bits=keep is not None)
+        att, lse, kbits = res[0], res[1], (res[2] if len(res) > 2 else None)
     elif s == 1 and getattr(kv_slot, "pos_index", None) is not None:
         # captured decode step (StaticKVSlot): keys split over workgroups, cache append fused, length read on the device
         att, lse = ops.attention_decode(qkv, kv_slot.cache, kv_slot.pos_index, npp).view(b, 1, npp, 64), None
@@ -533,7 +537,7 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
         keep.x, keep.a, keep.qkv, keep.att, keep.lse, keep.ao, keep.y, keep.c = x, a, qkv, att, lse, ao, y, c
         keep.u, keep.g, keep.mo = u, g, mo
         keep.st1, keep.st2, keep.st3, keep.st4 = (m1, r1), (m2, r2), (m3, r3), (m4, r4)
-        keep.d_attn, keep.d_ao, keep.d_mo = d_attn, d_ao, d_mo
+        keep.d_attn, keep.d_ao, keep.d_mo, keep.kbits = d_attn, d_ao, d_mo, kbits
     return out, slot_out
 
 
@@ -588,7 +592,8 @@ def _layer_backward(layer, kp, dout, sep):
     dqkv = torch.empty_like(qkv)
     ops.attention_bwd(d_att, q, k, v, kp.att, kp.lse, sep=sep, dropout=kp.d_attn,
                       dq=dqkv[:, :, 0:hp].view(b, s, npp, 64), dk=dqkv[:, :, hp:2 * hp].view(b, s, npp, 64),
-                      dv=dqkv[:, :, 2 * hp:].view(b, s, npp, 64), colsum_out=G(bq), colsum_accumulate=grad_accumulate(bq))
+                      dv=dqkv[:, :, 2 * hp:].view(b, s, npp, 64), colsum_out=G(bq), colsum_accumulate=grad_accumulate(bq),
+                      keep_bits=getattr(kp, "kbits", None))
     dqkv2 = dqkv.view(rows, 3 * hp)
     da = ops.gemm(dqkv2, Wq, trans_b=True)
     wgrads.append((dqkv2, kp.a.view(rows, h), Wq))

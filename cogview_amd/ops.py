@@ -4,6 +4,7 @@ torch is used for device memory, streams and shapes only; every FLOP / byte of t
 libcogview_hip.so.  All functions require CUDA(HIP) tensors and raise otherwise -- there is no CPU path.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -458,8 +459,14 @@ def _attn_desc(q, k, v, o, sep, dropout):
     return d
 
 
-def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None):
+STORE_KEEP_BITS = os.environ.get("COGV_ATTN_KEEP_BITS", "1") != "0"       # A/B switch of the stored dropout keep bits
+
+
+def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None, keep_bits=False):
     """q [b,s_q,H,64], k/v [b,s_k,H,64] (strided views are fine).  Returns (o [b,s_q,H,64] contiguous, lse).
+    keep_bits=True (dense form with dropout; the caller will run attention_bwd): returns (o, lse, bits) -- the forward
+    kernel stores its dropout keep decisions (1 bit per score, uint8 buffer of cogv_attention_keep_bits_bytes) and
+    attention_bwd(keep_bits=bits) reads them instead of regenerating the draws; bits is None where that does not apply.
     kv_index [b, n] int32 (forward only): key slot j is row kv_index[b, j] of k / v -- the gathered form of
     sparse_attention_inference; the left-to-right rule then applies to slots (the last s_q slots are the queries)."""
     _need_gpu(q, k, v)
@@ -475,8 +482,12 @@ def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None):
     elif sparse is not None:
         _sparse_desc(d, kv_index, sparse, b, s_q)
     d.lse = lse.data_ptr()
+    bits = None
+    if keep_bits and STORE_KEEP_BITS and dropout is not None and dropout[0] > 0.0 and kv_index is None and sparse is None:
+        bits = torch.empty(L.lib().cogv_attention_keep_bits_bytes(b, H, s_q, k.shape[1]), dtype=torch.uint8, device=q.device)
+        d.keep_bits = bits.data_ptr()
     L.check(L.lib().cogv_attention_fwd(C.byref(d), _stream()), "cogv_attention_fwd")
-    return o, lse
+    return (o, lse, bits) if keep_bits else (o, lse)
 
 
 _DECODE_WS = {}
@@ -581,7 +592,7 @@ def sparse_attention_bwd(dout, q, k, v, o, lse, kv_index, sparse, pivot_inv, tim
 
 
 def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, dv=None, colsum_out=None,
-                  colsum_accumulate=True):
+                  colsum_accumulate=True, keep_bits=None):
     """colsum_out [3*H*64]: (+)= column sums of (dq | dk | dv) over all tokens -- the bias gradient of the fused
     QKV projection -- taken from the kernels' accumulators instead of re-reading the three outputs."""
     _need_gpu(dout, q, k, v, o)
@@ -595,6 +606,9 @@ def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, 
     dvec = torch.empty((2, b, H, s_q), dtype=torch.float32, device=q.device)
     d = _attn_desc(q, k, v, o, sep, dropout)
     d.lse, d.dvec = lse.data_ptr(), dvec.data_ptr()
+    if keep_bits is not None:
+        assert keep_bits.numel() == L.lib().cogv_attention_keep_bits_bytes(b, H, s_q, k.shape[1])
+        d.keep_bits = keep_bits.data_ptr()
     d.dout, d.dq, d.dk, d.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     d.do_bs, d.do_rs = _attn_strides(dout)
     d.dq_bs, d.dq_rs = _attn_strides(dq)

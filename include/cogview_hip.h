@@ -184,9 +184,16 @@ typedef struct cogv_attn_desc {
    * invisible pivot, front padding): score -10000.  Pivot slots add sparse_pivot_bias = log(s // n_pivots) to the
    * scaled score; the left-to-right rule applies to the last sparse_window slots. */
   long long kv_index_gs; int sparse_window, sparse_pivots; float sparse_pivot_bias;
+  /* optional (dense form, dropout_p > 0): cogv_attention_keep_bits_bytes(B, H, s_q, s_k) bytes, 4-byte aligned.  The forward
+   * call WRITES the keep decisions of its attention dropout there (1 bit per score the kernel evaluated: the reference's
+   * dropout mask at mpu/sparse_transformer.py:667-669, which autograd keeps for the backward pass); the backward call given
+   * the same buffer READS them instead of regenerating the draws.  Results are bit-identical with and without it.  NULL:
+   * backward regenerates (also for the gathered / sparse forms, which ignore the field). */
+  void* keep_bits;
 } cogv_attn_desc;
 int cogv_attention_fwd(const cogv_attn_desc* d, void* stream);
 int cogv_attention_bwd(const cogv_attn_desc* d, void* stream);
+size_t cogv_attention_keep_bits_bytes(int B, int H, int s_q, int s_k);
 /* Decode step (generation/sampling.py:139-148: one model call per generated token; mems mpu/sparse_transformer.py:526-546):
  * ONE query token per batch row against a fixed-capacity key/value cache.  qkv: the QKV projection of the new token,
  * [B][3 * H * 64] = q | k | v (qkv_bs elements between batch rows); cache: [B][capacity][2 * H * 64] keys | values

@@ -5,9 +5,10 @@ oracle/gen_golden_cfg1.py).  No dimension is a multiple of 8 / 64 / 256: ragged 
 cross-entropy row tails.  The weights are not in the fixture: the mirror's constructors draw them under seed 1234 and
 tests/test_oracle_golden.py::test_cfg1_init_is_bit_identical_to_the_reference pins them to the reference's, bit for bit.
 
-Tolerances (relative to the fp32 reference): loss 2e-3 (fp16) / 5e-3 (bf16); logits rows rel-L2 1e-3 / 8e-3 (the weights
-are rounded to 16 bits here and are not in the reference run -- measured 4e-4 / 3e-3); per-tensor gradient norm 1e-2 /
-4e-2; gradient tensors rel-L2 1e-2 / 6e-2; global gradient norm 5e-3 / 2e-2.
+Tolerances (relative to the reference's fp32 run on UNROUNDED weights -- here they are rounded to 16 bits, which is most of
+the error): loss 2e-3 (fp16) / 5e-3 (bf16); whole-tensor |logits| 1e-3 / 8e-3 (measured 4e-7 / 2e-6); the worst single logits
+ROW rel-L2 1.5e-3 / 1.2e-2 (measured 9.5e-4 / 7.4e-3); per-tensor gradient norm 2e-3 / 1e-2 (2.0e-4 / 3.1e-3); gradient tensors
+rel-L2 3e-3 / 2e-2 (1.0e-3 / 8.2e-3); global gradient norm 1e-3 / 3e-3 (9e-5 / 7.4e-4).
 """
 import os
 
@@ -19,9 +20,10 @@ pytestmark = pytest.mark.gpu
 
 LOSS_TOL = {torch.float16: 2e-3, torch.bfloat16: 5e-3}
 LOGIT_TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
-NORM_TOL = {torch.float16: 1e-2, torch.bfloat16: 4e-2}
-GRAD_TOL = {torch.float16: 1e-2, torch.bfloat16: 6e-2}
-GNORM_TOL = {torch.float16: 5e-3, torch.bfloat16: 2e-2}
+ROW_TOL = {torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}
+NORM_TOL = {torch.float16: 2e-3, torch.bfloat16: 1e-2}
+GRAD_TOL = {torch.float16: 3e-3, torch.bfloat16: 2e-2}
+GNORM_TOL = {torch.float16: 1e-3, torch.bfloat16: 3e-3}
 
 
 def rel(a, b):
@@ -71,7 +73,7 @@ def test_cfg1_forward_backward_vs_the_reference_run(golden_dir, dtype):
           f"|logits| {e_norm:.1e}; per-tensor grad norms worst {worst_n:.2e} ({worst_name}); grad tensors {worst_g:.2e}; "
           f"global norm {gnorm:.5f} vs {float(z['grad_norm']):.5f} ({e_gn:.1e})")
     assert abs(loss.item() - float(z["loss"])) < LOSS_TOL[dtype] * float(z["loss"])
-    assert worst_row < LOGIT_TOL[dtype] and e_norm < LOGIT_TOL[dtype]
+    assert worst_row < ROW_TOL[dtype] and e_norm < LOGIT_TOL[dtype]
     assert worst_n < NORM_TOL[dtype], (worst_n, worst_name)
     assert worst_g < GRAD_TOL[dtype]
     assert e_gn < GNORM_TOL[dtype]

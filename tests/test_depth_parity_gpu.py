@@ -25,7 +25,8 @@ CFG = {"cogview-small-336M": (24, 1024, 16), "cogview-base-4B": (48, 2560, 40)}
 VOCAB, N_IDS, S = 58240, 58219, 1088
 LOGIT_TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
 STREAM_TOL = {torch.float16: 8e-4, torch.bfloat16: 6e-3}
-GRAD_TOL = {torch.float16: 1e-2, torch.bfloat16: 6e-2}
+GRAD_TOL = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}      # <= 2x the measured worst tensor (round 4: 9.7e-4 / 7.7e-3 at 48 layers,
+                                                                 # 1.1e-3 for the model-parallel shards)
 
 
 def _build(cfg, dtype):

@@ -369,6 +369,41 @@ def test_attention_dropout_at_the_bench_length_vs_oracle(ops, dtype, b, H, s_q, 
         assert worst < TOL[dtype] * 4, (name, worst)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("b,H,s_q,s_k,sep", [(2, 3, 1088, 1088, 0), (1, 2, 320, 1088, 70), (3, 2, 255, 255, 0), (1, 1, 96, 160, 0)])
+def test_attention_stored_keep_bits_equal_the_regenerated_mask(ops, dtype, b, H, s_q, s_k, sep):
+    """The forward kernel stores its dropout keep decisions (cogv_attn_desc.keep_bits: the reference keeps the dropout mask
+    of mpu/sparse_transformer.py:667-669 for autograd) and the backward kernels read them instead of regenerating the
+    draws.  The stored form must reproduce the regenerating form BIT FOR BIT -- forward output and dQ / dK / dV -- at the
+    bench length (17 key blocks), a `sep` + memory shape, the ragged cfg 1 length (255) and a short memory shape; the
+    regenerating form itself is pinned to the oracle's mask by the two tests above.  The bit buffer starts as 0xFF / 0x00
+    garbage: words the forward pass does not write (blocks above the diagonal) must not matter."""
+    g = torch.Generator().manual_seed(3 * s_q + s_k)
+    qkv = dev(rnd((b, s_k, 3 * H * 64), dtype, g))
+    q = qkv[:, s_k - s_q:, 0:H * 64].view(b, s_q, H, 64)
+    k = qkv[:, :, H * 64:2 * H * 64].view(b, s_k, H, 64)
+    v = qkv[:, :, 2 * H * 64:].view(b, s_k, H, 64)
+    dout = dev(rnd((b, s_q, H, 64), dtype, g))
+    drop = (0.1, 77, 5)
+    o0, lse0 = ops.attention_fwd(q, k, v, sep=sep, dropout=drop)
+    ref = ops.attention_bwd(dout, q, k, v, o0, lse0, sep=sep, dropout=drop)
+    for fill in (0xFF, 0x00):
+        torch.cuda.synchronize()
+        junk = torch.full((512 << 20,), fill, dtype=torch.uint8, device="cuda")      # the allocator hands this memory back below
+        del junk
+        o1, lse1, bits = ops.attention_fwd(q, k, v, sep=sep, dropout=drop, keep_bits=True)
+        assert bits is not None and bits.dtype == torch.uint8
+        assert torch.equal(o1, o0) and torch.equal(lse1, lse0)
+        got = ops.attention_bwd(dout, q, k, v, o1, lse1, sep=sep, dropout=drop, keep_bits=bits)
+        for name, a_, b_ in zip("qkv", got, ref):
+            assert torch.equal(a_, b_), (name, fill, rel(a_, b_))
+    # the fraction of kept scores among the words the forward pass wrote: 1 - p
+    w = bits.view(torch.int32).view(b, H, (s_k + 63) // 64, 2, s_q)
+    first = w[:, :, 0, :, s_q - 1].reshape(-1)                  # key block 0 is visible to the last query in every shape here
+    ones = sum(bin(int(x) & 0xFFFFFFFF).count("1") for x in first.tolist())
+    assert abs(ones / (32.0 * first.numel()) - 0.9) < 0.08
+
+
 def test_attention_full_length_properties(ops):
     """s = 1088 (BASELINE sequence): causal property -- output at position i must not change when
     later keys/values change; checked bit-exactly."""
