@@ -144,7 +144,8 @@ SIGNATURES = {
     "cogv_colsum_workspace_bytes": (_sz, [_i, _i]),
     "cogv_ce_fwd": (_i, [_i, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cogv_ce_bwd": (_i, [_i, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "cogv_grad_stats": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "cogv_grad_stats": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "cogv_grad_stats_workspace_bytes": (_sz, []),
     "cogv_adamw_step": (_i, [C.POINTER(AdamDesc), _vp]),
     "cogv_cast_flat": (_i, [_i, _vp, _vp, _sz, _vp]),
     "cogv_cast_flat_back": (_i, [_i, _vp, _vp, _sz, _vp]),

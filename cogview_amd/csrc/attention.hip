@@ -802,6 +802,11 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
         f32x16 sacc, pacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; pacc[e] = 0.f; }
+        // KB (stored keep bits: ~60 registers below the limit): the transposed dO / Q fragments of the dV / dK products are
+        // requested NOW and land behind the S / dP products and the element-wise chain; the regenerating form (register
+        // pressure at the limit) reads them synchronously where they are used -- two exposed LDS round trips per half
+        TrRaw dor_a[2][2], qr_a[2][2];
+        if (KB) { tr_frags_issue<T, sb>(ldot, loff, dor_a); tr_frags_issue<T, sb>(lqt, loff, qr_a); }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           sacc = HT<T>::mfma32(nat_frag<T>(lq, sb * 32 + fr, 2 * t + fg), kf[t], sacc);     // S = Q K^T
@@ -883,21 +888,34 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
         typename HT<T>::v8 pb[2], dsb[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) { pb[t] = cvt8<T>(pd + 8 * t); dsb[t] = cvt8<T>(ds + 8 * t); }
-        {
-          TrRaw dor[2][2];
-          tr_frags_sync<T, sb>(ldot, loff, dor);
+        if (KB) {
+          tr_wait(dor_a[0][0], dor_a[0][1]); tr_wait(dor_a[1][0], dor_a[1][1]);
+          tr_wait(qr_a[0][0], qr_a[0][1]); tr_wait(qr_a[1][0], qr_a[1][1]);
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int d = 0; d < 2; ++d) dvacc[d] = HT<T>::mfma32(tr_pack<T>(dor[t][d]), pb[t], dvacc[d]);
-        }
-        {
-          TrRaw qr[2][2];
-          tr_frags_sync<T, sb>(lqt, loff, qr);
+            for (int d = 0; d < 2; ++d) dvacc[d] = HT<T>::mfma32(tr_pack<T>(dor_a[t][d]), pb[t], dvacc[d]);
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int d = 0; d < 2; ++d) dkacc[d] = HT<T>::mfma32(tr_pack<T>(qr[t][d]), dsb[t], dkacc[d]);
+            for (int d = 0; d < 2; ++d) dkacc[d] = HT<T>::mfma32(tr_pack<T>(qr_a[t][d]), dsb[t], dkacc[d]);
+        } else {
+          {
+            TrRaw dor[2][2];
+            tr_frags_sync<T, sb>(ldot, loff, dor);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int d = 0; d < 2; ++d) dvacc[d] = HT<T>::mfma32(tr_pack<T>(dor[t][d]), pb[t], dvacc[d]);
+          }
+          {
+            TrRaw qr[2][2];
+            tr_frags_sync<T, sb>(lqt, loff, qr);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int d = 0; d < 2; ++d) dkacc[d] = HT<T>::mfma32(tr_pack<T>(qr[t][d]), dsb[t], dkacc[d]);
+          }
         }
       };
       half(std::integral_constant<int, 0>{});

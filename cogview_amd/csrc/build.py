@@ -107,6 +107,9 @@ def scan_asm_hazards(lines):
         if in_asm and op.startswith("ds_read"):
             flight["lgkmcnt"].append(regs(toks[0]))
             continue
+        if in_asm and op.startswith("ds_write"):       # no destination, but it takes a slot of the in-order LDS counter
+            flight["lgkmcnt"].append(set())
+            continue
         if op.startswith("s_waitcnt"):
             for cnt in ("vmcnt", "lgkmcnt"):
                 m = re.search(cnt + r"\((\d+)\)", t)

@@ -248,20 +248,20 @@ extern "C" int cogv_ce_bwd(int logits_dtype, const void* logits, const int64_t* 
   return cogv_check_launch();
 }
 
+extern "C" size_t cogv_grad_stats_workspace_bytes(void) { return 2048 * sizeof(double); }
+
 extern "C" int cogv_grad_stats(int dtype, const void* grads, const int64_t* chunk_start, const int32_t* chunk_len,
-                               const uint8_t* chunk_norm, int nchunks, double* stats, void* stream) {
+                               const uint8_t* chunk_norm, int nchunks, double* stats, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
   if (!grads || !chunk_start || !chunk_len || !chunk_norm || nchunks <= 0 || !stats) return COGV_ERR_ARG;
   if ((uintptr_t)grads & 15) return COGV_ERR_ARG;
+  // per-workgroup partial sums live in the CALLER's workspace (round 3 kept them in a lazily allocated static buffer: a race
+  // between two streams / host threads, and a hipMalloc inside a graph capture)
+  if (!workspace || ((uintptr_t)workspace & 7) || workspace_bytes < cogv_grad_stats_workspace_bytes()) return COGV_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int g = nchunks < 2048 ? nchunks : 2048;
-  // 16 KiB of per-workgroup partial sums, allocated by the library once per device (like the GEMM's work-queue counters):
-  // the statistics pass of one device runs on one stream at a time (the optimizer's), so the buffer is not contended
-  static double* partial_ws[64] = {nullptr};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return COGV_ERR_LAUNCH;
-  if (!partial_ws[dev] && hipMalloc(reinterpret_cast<void**>(&partial_ws[dev]), 2048 * sizeof(double)) != hipSuccess) return COGV_ERR_LAUNCH;
-  double* partial = partial_ws[dev];
+  double* partial = reinterpret_cast<double*>(workspace);
   if (dtype == COGV_F16) hipLaunchKernelGGL((grad_stats_kernel<f16_t>), dim3(g), dim3(256), 0, st, (const f16_t*)grads, chunk_start, chunk_len, chunk_norm, nchunks, stats, partial);
   else hipLaunchKernelGGL((grad_stats_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)grads, chunk_start, chunk_len, chunk_norm, nchunks, stats, partial);
   hipLaunchKernelGGL(grad_stats_final_kernel, dim3(1), dim3(64), 0, st, partial, g, stats);

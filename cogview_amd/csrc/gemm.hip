@@ -1278,6 +1278,129 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// ---- epilogue of the generation-4 kernel (round 4): the same 8-rows-per-store strip transposition and epilogue8 chain as
+//      pp64_epilogue, but with the LDS traffic issued BY HAND as a pipeline.  The compiler-scheduled form above waits, in
+//      every pass, for the pass's own strip writes and for the previous pass's reads before it issues the next reads
+//      (s_waitcnt lgkmcnt(3) x 2 in front of the two ds_read_b128, lgkmcnt(3 / 2) in front of the arithmetic): two exposed LDS
+//      round trips per 8-row pass, ~310 cycles for ~22 instructions, whatever the shader clock -- measured with in-kernel
+//      timestamps (profiles/r04_gemm_item_phase_probe_v1.log): 2.5-3.9 us per 128 x 64 half in the plain / bias forms, 9 % of a
+//      K = 2560 item with the matrix pipe idle.  Here a "super-pass" moves a whole 16-row block: ALL lanes write their four
+//      16 x 16 blocks (rows 0-7 into the wave's strip A, rows 8-15 into strip B: 4 KiB per wave, no exec-masked half), the
+//      four reads of the block follow at once, and the writes + reads of block T + 1 are issued BEFORE block T's registers are
+//      awaited with a counted lgkmcnt(8) -- the LDS unit executes a wave's instructions in order, so the reads of T see T's
+//      data and the writes of T + 1 cannot overtake them.  Accumulators are written straight from the AGPRs.
+__device__ __forceinline__ void w4_strip_put(const uint32_t (&wa)[4], f32x4 (&blk)[4]) {       // four 16 x 16 blocks, AGPR -> LDS
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asm volatile("ds_write_b128 %0, %1" : : "v"(wa[j]), "a"(blk[j]) : "memory");
+}
+__device__ __forceinline__ void w4_strip_get(uint32_t ra0, uint32_t ra1, f32x4 (&x)[4]) {
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %5 offset:2048"
+               : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(ra0), "v"(ra1) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void w4_strip_land(f32x4 (&x)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(N) : "memory");
+}
+template <typename T, int F>
+__device__ __forceinline__ void w4_epilogue(const GemmArgs& pg, f32x4 (&acc)[8][4], char* strip, int m_base, int n_base,
+                                            int ksplit, int lane, uint32_t& amax_pk, int colsum_row, bool land_dma_first) {
+  const int l15 = lane & 15, kb = lane >> 4;
+  if ((COGV_EXP & 2048) && lane == 65) return;                    // probe: no epilogue at all
+  GemmArgs p = pg;
+  pin_s(p.C); pin_s(p.M); pin_s(p.N); pin_s(p.ldc);
+  if (F < 0 || (F & (COGV_EPI_GELU | COGV_EPI_DGELU | COGV_EPI_MULAUX))) { pin_s(p.aux); pin_s(p.ldaux); }
+  if (F < 0 || (F & COGV_EPI_DROPOUT)) { pin_s(p.seed); pin_s(p.stream_id); pin_s(p.thr16); pin_s(p.keep_scale); }
+  if (F < 0) { pin_s(p.flags); pin_s(p.out_f32); pin_s(p.bias); }
+  if (F == -2) pin_s(p.ws);
+  const bool want_cs = (F == -1) ? ((p.flags & COGV_EPI_COLSUM) != 0 && !p.out_f32) : (F >= 0 && (F & COGV_EPI_COLSUM));
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int sr = lane >> 3, sc = lane & 7;           // read side: strip row, 8-column group
+  constexpr bool PRE_BIAS = F >= 0 && (F & COGV_EPI_BIAS), PRE_AUX = F >= 0 && (F & (COGV_EPI_DGELU | COGV_EPI_MULAUX)), PRE_C = F >= 0 && (F & COGV_EPI_ACCUM);
+  u32x4 bias_v = {0u, 0u, 0u, 0u}, aux_v[PRE_AUX ? 16 : 1], c_v[PRE_C ? 16 : 1];
+  const int n = n_base + 8 * sc;
+  {
+    if (PRE_BIAS && n < p.N) bias_v = gload16(reinterpret_cast<const T*>(pg.bias) + n);
+    if (PRE_AUX || PRE_C) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int m = m_base + 8 * t + sr;
+        const bool ok = m < p.M && n < p.N;
+        if (PRE_AUX) aux_v[t] = ok ? gload16(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n) : u32x4{0u, 0u, 0u, 0u};
+        if (PRE_C) c_v[t] = ok ? gload16(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+  // write side: lane (row l15, column quad kb) of block j -> strip (l15 >> 3), row r = l15 & 7, 16-byte chunk (4 j + kb) ^ r
+  const uint32_t sbase = (uint32_t)(uintptr_t)strip;
+  uint32_t wa[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wa[j] = sbase + (uint32_t)((l15 >> 3) * 2048 + (l15 & 7) * 256 + ((((4 * j + kb) ^ (l15 & 7))) << 4));
+  const uint32_t ra0 = sbase + (uint32_t)(sr * 256 + (((2 * sc) ^ sr) << 4)), ra1 = sbase + (uint32_t)(sr * 256 + (((2 * sc + 1) ^ sr) << 4));
+  f32x4 xq[2][4];                                    // [register set][strip * 2 + {columns 0-3, 4-7}]
+  // (F == -1, the run-time-flag instance -- fp32 output, rare flag combinations: its element-wise chain keeps a small
+  //  array in scratch, and the build refuses scratch traffic while asm-issued loads are in flight: no read-ahead there)
+  constexpr bool AHEAD = F != -1;
+  if (AHEAD) {
+    w4_strip_put(wa, acc[0]);
+    w4_strip_get(ra0, ra1, xq[0]);
+  }
+#pragma unroll
+  for (int TT = 0; TT < 8; ++TT) {
+    if (!AHEAD) {
+      w4_strip_put(wa, acc[TT]);
+      w4_strip_get(ra0, ra1, xq[TT & 1]);
+      w4_strip_land<0>(xq[TT & 1]);
+    } else if (TT + 1 < 8) {
+      w4_strip_put(wa, acc[TT + 1]);
+      w4_strip_get(ra0, ra1, xq[(TT + 1) & 1]);
+      w4_strip_land<8>(xq[TT & 1]);
+    } else {
+      w4_strip_land<0>(xq[TT & 1]);
+    }
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+      const int t = 2 * TT + hs;
+      const f32x4 x0 = xq[TT & 1][2 * hs], x1 = xq[TT & 1][2 * hs + 1];
+      int m = m_base + 8 * t + sr;
+      if ((COGV_EXP & 64) && x0[0] != 12345.f) continue;      // probe: no epilogue arithmetic / stores
+      if (COGV_EXP & 128) m &= 255;                           // probe: all tiles store to the same L2-resident rows
+      // the next item's prologue DMAs, issued in front of this epilogue, are waited for in front of its FIRST store: behind
+      // it a vmcnt wait would also have to wait for stores
+      if (t == 0 && land_dma_first) wait_vmcnt<0>();
+      if (m < p.M && n < p.N) {
+        if (F == -2) {                                        // split-K partial: raw fp32 slab
+          float* w = p.ws + ((size_t)ksplit * p.M + m) * p.N + n;
+          gstore16(w, x0);
+          gstore16(w + 4, x1);
+        } else {
+          float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          float rv[8];
+          amax_pk = absmax_pk(amax_pk, epilogue8<T, (F < 0 ? -1 : F)>(p, m, n, v, PRE_BIAS ? &bias_v : nullptr,
+                                                                       PRE_AUX ? &aux_v[t] : nullptr,
+                                                                       PRE_C ? &c_v[t] : nullptr, want_cs ? rv : nullptr));
+          if (want_cs) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] += rv[e];
+          }
+        }
+      }
+    }
+  }
+  if (want_cs) {     // lanes with the same (lane & 7) hold the same 8 columns: fold the 8 strip rows, lanes 0..7 write
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = cs[e];
+      t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+      cs[e] = t;
+    }
+    if (sr == 0 && n < p.N) {
+      float* w = pg.colsum_ws + (size_t)colsum_row * p.N + n;
+      gstore16(w, f32x4{cs[0], cs[1], cs[2], cs[3]});
+      gstore16(w + 4, f32x4{cs[4], cs[5], cs[6], cs[7]});
+    }
+  }
+}
+
 // Probe builds only (-DCOGV_W4_TS, tools/probes/w4_ts.py): per-wave wall time (s_memrealtime, 100 MHz) of the phases of an
 // item, summed over the wave's items and written over the first 32 KiB of problem 0's C when the workgroup exits -- the
 // output of such a build is garbage there by design.  Phases: 0 first wait + barrier, 1 pre-step (queue atomic, first
@@ -1295,7 +1418,7 @@ void gemm_w4_kernel(const GroupArgs ga) {
   constexpr int NW = 4, TBM = 256, TBN = 256, KT = 64;
   constexpr int GRAN = 16384, BUF = 32768, BREG = 65536, ROWB = 256;   // BUF: buffer stride inside an operand's region
   constexpr int G_A01 = 0, G_A23 = 1, G_B01 = 2, G_B23 = 3;
-  extern __shared__ __attribute__((aligned(1024))) char smem[];     // 2 * BUF + NW * 2048
+  extern __shared__ __attribute__((aligned(1024))) char smem[];     // 2 * BREG + NW * 4096
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1549,16 +1672,16 @@ void gemm_w4_kernel(const GroupArgs ga) {
     const bool land_first = certified;
 
     uint32_t amax_pk = 0u;
-    float* strip = reinterpret_cast<float*>(smem + 2 * BREG + wave * 2048);
+    char* strip = smem + 2 * BREG + wave * 4096;
     constexpr int F_FWD_DROP = COGV_EPI_BIAS | COGV_EPI_DROPOUT | COGV_EPI_ABSMAX, F_FWD_GELU = COGV_EPI_BIAS | COGV_EPI_GELU;
     const int mb = done.m0 + wr * 128, nb = done.n0 + wc * 128, csr = (done.m0 >> 7) + wr;
     // transposition through the wave's LDS strip.  (Round 3 also measured a register-exchange form -- v_permlane16_swap,
     // no LDS: equal on plain / bias epilogues, +1.5 % GeLU, -2.3 % column sums, profiles/r03_gemm_swap_epilogue_ab.log; removed.)
 #define W4_EPI(F_)                                                                                   \
   do {                                                                                               \
-    pp64_epilogue<T, F_>(p, acc[0], strip, mb, nb, done.ksplit, lane, amax_pk, csr, land_first);     \
+    w4_epilogue<T, F_>(p, acc[0], strip, mb, nb, done.ksplit, lane, amax_pk, csr, land_first);       \
     W4_TS(5);                                                                                        \
-    pp64_epilogue<T, F_>(p, acc[1], strip, mb, nb + 64, done.ksplit, lane, amax_pk, csr);            \
+    w4_epilogue<T, F_>(p, acc[1], strip, mb, nb + 64, done.ksplit, lane, amax_pk, csr, false);       \
     W4_TS(6);                                                                                        \
   } while (0)
     if (p.splitk > 1) W4_EPI(-2);
@@ -2412,7 +2535,7 @@ extern "C" __attribute__((visibility("hidden"))) int W4_CAT(cogv_w4_launch_, COG
   using T = std::conditional<(COGV_W4_TU & 4) != 0, f16_t, bf16_t>::type;
   constexpr int L = COGV_W4_TU & 3;
   constexpr bool AT = L >= 2, BT = L == 1 || L == 2;
-  constexpr int shmem = 2 * 65536 + 4 * 2048;
+  constexpr int shmem = 2 * 65536 + 4 * 4096;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<T, AT, BT>),

@@ -332,11 +332,15 @@ def dropout(x, p, training=True):
 class _Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
+        ctx.dtypes = (a.dtype, b.dtype)
         return ops.add(a if a.is_contiguous() else a.contiguous(), b if b.is_contiguous() else b.contiguous())
 
     @staticmethod
     def backward(ctx, dy):
-        return dy, dy
+        # the fp32 residual stream joined by a 16-bit branch: each input gets its gradient in ITS dtype (explicitly, not by
+        # the autograd engine's silent cast)
+        da, db = ctx.dtypes
+        return (dy if dy.dtype == da else dy.to(da)), (dy if dy.dtype == db else dy.to(db))
 
 
 def add(a, b):
@@ -457,7 +461,7 @@ def tied_logits(x, emb_weight):
 class _LayerCtx:
     """Everything one layer's backward needs (activations + per-row LN statistics + dropout streams)."""
     __slots__ = ("x", "a", "qkv", "att", "lse", "ao", "y", "c", "u", "g", "mo", "st1", "st2", "st3", "st4",
-                 "d_attn", "d_ao", "d_mo")
+                 "d_attn", "d_ao", "d_mo", "kbits")
 
 
 def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):

@@ -11,10 +11,27 @@ from .initialize import get_model_parallel_group, mp_rank_or_0, mp_world_size_or
 inf = float('inf')
 
 
-def _one_chunk_table(t):
-    dev = t.device
-    return (torch.zeros(1, dtype=torch.int64, device=dev), torch.tensor([t.numel()], dtype=torch.int32, device=dev),
-            torch.ones(1, dtype=torch.uint8, device=dev))
+def _chunk_tables(grads):
+    """[(flat view, chunk_start, chunk_len, chunk_norm)]: ONE chunk table per underlying storage -- the gradients of a model
+    built on the flat arena (cogview_amd/arena.py) are views of one buffer, so the whole norm is one cogv_grad_stats launch
+    (round 3 issued two launches per parameter: ~1.5k at 48 layers).  A tensor whose offset in its storage is not a
+    multiple of 8 elements (the kernel's 16-byte vector loads) gets a table of its own on a contiguous copy."""
+    by_storage, out = {}, []
+    for g in grads:
+        st = g.untyped_storage()
+        off = g.storage_offset()
+        if g.is_contiguous() and off % 8 == 0 and st.data_ptr() % 16 == 0:
+            by_storage.setdefault((st.data_ptr(), g.dtype), (st, [])).__getitem__(1).append((off, g.numel()))
+        else:
+            gc = g.contiguous().view(-1)
+            out.append((gc, [(0, gc.numel())]))
+    for (_, dtype), (st, chunks) in by_storage.items():
+        flat = torch.empty(0, dtype=dtype, device=grads[0].device).set_(st, 0, (st.nbytes() // 2,))      # 16-bit elements
+        out.append((flat, sorted(chunks)))
+    dev = grads[0].device
+    return [(flat, torch.tensor([c[0] for c in ch], dtype=torch.int64, device=dev),
+             torch.tensor([c[1] for c in ch], dtype=torch.int32, device=dev),
+             torch.ones(len(ch), dtype=torch.uint8, device=dev)) for flat, ch in out]
 
 
 def clip_grad_norm(parameters, max_norm, norm_type=2):
@@ -40,14 +57,15 @@ def clip_grad_norm(parameters, max_norm, norm_type=2):
         total_norm = total.item()
     elif norm_type == 2.0:
         stats = torch.zeros(2, dtype=torch.float64, device=dev)
-        for p in parameters:
-            if getattr(p, 'model_parallel', False) or mp_rank_or_0() == 0:
-                g = p.grad.data
-                if g.dtype == torch.float32:
-                    # fp32 master gradients (FP16_Optimizer's non-arena path): torch reduction on a tiny API path
-                    stats[0] += g.double().pow(2).sum()
-                else:
-                    ops.grad_stats(g.contiguous().view(-1), *_one_chunk_table(g), stats)
+        counted = [p.grad.data for p in parameters if getattr(p, 'model_parallel', False) or mp_rank_or_0() == 0]
+        for g in counted:
+            if g.dtype == torch.float32:
+                # fp32 master gradients (FP16_Optimizer's non-arena path): torch reduction on a tiny API path
+                stats[0] += g.double().pow(2).sum()
+        half = [g for g in counted if g.dtype != torch.float32]
+        if half:
+            for flat, cs, cl, cn in _chunk_tables(half):
+                ops.grad_stats(flat, cs, cl, cn, stats)
         if mp > 1:
             torch.distributed.all_reduce(stats, group=get_model_parallel_group())
         total_norm = float(stats[0].item()) ** 0.5

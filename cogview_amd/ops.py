@@ -711,6 +711,9 @@ def dropout(x, p, seed, stream_id, absmax_out=None):
 def add(a, b, absmax_out=None):
     """a + b.  An fp32 `a` is the residual stream joined by the 16-bit branch output `b` (fp32 result)."""
     _need_gpu(a, b)
+    if b.dtype == torch.float32 and a.dtype != torch.float32:
+        raise L.CogviewHipError("ops.add: the fp32 operand (the residual stream) must come first")
+    assert a.numel() == b.numel()
     if a.dtype == torch.float32 and b.dtype != torch.float32:
         out = torch.empty_like(_flat(a))
         L.check(L.lib().cogv_add_stream(dt_code(b), _p(a), _p(_flat(b)), _p(out), a.numel(), _p(absmax_out), _stream()),
@@ -778,8 +781,12 @@ def ce_bwd(logits2d, target1d, vocab_start, gmax, gsum, grad, out=None):
 # ------------------------------------------------------------------------------------------ optimizer
 def grad_stats(flat_grads, chunk_start, chunk_len, chunk_norm, stats):
     _need_gpu(flat_grads)
-    L.check(L.lib().cogv_grad_stats(dt_code(flat_grads), _p(flat_grads), _p(chunk_start), _p(chunk_len),
-                                    _p(chunk_norm), chunk_start.numel(), _p(stats), _stream()), "cogv_grad_stats")
+    lib = L.lib()
+    # the partial sums of the pass: scratch owned by this side of the C ABI, one buffer per (device, stream) so that two
+    # streams running the pass concurrently do not share it
+    ws = workspace("grad_stats_%x" % (_stream() or 0), lib.cogv_grad_stats_workspace_bytes(), flat_grads.device)
+    L.check(lib.cogv_grad_stats(dt_code(flat_grads), _p(flat_grads), _p(chunk_start), _p(chunk_len),
+                                _p(chunk_norm), chunk_start.numel(), _p(stats), _p(ws), ws.numel(), _stream()), "cogv_grad_stats")
 
 
 def adamw_step(params, grads, master, exp_avg, exp_avg_sq, chunk_start, chunk_len, chunk_group, lrs, wds, beta1,

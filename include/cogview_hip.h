@@ -96,8 +96,7 @@ int cogv_colsum_finalize(int dtype, const float* partial, int rows, int N, void*
  * kernel (M, N >= 256, K % 64 == 0): issue them one by one then.  Split-K as in cogv_gemm, per problem. */
 int cogv_gemm_grouped(const cogv_gemm_desc* descs, int count, void* stream);
 /* Note: the persistent GEMM kernel distributes tiles through per-XCD atomic work queues; the library keeps their
- * counters in 4 KiB of device memory per GPU that it allocates itself on the first GEMM call (its only allocations: this and
- * the 16 KiB of partial sums of cogv_grad_stats). */
+ * counters in 4 KiB of device memory per GPU that it allocates itself on the first GEMM call (its only allocation). */
 int cogv_gemm_pick_splitk_tiles(int tiles_256x256, int K);
 
 /* Decode-step matrix-vector product with the layer's LayerNorms as prologue (M <= 8 rows, K = hidden size <= 4096,
@@ -285,9 +284,12 @@ int cogv_ce_bwd(int logits_dtype, const void* logits, const int64_t* target, int
  * mpu/grads.py:61).  chunk_start % 8 == 0.
  */
 /* stats[0] += sum of squares of grads in counted chunks (double; per-workgroup partials summed in a fixed order: the same
- * bits run after run -- the partials live in 16 KiB the library allocates once per device), stats[1] = 1.0 if any grad is inf/nan */
+ * bits run after run), stats[1] = 1.0 if any grad is inf/nan.  workspace: cogv_grad_stats_workspace_bytes() bytes of scratch
+ * owned by the caller (8-byte aligned, no initialisation; one per stream that may run the pass concurrently). */
 int cogv_grad_stats(int dtype, const void* grads, const int64_t* chunk_start, const int32_t* chunk_len,
-                    const uint8_t* chunk_norm, int nchunks, double* stats, void* stream);
+                    const uint8_t* chunk_norm, int nchunks, double* stats, void* workspace, size_t workspace_bytes,
+                    void* stream);
+size_t cogv_grad_stats_workspace_bytes(void);
 typedef struct cogv_adam_desc {
   int dtype;                       /* dtype of model params / grads (F16|BF16) */
   void* params; const void* grads; /* flat model params (written) and their (scaled) grads */

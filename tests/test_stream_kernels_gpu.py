@@ -203,3 +203,51 @@ def test_gemv_layernorm_prologue_on_the_fp32_stream(ops, dtype, M, K, N, post, g
     if gelu:
         ref = O.gelu(ref.to(dtype).float())
     assert rel(out, ref) < TOL[dtype]
+
+
+def test_add_gradient_dtypes_and_operand_order():
+    """functional.add joins the fp32 residual stream (first operand) with a 16-bit branch: each input receives its gradient
+    in ITS OWN dtype (explicitly, round-3 advisor item), and the swapped order -- which would reinterpret fp32 bytes as 16-bit
+    values -- is refused."""
+    from cogview_amd import _lib as L, functional as F_, ops
+    a = torch.randn(4, 64, device="cuda", dtype=torch.float32, requires_grad=True)
+    b = torch.randn(4, 64, device="cuda", dtype=torch.float16, requires_grad=True)
+    y = F_.add(a, b)
+    assert y.dtype == torch.float32
+    y.backward(torch.ones_like(y))
+    assert a.grad.dtype == torch.float32 and b.grad.dtype == torch.float16
+    assert torch.equal(a.grad, torch.ones_like(a)) and torch.equal(b.grad, torch.ones_like(b))
+    with pytest.raises(L.CogviewHipError):
+        ops.add(b.detach(), a.detach())
+
+
+def test_clip_grad_norm_is_one_pass_per_storage_and_exact():
+    """mpu.clip_grad_norm (mpu/grads.py:28-74): gradients that are views of ONE buffer (the flat arena) go through a single
+    chunk table -- one cogv_grad_stats launch, not one per parameter -- together with a stand-alone tensor, a view at an offset
+    that is not a multiple of 8 elements, and an fp32 gradient; the norm equals the float64 reference and the clip scales
+    every tensor."""
+    from cogview_amd import mpu, ops
+    g = torch.Generator().manual_seed(3)
+    arena = (torch.randn(10000, generator=g) * 0.5).half().cuda()
+    views = [arena[0:1000], arena[1024:1024 + 3000].view(30, 100), arena[4096:4096 + 333], arena[5003:5003 + 64]]   # last: odd offset
+    lone = (torch.randn(777, generator=g)).to(torch.bfloat16).cuda()
+    f32 = torch.randn(50, generator=g).cuda()
+    params = []
+    for t in views + [lone, f32]:
+        p = torch.nn.Parameter(torch.zeros_like(t))
+        p.grad = t
+        p.model_parallel = False
+        params.append(p)
+    ref = sum(float((p.grad.double() ** 2).sum()) for p in params) ** 0.5
+    calls = []
+    real = ops.grad_stats
+    ops.grad_stats = lambda *a, **k: (calls.append(a[1].numel()), real(*a, **k))[1]
+    try:
+        before = [p.grad.clone() for p in params]
+        total = mpu.clip_grad_norm(params, ref / 2)
+    finally:
+        ops.grad_stats = real
+    assert abs(total - ref) < 1e-6 * ref
+    assert sorted(calls) == [1, 1, 3], calls            # arena views sharing a table (3 chunks), the odd-offset view, the bf16 tensor
+    for p, b0 in zip(params, before):
+        assert ((p.grad.float() - 0.5 * b0.float()).abs().max() <= 4e-3 * b0.float().abs().max()).item()
