@@ -24,6 +24,8 @@ def _chunk_tables(grads):
             by_storage.setdefault((st.data_ptr(), g.dtype), (st, [])).__getitem__(1).append((off, g.numel()))
         else:
             gc = g.contiguous().view(-1)
+            if gc.data_ptr() % 16:                  # a contiguous view at an odd offset: .contiguous() returned the view itself
+                gc = gc.clone()
             out.append((gc, [(0, gc.numel())]))
     for (_, dtype), (st, chunks) in by_storage.items():
         flat = torch.empty(0, dtype=dtype, device=grads[0].device).set_(st, 0, (st.nbytes() // 2,))      # 16-bit elements
