@@ -109,9 +109,25 @@ def enable_gemm_timing():
     return _GEMM_TIMING
 
 
+_GEMM_TIMING_PARKED = None
+
+
+def sample_gemm_timing(active):
+    """Inside the timed region: bracket the launches of THIS step (active) or let it run bare.  bench.py samples one step
+    in four -- 870 event records per sampled 4B step cost 0.6 % of the step when every step carries them
+    (profiles/r04_bench_event_overhead_ab.log)."""
+    global _GEMM_TIMING, _GEMM_TIMING_PARKED
+    if active and _GEMM_TIMING is None and _GEMM_TIMING_PARKED is not None:
+        _GEMM_TIMING, _GEMM_TIMING_PARKED = _GEMM_TIMING_PARKED, None
+    elif not active and _GEMM_TIMING is not None:
+        _GEMM_TIMING_PARKED, _GEMM_TIMING = _GEMM_TIMING, None
+
+
 def collect_gemm_timing():
     """Synchronise, resolve the events and return aggregate statistics; disables timing."""
-    global _GEMM_TIMING
+    global _GEMM_TIMING, _GEMM_TIMING_PARKED
+    if _GEMM_TIMING is None:
+        _GEMM_TIMING, _GEMM_TIMING_PARKED = _GEMM_TIMING_PARKED, None
     rec, _GEMM_TIMING = _GEMM_TIMING, None
     torch.cuda.synchronize()
     tot_ms, tot_fl, tot_by, by, shapes = 0.0, 0.0, 0.0, {}, {}

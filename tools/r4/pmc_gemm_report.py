@@ -1,5 +1,6 @@
 """Per-dispatch counters of gemm_w4_kernel joined with the kernel trace (durations) of the same rocprofv3 pass.
-MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x shader cycles of the dispatch); shader clock = GRBM_GUI_ACTIVE /
+MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x shader cycles of the dispatch); shader cycles = GRBM_GUI_ACTIVE / 8
+(rocprofv3 sums the counter over the 8 XCDs: a 72-us dispatch reads 1.38e6 = 8 x 72 us x 2.39 GHz); shader clock = cycles /
 wall time (MI355X_MICROARCH.md "DVFS give-back").  Usage: pmc_gemm_report.py <dirA> [<dirB>]"""
 import collections, csv, glob, re, sys
 
@@ -37,8 +38,9 @@ def main():
             m = {k: sum(v) / len(v) for k, v in c.items()}
             line = f"{key:78s} n={len(c['ns']):3d} {m['ns'] / 1e3:8.1f} us"
             if "GRBM_GUI_ACTIVE" in m:
-                clk = m["GRBM_GUI_ACTIVE"] / m["ns"]                     # cycles per ns = GHz
-                busy = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * m["GRBM_GUI_ACTIVE"])
+                cyc = m["GRBM_GUI_ACTIVE"] / 8.0                         # the counter is summed over the 8 XCDs
+                clk = cyc / m["ns"]                                      # cycles per ns = GHz
+                busy = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc)      # 1024 SIMDs; 16 busy cycles per 16x16x32 MFMA
                 line += f"  shader clock {clk:5.3f} GHz  MFMA busy {100 * busy:5.1f} % of SIMD cycles  MFMA insts {m.get('SQ_INSTS_MFMA', 0):.3g}"
                 line += f"  -> peak at this clock {2500.0 * clk / 2.4:6.0f} TFLOP/s"
             if "SQ_WAIT_ANY" in m:
