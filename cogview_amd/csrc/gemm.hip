@@ -71,7 +71,39 @@ struct GroupArgs {
   int count;
   int* sched;                        // [0..7] per-XCD item counters, [8] finished workgroups: 0 at launch, re-armed by the last workgroup
   int group_m;                       // generation 4: tile rows per raster group (the 32 CUs of an XCD work on group_m x 32/group_m tiles)
+  // generation 4, cross-item prefetch (round 4): one problem, no split-K, an even number (>= 4) of k-tiles, and the three
+  // divisions of the tile order replaced by multiplications (w4_tile_fast) that the host verified against w4_tile_slow for
+  // every item of this geometry.  xp_ok = 0: every item boundary takes the set-up + prologue path.
+  int xp_ok;
+  uint32_t xp_magic_ig, xp_magic_gfull, xp_magic_gtail;
 };
+
+// Tile order of the generation-3 / 4 kernels: item (position in the launch's work list) -> tile row / column.  Workgroup ids
+// are dealt to the 8 XCDs round robin; inside an XCD the tiles run in raster groups of group_m tile rows x all tile columns,
+// row fastest (the 32 CUs of an XCD work on group_m x 32 / group_m neighbouring tiles: shared operand panels in one L2).
+__host__ __device__ inline void w4_tile_slow(uint32_t bid, uint32_t tiles_m, uint32_t tiles_n, uint32_t group_m, uint32_t& tm, uint32_t& tn) {
+  const uint32_t nwg = tiles_m * tiles_n, q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const uint32_t wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  const uint32_t in_group = group_m * tiles_n, group_id = wgid / in_group, first_m = group_id * group_m;
+  const uint32_t gsz = tiles_m - first_m < group_m ? tiles_m - first_m : group_m;
+  tm = first_m + (wgid % in_group) % gsz;
+  tn = (wgid % in_group) / gsz;
+}
+// x / d as the high word of x * ceil(2^32 / d): exact while x * d < 2^32 (d = 1: magic 0, handled by the caller)
+inline uint32_t w4_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
+__host__ __device__ inline uint32_t w4_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)a * b) >> 32); }
+__host__ __device__ inline void w4_tile_fast(uint32_t bid, uint32_t tiles_m, uint32_t tiles_n, uint32_t group_m, uint32_t magic_ig,
+                                             uint32_t magic_gfull, uint32_t magic_gtail, uint32_t& tm, uint32_t& tn) {
+  const uint32_t nwg = tiles_m * tiles_n, q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const uint32_t wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  const uint32_t in_group = group_m * tiles_n;
+  const uint32_t group_id = in_group == 1 ? wgid : w4_mulhi(wgid, magic_ig);
+  const uint32_t rem = wgid - group_id * in_group, first_m = group_id * group_m;
+  const bool tail = tiles_m - first_m < group_m;
+  const uint32_t gsz = tail ? tiles_m - first_m : group_m, mg = tail ? magic_gtail : magic_gfull;
+  tn = gsz == 1 ? rem : w4_mulhi(rem, mg);
+  tm = first_m + rem - tn * gsz;
+}
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 7); }
 
@@ -1429,32 +1461,36 @@ void gemm_w4_kernel(const GroupArgs ga) {
 
   struct Item {
     int pi, m0, n0, ksplit, kt0, nk;
-    uint32_t off[4][4];                // [granule][piece]: per-lane byte offsets against a wave-uniform base
+    const char* baseA; const char* baseB;   // wave-uniform: operand + tile origin + the item's first k-tile
+    uint32_t off[4][4];                // [granule][piece]: per-lane byte offsets RELATIVE to the tile origin (clamped at the
+                                       // matrix edge; every interior tile of a problem has the same 16 values)
+  };
+  // tile origin and first k-tile of an item (64-bit scalar arithmetic)
+  auto set_bases = [&](const GemmArgs& p, Item& it) {
+    const size_t ksA = AT ? (size_t)KT * p.lda * 2 : (size_t)KT * 2, ksB = BT ? (size_t)KT * p.ldb * 2 : (size_t)KT * 2;
+    it.baseA = reinterpret_cast<const char*>(p.A) + (AT ? (size_t)it.m0 * 2 : (size_t)it.m0 * p.lda * 2) + (size_t)it.kt0 * ksA;
+    it.baseB = reinterpret_cast<const char*>(p.B) + (BT ? (size_t)it.n0 * 2 : (size_t)it.n0 * p.ldb * 2) + (size_t)it.kt0 * ksB;
   };
   auto setup = [&](int item, Item& it) {
     int pi = 0;
+    if (ga.count > 1) {
 #pragma unroll
-    for (int t = 1; t < MAX_GROUP; ++t) pi += (t < ga.count && item >= ga.item_start[t]) ? 1 : 0;
+      for (int t = 1; t < MAX_GROUP; ++t) pi += (t < ga.count && item >= ga.item_start[t]) ? 1 : 0;
+    }
     const GemmArgs& p = ga.g[pi];
     const int local = item - ga.item_start[pi];
     const int nwg = p.tiles_m * p.tiles_n;
     const int bid = local % nwg;
     it.pi = pi; it.ksplit = local / nwg;
-    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int GROUP_M = ga.group_m;
-    const int in_group = GROUP_M * p.tiles_n;
-    const int group_id = wgid / in_group;
-    const int first_m = group_id * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    const int tile_m = first_m + (wgid % in_group) % gsz;
-    const int tile_n = (wgid % in_group) / gsz;
+    uint32_t tile_m, tile_n;
+    w4_tile_slow((uint32_t)bid, (uint32_t)p.tiles_m, (uint32_t)p.tiles_n, (uint32_t)ga.group_m, tile_m, tile_n);
     // (the integer divisions above run on the VALU: bring the wave-uniform results back to SGPRs, so that the k-loop
     //  counter, the DMA base pointers and the LDS destinations stay scalar)
     it.ksplit = __builtin_amdgcn_readfirstlane(it.ksplit);
-    it.m0 = __builtin_amdgcn_readfirstlane(tile_m * TBM); it.n0 = __builtin_amdgcn_readfirstlane(tile_n * TBN);
+    it.m0 = __builtin_amdgcn_readfirstlane((int)tile_m * TBM); it.n0 = __builtin_amdgcn_readfirstlane((int)tile_n * TBN);
     it.kt0 = it.ksplit * p.ktiles_per_split;
     it.nk = min(p.K / KT, it.kt0 + p.ktiles_per_split) - it.kt0;       // >= 1 by construction
+    set_bases(p, it);
     // Piece = one 1-KiB LDS-DMA instruction; a granule is 16 pieces, wave w owns pieces i*4 + w.
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi) {
@@ -1469,7 +1505,7 @@ void gemm_w4_kernel(const GroupArgs ga) {
           const int row = piece * 8 + (lane >> 3);                 // granule row 0..127
           const int c = (lane & 7) ^ swz(row);
           const int tr = (row & 63) + 128 * (row >> 6) + 64 * g;   // tile row / column
-          const int gm = min(t0 + tr, lim - 1);
+          const int gm = min(tr, lim - 1 - t0);                    // relative to the tile origin
           it.off[gi][i] = (uint32_t)(((size_t)gm * ld + c * 8) * 2);
         } else {
           const int off = piece * 1024 + lane * 16;
@@ -1477,22 +1513,26 @@ void gemm_w4_kernel(const GroupArgs ga) {
           const int c = pc ^ trswz16(krow);
           const int gc = c * 8;                                    // granule column 0..127
           const int tcol = (gc & 63) + 128 * (gc >> 6) + 64 * g;
-          const int col = min(t0 + tcol, lim - 8);
+          const int col = min(tcol, lim - 8 - t0);                 // relative to the tile origin
           it.off[gi][i] = (uint32_t)(((size_t)krow * ld + col) * 2);
         }
       }
     }
   };
-  auto dma = [&](const Item& it, int gi, int i, int kt, int buf) {
+  // one piece of granule gi from k-tile source `src` (an operand base of an item, already advanced to the k-tile)
+  auto dma_from = [&](const char* src, const Item& it, int gi, int i, int buf) {
     if (COGV_EXP & 1) return;
+    const bool isB = gi >= 2;
+    const uint32_t l = smem_u32 + (uint32_t)((isB ? BREG : 0) + buf * BUF + (gi & 1) * GRAN + (i * NW + wave) * 1024);
+    dma16(src, it.off[gi][i], l);
+  };
+  auto dma = [&](const Item& it, int gi, int i, int kt, int buf) {
     const GemmArgs& p = ga.g[it.pi];
     const bool isB = gi >= 2;
     const bool trn = isB ? BT : AT;
     const int ld = isB ? p.ldb : p.lda;
     const size_t kstride = trn ? (size_t)KT * ld * 2 : (size_t)KT * 2;
-    const char* g = reinterpret_cast<const char*>(isB ? p.B : p.A) + (size_t)(it.kt0 + kt) * kstride;
-    const uint32_t l = smem_u32 + (uint32_t)((isB ? BREG : 0) + buf * BUF + (gi & 1) * GRAN + (i * NW + wave) * 1024);
-    dma16(g, it.off[gi][i], l);
+    dma_from((isB ? it.baseB : it.baseA) + (size_t)kt * kstride, it, gi, i, buf);
   };
   // two whole k-tiles, in the order the loop certifies them: [A01 B01](0) [B23 A23](0) [A01 B01](1) [B23 A23](1)
   auto prologue = [&](const Item& it) {
@@ -1548,13 +1588,20 @@ void gemm_w4_kernel(const GroupArgs ga) {
       }
   };
 
-  __shared__ int s_next;
+  // Work items are taken from the XCD's queue TWO ahead (round 4): while item i is computed the index of item i + 1 is
+  // already known, so that its first two k-tiles can ride in the DMA slots of item i's last two k-tiles (cross-item
+  // prefetch, below); the queue position asked for in item i's pre-step is item i + 2.
+  __shared__ int s_next[2];
   const int xq = blockIdx.x & 7;
-  if (threadIdx.x == 0) s_next = xq + 8 * atomicAdd(ga.sched + xq, 1);
+  if (threadIdx.x == 0) {
+    s_next[0] = xq + 8 * atomicAdd(ga.sched + xq, 1);
+    s_next[1] = xq + 8 * atomicAdd(ga.sched + xq, 1);
+  }
   __syncthreads();
   Item cur;
   bool certified = false;
-  int item = __builtin_amdgcn_readfirstlane(s_next);     // wave-uniform by construction: keeps the DMA bases in SGPRs
+  int item = __builtin_amdgcn_readfirstlane(s_next[0]);  // wave-uniform by construction: keeps the DMA bases in SGPRs
+  int nxt = __builtin_amdgcn_readfirstlane(s_next[1]);
   if (item < nitems) { setup(item, cur); prologue(cur); }
 #if defined(COGV_W4_TS)
   uint32_t ts_acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -1586,8 +1633,28 @@ void gemm_w4_kernel(const GroupArgs ga) {
     if (!certified) wait_vmcnt<24>();
     __builtin_amdgcn_s_barrier();
     W4_TS(0);
-    int grabbed = 0;                                       // the item after this one: asked for now, used after the k-loop
+    int grabbed = 0;                                       // the item after the next: asked for now, used after the k-loop
     if (threadIdx.x == 0) grabbed = atomicAdd(ga.sched + xq, 1);
+    // Cross-item prefetch: the DMA slots of this item's last two k-tiles -- which would re-fetch its own last k-tile --
+    // carry the first two k-tiles of the NEXT item instead, and the next item starts with both resident: no set-up
+    // arithmetic, no 32-DMA prologue and no exposed first fetch between the items (2.1-2.7 us of a 60-85 us item with the
+    // matrix pipe idle, profiles/r04_gemm_item_phase_probe_v1.log), and 2 of 40 k-tiles less L2 traffic at K = 2560.
+    // Taken when the launch allows it (ga.xp_ok) and both tiles are interior: every interior tile has the SAME per-lane
+    // offsets against its origin, so only two scalar base pointers change -- selected without a branch inside the k-loop.
+    Item nx = cur;                                         // scalar fields only (off unused)
+    bool xp = false;
+    if (ga.xp_ok && nxt < nitems) {
+      uint32_t tm, tn;
+      w4_tile_fast((uint32_t)nxt, (uint32_t)p.tiles_m, (uint32_t)p.tiles_n, (uint32_t)ga.group_m, ga.xp_magic_ig, ga.xp_magic_gfull,
+                   ga.xp_magic_gtail, tm, tn);
+      nx.pi = 0; nx.ksplit = 0; nx.kt0 = 0; nx.nk = nk;
+      nx.m0 = (int)tm * TBM; nx.n0 = (int)tn * TBN;
+      set_bases(p, nx);
+      xp = cur.m0 + TBM <= p.M && cur.n0 + TBN <= p.N && nx.m0 + TBM <= p.M && nx.n0 + TBN <= p.N;
+    }
+    const char* const xA = xp ? nx.baseA : cur.baseA;      // source of the k-tiles past this item's end
+    const char* const xB = xp ? nx.baseB : cur.baseB;
+    const size_t ksA = AT ? (size_t)KT * p.lda * 2 : (size_t)KT * 2, ksB = BT ? (size_t)KT * p.ldb * 2 : (size_t)KT * 2;
     static_for<8>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       read1(fA, IC<G_A01>{}, IC<0>{}, IC<(r >> 2)>{}, IC<(r & 3)>{});
@@ -1598,7 +1665,7 @@ void gemm_w4_kernel(const GroupArgs ga) {
 
     // one quarter-step: acc[bh][4 ah + i][j] += A(fa) x B(fb) while granule gin of buffer bin is read into fin and
     // granule gd of k-tile ktd is DMA'd into buffer bd
-    auto quarter = [&](auto ahc, auto bhc, Frag& fa, Frag& fb, Frag& fin, auto ginc, auto binc, int gd, int ktd, int bd) {
+    auto quarter = [&](auto ahc, auto bhc, Frag& fa, Frag& fb, Frag& fin, auto ginc, auto binc, int gd, const char* gsrc, int bd) {
       constexpr int ah = decltype(ahc)::value, bh = decltype(bhc)::value, gin = decltype(ginc)::value;
       static_for<8>([&](auto rc) {
           constexpr int r = decltype(rc)::value, ks = r >> 2, i = r & 3;
@@ -1608,7 +1675,7 @@ void gemm_w4_kernel(const GroupArgs ga) {
             read1(fin, ginc, binc, IC<((2 * r) >> 2)>{}, IC<((2 * r) & 3)>{});
             read1(fin, ginc, binc, IC<((2 * r + 1) >> 2)>{}, IC<((2 * r + 1) & 3)>{});
           } else {
-            dma(cur, gd, r - 4, ktd, bd);
+            dma_from(gsrc, cur, gd, r - 4, bd);
           }
           typename HT<T>::v8 va;
           if (AT) va = tr_pack<T>(fa.t[ks][i]); else __builtin_memcpy(&va, &fa.n[ks][i], 16);
@@ -1629,19 +1696,24 @@ void gemm_w4_kernel(const GroupArgs ga) {
     auto tile = [&](int kt, auto bufc, Frag& fb01, Frag& fbx, auto w0c, auto w1c) {
       constexpr int buf = decltype(bufc)::value;
       constexpr bool W0 = decltype(w0c)::value != 0, W1 = decltype(w1c)::value != 0;   // vmcnt waits of the two half-steps
-      const int t2 = min(kt + 2, nk - 1);
+      // k-tile kt + 2 of this item; past its end: k-tile kt + 2 - nk of the next item (cross-item prefetch) or, without it,
+      // this item's last k-tile once more.  Scalar selects, no branch.
+      const bool past = kt + 2 >= nk;
+      const int ktd = past ? (xp ? kt + 2 - nk : nk - 1) : kt + 2;
+      const char* const gA = (past ? xA : cur.baseA) + (size_t)ktd * ksA;
+      const char* const gB = (past ? xB : cur.baseB) + (size_t)ktd * ksB;
       if (W0 && !(COGV_EXP & 8192)) wait_vmcnt<16>();
       __builtin_amdgcn_sched_barrier(0);
       if (!(COGV_EXP & 4096)) __builtin_amdgcn_s_barrier();      // probes: results are garbage without them
       __builtin_amdgcn_sched_barrier(0);
-      quarter(IC<0>{}, IC<0>{}, fA, fb01, fbx, IC<G_B23>{}, IC<buf>{}, G_A01, t2, buf);
-      quarter(IC<0>{}, IC<1>{}, fA, fbx, fI, IC<G_A23>{}, IC<buf>{}, G_B01, t2, buf);
+      quarter(IC<0>{}, IC<0>{}, fA, fb01, fbx, IC<G_B23>{}, IC<buf>{}, G_A01, gA, buf);
+      quarter(IC<0>{}, IC<1>{}, fA, fbx, fI, IC<G_A23>{}, IC<buf>{}, G_B01, gB, buf);
       if (W1 && !(COGV_EXP & 8192)) wait_vmcnt<16>();
       __builtin_amdgcn_sched_barrier(0);
       if (!(COGV_EXP & 4096)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      quarter(IC<1>{}, IC<1>{}, fI, fbx, fA, IC<G_A01>{}, IC<(buf ^ 1)>{}, G_B23, t2, buf);
-      quarter(IC<1>{}, IC<0>{}, fI, fb01, fbx, IC<G_B01>{}, IC<(buf ^ 1)>{}, G_A23, t2, buf);
+      quarter(IC<1>{}, IC<1>{}, fI, fbx, fA, IC<G_A01>{}, IC<(buf ^ 1)>{}, G_B23, gB, buf);
+      quarter(IC<1>{}, IC<0>{}, fI, fb01, fbx, IC<G_B01>{}, IC<(buf ^ 1)>{}, G_A23, gA, buf);
     };
     int kt = 0;
     // half-steps 0..2 read the prologue's granules (all certified above); half-step 3 reads what half-step 0 issued:
@@ -1658,18 +1730,26 @@ void gemm_w4_kernel(const GroupArgs ga) {
     if (nk & 1) tile(nk - 1, IC<0>{}, fB0, fB1, IC<1>{}, IC<1>{});
     __builtin_amdgcn_sched_barrier(0);
     W4_TS(2);
-    wait_vmcnt<0>();                                        // the (redundant) tail prefetches of this item
+    wait_vmcnt<0>();                                        // the tail prefetches: the next item's first two k-tiles (or redundant)
 
-    // ---- next item's prologue goes out BEFORE this item's epilogue (the barrier also retires every wave's last reads)
-    if (threadIdx.x == 0) s_next = xq + 8 * (int)grabbed;
+    // ---- without the cross-item prefetch the next item's prologue goes out BEFORE this item's epilogue (the barrier also
+    //      retires every wave's last reads)
+    if (threadIdx.x == 0) s_next[0] = xq + 8 * (int)grabbed;
     __syncthreads();
-    const int next = __builtin_amdgcn_readfirstlane(s_next);
+    const int after = __builtin_amdgcn_readfirstlane(s_next[0]);
+    const int next = nxt;
     W4_TS(3);
     const Item done = cur;
-    if (next < nitems) { setup(next, cur); prologue(cur); }
+    bool land_first = false;
+    if (xp) {              // both k-tiles resident (vmcnt(0) above, barrier): only the scalar fields change
+      cur.m0 = nx.m0; cur.n0 = nx.n0; cur.baseA = nx.baseA; cur.baseB = nx.baseB;
+      certified = true;
+    } else {
+      if (next < nitems) { setup(next, cur); prologue(cur); }
+      certified = next < nitems;
+      land_first = certified;
+    }
     W4_TS(4);
-    certified = next < nitems;
-    const bool land_first = certified;
 
     uint32_t amax_pk = 0u;
     char* strip = smem + 2 * BREG + wave * 4096;
@@ -1704,6 +1784,7 @@ void gemm_w4_kernel(const GroupArgs ga) {
       if (lane == 0) atomic_max_nonneg(p.absmax, bits_to_f<T>((uint16_t)wv));
     }
     item = next;
+    nxt = after;
 #if defined(COGV_W4_TS)
     ts_acc[7] += 1u;
 #endif
@@ -2252,6 +2333,37 @@ int launch_pp64(GroupArgs& ga, hipStream_t st) {
   const int num_cu = num_cus();
   const int items = ga.item_start[ga.count];
   if constexpr (GEN == 4) {
+    ga.xp_ok = 0; ga.xp_magic_ig = ga.xp_magic_gfull = ga.xp_magic_gtail = 0u;
+    const char* xp_env = getenv("COGV_GEMM_XP");          // read per launch: tests and A/B runs switch it inside one process
+    const bool xp_enabled = !xp_env || atoi(xp_env) != 0;
+    const GemmArgs& a0 = ga.g[0];
+    const int nkt = a0.K / 64;
+    if (xp_enabled && ga.count == 1 && a0.splitk == 1 && nkt >= 4 && (nkt & 1) == 0 && items > num_cu) {
+      // multiplicative forms of the three divisions of the tile order, verified against the dividing form for EVERY item of
+      // this geometry (cached: a training step launches a handful of distinct geometries)
+      struct Geo { int tm, tn, gm, ok; uint32_t mig, mgf, mgt; };
+      static Geo cache[32];
+      static int ncache = 0;
+      const Geo* hit = nullptr;
+      for (int i = 0; i < ncache; ++i)
+        if (cache[i].tm == a0.tiles_m && cache[i].tn == a0.tiles_n && cache[i].gm == ga.group_m) { hit = &cache[i]; break; }
+      Geo g;
+      if (!hit) {
+        g.tm = a0.tiles_m; g.tn = a0.tiles_n; g.gm = ga.group_m;
+        const uint32_t tail = (uint32_t)(a0.tiles_m % ga.group_m);
+        g.mig = w4_magic((uint32_t)(ga.group_m * a0.tiles_n)); g.mgf = w4_magic((uint32_t)ga.group_m); g.mgt = w4_magic(tail);
+        g.ok = 1;
+        for (uint32_t b = 0; b < (uint32_t)items && g.ok; ++b) {
+          uint32_t m1, n1, m2, n2;
+          w4_tile_slow(b, (uint32_t)g.tm, (uint32_t)g.tn, (uint32_t)g.gm, m1, n1);
+          w4_tile_fast(b, (uint32_t)g.tm, (uint32_t)g.tn, (uint32_t)g.gm, g.mig, g.mgf, g.mgt, m2, n2);
+          if (m1 != m2 || n1 != n2) g.ok = 0;
+        }
+        if (ncache < 32) cache[ncache++] = g;
+        hit = &g;
+      }
+      ga.xp_ok = hit->ok; ga.xp_magic_ig = hit->mig; ga.xp_magic_gfull = hit->mgf; ga.xp_magic_gtail = hit->mgt;
+    }
     return W4_LAUNCH[w4_unit<T, AT, BT>()](&ga, items < num_cu ? items : num_cu, st);
   } else {
     static bool attr_set = false;

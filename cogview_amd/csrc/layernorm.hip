@@ -11,7 +11,6 @@
 #include "cogview_hip.h"
 
 #include <cstdlib>
-#include <type_traits>
 
 // rows in flight of the wide STREAM_IN backward (fp32 x, add_in, dx: 20 prefetch registers per row instead of 12).
 // h = 2560, 26112 rows (tools/r3/mb_ln_stream.py): two rows at 162 registers 171.6 us, four rows at 256 registers
@@ -127,10 +126,7 @@ struct LnBwdArgs {
 // loads per lane); the two row statistics go through a double-buffered LDS exchange, one barrier per R rows.
 // MODE as in ln_fwd_kernel, seen from the backward side: 1 (STREAM_IN: LN1, LN2) = x, add_in and dx are the fp32
 // stream / its gradient, dy is T;  2 (STREAM_OUT: LN3, LN4) = dy is the fp32 stream gradient, x, add_in, dx are T.
-// PF (round 4): prefetch distance in iterations.  PF = 1: the rows of iteration i + 1 are requested in the middle of iteration
-// i (one register set).  PF = 2: TWO sets -- set i & 1 is consumed by phase 1 of iteration i and refilled at once with the
-// rows of iteration i + 2, so a request has a whole iteration (barrier, phase 2, stores) plus phase 1 of the next to land.
-template <typename T, int R, int MODE, int PF = 1>
+template <typename T, int R, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 2 ? 3 : 2)))
 void ln_bwd_kernel(const LnBwdArgs p) {
   typedef Row8<T, MODE == 2> DYR;
@@ -147,28 +143,23 @@ void ln_bwd_kernel(const LnBwdArgs p) {
   for (int i = 0; i < 8; ++i) { g[i] = 0.f; dg[i] = 0.f; db[i] = 0.f; cs[i] = 0.f; }
   if (act) unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.gamma) + col), g);
   int buf = 0;
-  typename DYR::raw dyn_[PF][R];       // the rows of the next PF iterations: loaded before this iteration's barrier and stores
-  typename XR::raw xn__[PF][R], adn_[PF][R];
-  float meann_[PF][R], rstdn_[PF][R];
-  auto fetch = [&](int row0, auto setc) {
-    constexpr int S = decltype(setc)::value;
+  typename DYR::raw dyn[R];            // the NEXT iteration's rows: loaded before this iteration's barrier and stores
+  typename XR::raw xn_[R], adn[R];
+  float meann[R], rstdn[R];
+  auto fetch = [&](int row0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int row = row0 + r;
       const bool ok = act && row < p.rows;
-      dyn_[S][r] = ok ? DYR::ld(p.dy, (size_t)row * p.h + col) : DYR::zero();
-      xn__[S][r] = ok ? XR::ld(p.x, (size_t)row * p.h + col) : XR::zero();
-      if (has_add) adn_[S][r] = ok ? XR::ld(p.add_in, (size_t)row * p.h + col) : XR::zero();
-      meann_[S][r] = row < p.rows ? p.mean[row] : 0.f;
-      rstdn_[S][r] = row < p.rows ? p.rstd[row] : 0.f;
+      dyn[r] = ok ? DYR::ld(p.dy, (size_t)row * p.h + col) : DYR::zero();
+      xn_[r] = ok ? XR::ld(p.x, (size_t)row * p.h + col) : XR::zero();
+      if (has_add) adn[r] = ok ? XR::ld(p.add_in, (size_t)row * p.h + col) : XR::zero();
+      meann[r] = row < p.rows ? p.mean[row] : 0.f;
+      rstdn[r] = row < p.rows ? p.rstd[row] : 0.f;
     }
   };
-  const int stride = gridDim.x * R;
-  fetch(blockIdx.x * R, std::integral_constant<int, 0>{});
-  if (PF == 2) fetch(blockIdx.x * R + stride, std::integral_constant<int, 1>{});
-  auto iteration = [&](int row0, auto setc) {
-    constexpr int S = decltype(setc)::value;
-    auto& dyn = dyn_[S]; auto& xn_ = xn__[S]; auto& adn = adn_[S]; auto& meann = meann_[S]; auto& rstdn = rstdn_[S];
+  fetch(blockIdx.x * R);
+  for (int row0 = blockIdx.x * R; row0 < p.rows; row0 += gridDim.x * R) {
     typename XR::raw adv[R];
     float rstd[R], s1[R], s2[R];
     float xhk[R][8], gyk[R][8];        // normalised input and gamma * dy of the rows in flight (kept for phase 2)
@@ -192,7 +183,7 @@ void ln_bwd_kernel(const LnBwdArgs p) {
       }
       s1[r] = wave_sum_uniform(a1); s2[r] = wave_sum_uniform(a2);
     }
-    fetch(row0 + PF * stride, setc);   // the rows of iteration + PF into the set just consumed (rows past the end load nothing)
+    fetch(row0 + gridDim.x * R);       // next iteration's rows (rows past the end load nothing)
     if (lane == 0) {
 #pragma unroll
       for (int r = 0; r < R; ++r) { red[buf][r][wave][0] = s1[r]; red[buf][r][wave][1] = s2[r]; }
@@ -227,14 +218,6 @@ void ln_bwd_kernel(const LnBwdArgs p) {
       }
     }
     buf ^= 1;
-  };
-  if (PF == 1) {
-    for (int row0 = blockIdx.x * R; row0 < p.rows; row0 += stride) iteration(row0, std::integral_constant<int, 0>{});
-  } else {
-    for (int row0 = blockIdx.x * R; row0 < p.rows; row0 += 2 * stride) {
-      iteration(row0, std::integral_constant<int, 0>{});
-      if (row0 + stride < p.rows) iteration(row0 + stride, std::integral_constant<int, PF - 1>{});
-    }
   }
   if (act) {
     float* out = p.partial + (size_t)blockIdx.x * 3 * p.h + col;
@@ -305,11 +288,9 @@ template <typename T, int MODE> void launch_bwd_m(const LnBwdArgs& a, int blocks
   const int nw = (a.h + 511) / 512;             // waves per row (h <= 4096 -> <= 8)
   // wide rows with the dropout replay: two rows in flight at 128 registers (two workgroups per CU) beat four rows at
   // 206 (one per CU) -- 112 vs 129 us at h = 2560; without the replay four rows and one workgroup per CU win (109 vs 116)
-  static const int pf = [] { const char* e = getenv("COGV_LN_BWD_PF"); return e ? atoi(e) : 1; }();
-  if (nw >= 4 && (a.thr16 || (MODE == 1 && ln_bwd_stream_in_rows() == 2))) {
-    if (pf == 2) hipLaunchKernelGGL((ln_bwd_kernel<T, 2, MODE, 2>), dim3(blocks), dim3(nw * 64), 0, st, a);
-    else hipLaunchKernelGGL((ln_bwd_kernel<T, 2, MODE, 1>), dim3(blocks), dim3(nw * 64), 0, st, a);
-  } else hipLaunchKernelGGL((ln_bwd_kernel<T, 4, MODE>), dim3(blocks), dim3(nw * 64), 0, st, a);
+  if (nw >= 4 && (a.thr16 || (MODE == 1 && ln_bwd_stream_in_rows() == 2)))
+    hipLaunchKernelGGL((ln_bwd_kernel<T, 2, MODE>), dim3(blocks), dim3(nw * 64), 0, st, a);
+  else hipLaunchKernelGGL((ln_bwd_kernel<T, 4, MODE>), dim3(blocks), dim3(nw * 64), 0, st, a);
 }
 template <typename T> void launch_bwd(const LnBwdArgs& a, int mode, int blocks, hipStream_t st) {
   if (mode == COGV_LN_STREAM_IN) launch_bwd_m<T, 1>(a, blocks, st);
