@@ -348,6 +348,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
     dma_tile<T>(K, p.k_rs, kb * 64, p.s_k, smem + st * STAGE, wave, lane, lidx);
     dma_tile<T>(V, p.v_rs, kb * 64, p.s_k, smem + st * STAGE + TILE, wave, lane, lidx);
   };
+  // DROP == 2: this lane's keep word of key block kb goes to kwp[kb * 2 * s_q]
+  uint32_t* const kwp = DROP == 2 ? p.keepbits + ((((long long)b * p.H + head) * ((p.s_k + 63) >> 6)) * 2 + fg) * p.s_q + min(myq, p.s_q - 1) : nullptr;
   if (nkb > 0) { issue(0, 0); issue(nkb > 1 ? 1 : 0, 1); }
   int st = 0;
   for (int kb = 0; kb < nkb; ++kb) {
@@ -442,13 +444,12 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
               sacc[sb][4 * gq + i] = kp ? sacc[sb][4 * gq + i] : 0.f;
               if (DROP == 2) {       // kw = 2 kw + keep as ONE v_addc_co_u32: the compare's lane mask is the carry-in (left to
                                      // itself the compiler builds the word with two selects, an or and a shift per pair)
-                unsigned long long cm = __ballot(kp);
-                asm("v_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(kw), "+s"(cm));
+                const unsigned long long cm = __ballot(kp);
+                asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(kw) : "s"(cm) : "vcc");
               }
             }
           }
-        if (DROP == 2 && myq < p.s_q)
-          p.keepbits[((((long long)b * p.H + head) * ((p.s_k + 63) >> 6) + kb) * 2 + fg) * p.s_q + myq] = kw;
+        if (DROP == 2 && myq < p.s_q) kwp[(long long)kb * 2 * p.s_q] = kw;
       }
       // O^T[d][query] += V^T[d][key] . P^T[key][query]
       TrRaw vr2[2][2];
