@@ -86,7 +86,7 @@ def clip_grad_norm(parameters, max_norm, norm_type=2):
     if clip_coef < 1:
         for p in parameters:
             g = p.grad.data
-            if g.dtype == torch.float32 or g.numel() % 8 or not g.is_contiguous():
+            if g.dtype == torch.float32 or g.numel() % 8 or not g.is_contiguous() or g.data_ptr() % 16:
                 g.mul_(clip_coef)
             else:
                 g.copy_(ops.scale(g, clip_coef))
