@@ -181,6 +181,14 @@ __device__ __forceinline__ typename HT<T>::v8 read_frag(const char* lds, int row
 __device__ __forceinline__ u32x4 gload16(const void* q) { return *(const COGV_GLOBAL u32x4*)q; }
 __device__ __forceinline__ void gstore16(void* q, u32x4 v) { *(COGV_GLOBAL u32x4*)q = v; }
 __device__ __forceinline__ void gstore16(float* q, f32x4 v) { *(COGV_GLOBAL f32x4*)q = v; }
+// 16-bit C / aux stores of the non-accumulating epilogues carry the NON-TEMPORAL hint (round 4): a 32-CU XCD writes 4 MiB of C per
+// round of tiles -- the size of its L2 -- through a write-allocating cache that also holds the operand panels.  Measured against
+// plain stores in alternating processes (profiles/r04_gemm_nt_store_ab.log): QKV forward +1.7 %, GeLU + stored gelu' +2.5 % (+3-4 % at
+// K = 1024), the other forward / dgrad launches 0 .. +1 %; the accumulating weight gradient, which reads C back, -0.4 % (kept plain).
+template <bool NT>
+__device__ __forceinline__ void gstore16c(void* q, u32x4 v) {
+  if (NT) __builtin_nontemporal_store(v, (COGV_GLOBAL u32x4*)q); else *(COGV_GLOBAL u32x4*)q = v;
+}
 
 template <typename T, int F = -1>
 //      bias_pre / aux_pre / c_pre: values the caller already loaded (the generation-3 epilogue issues all of a
@@ -189,6 +197,7 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
                                            const u32x4* aux_pre = nullptr, const u32x4* c_pre = nullptr, float* rounded = nullptr) {
   const int flags = F >= 0 ? F : p.flags;
   const bool out_f32 = F >= 0 ? false : (p.out_f32 != 0);
+  constexpr bool NT = F >= 0 && !(F & COGV_EPI_ACCUM);
   if (flags & COGV_EPI_BIAS) {
     u32x4 bv = bias_pre ? *bias_pre : gload16(reinterpret_cast<const T*>(p.bias) + n);
     float b[8]; unpack8<T>(bv, b);
@@ -205,14 +214,14 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
       float gd[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) gelu_and_grad_f(v[i], v[i], gd[i]);
-      if (p.aux) gstore16(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n, pack8<T>(gd));
+      if (p.aux) gstore16c<NT>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n, pack8<T>(gd));
     } else {
       // when the pre-activation is STORED, the activation is evaluated on its rounded value -- exactly what the backward
       // pass (COGV_EPI_DGELU) will read; with nothing stored (inference) it is taken from the fp32 value like above
       if (p.aux) {
         const u32x4 rv = pack8<T>(v);
         unpack8<T>(rv, v);
-        gstore16(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n, rv);
+        gstore16c<NT>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n, rv);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
@@ -261,7 +270,7 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
     if (flags & COGV_EPI_ABSMAX) amax_pk = absmax_pk8(0u, pack8<T>(v));      // fp32 output: max taken on the 16-bit rounding
   } else {
     u32x4 o = pack8<T>(v);
-    gstore16(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n, o);
+    gstore16c<NT>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + n, o);
     if (rounded) unpack8<T>(o, rounded);
     if (flags & COGV_EPI_ABSMAX) amax_pk = absmax_pk8(0u, o);
   }
