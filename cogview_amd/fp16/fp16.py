@@ -141,6 +141,7 @@ class FP16_Optimizer(object):
             self.dynamic_loss_scale = False
             self.loss_scaler = LossScaler(static_loss_scale)
         self.overflow = False
+        self._fwd_nan_dev, self._fwd_nan_host = None, None
         self.first_closure_call_this_step = True
         self.clip_grad_norm = clip_grad_norm
         self._clip, self._stats_valid, self._ddp, self._shard = 0.0, False, None, None
@@ -212,8 +213,23 @@ class FP16_Optimizer(object):
             torch.distributed.all_reduce(st[0:1], group=g)                                    # mpu/grads.py:66
             torch.distributed.all_reduce(st[1:2], op=torch.distributed.ReduceOp.MAX, group=g)  # loss_scaler.py:119
             self._stats.copy_(st)
-        self._host_stats = self._stats.tolist()      # the single host read of the step
+        if self._fwd_nan_dev is not None:            # the forward NaN guard's flag rides in the same read (training.train_step)
+            both = torch.cat((self._stats, self._fwd_nan_dev)).tolist()
+            self._host_stats, self._fwd_nan_host, self._fwd_nan_dev = both[:2], both[2] != 0.0, None
+        else:
+            self._host_stats = self._stats.tolist()  # the single host read of the step
         self._stats_valid = True
+
+    def defer_forward_nan_flag(self, total_loss):
+        """training.train_step(check_forward_nan=True): remember `not isfinite(total_loss)` as a device scalar; it reaches the
+        host together with the gradient statistics (arena path) or at forward_was_nan()."""
+        self._fwd_nan_dev = (~torch.isfinite(total_loss.detach()).all()).to(torch.float64).view(1)
+        self._fwd_nan_host = None
+
+    def forward_was_nan(self):
+        if self._fwd_nan_dev is not None:            # not consumed by a statistics pass (no arena / static loss scale)
+            self._fwd_nan_host, self._fwd_nan_dev = bool(self._fwd_nan_dev.item() != 0.0), None
+        return bool(self._fwd_nan_host)
 
     def _check_overflow(self):
         if self._arena is not None:

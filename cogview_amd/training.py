@@ -91,20 +91,31 @@ def backward_step(optimizer, model, lm_loss, clip_grad=1.0, fp16=True, world_siz
 def train_step(batch, model, optimizer, lr_scheduler=None, clip_grad=1.0, txt_loss_scale=1.0, fp16=True, log=False,
                world_size=1, is_sparse=0, check_forward_nan=False):
     """pretrain_gpt2.py:406-448.  Returns (loss, skipped_iter).
-    check_forward_nan: the reference's guard (:414-416) -- the all-reduced image + text losses are read on the host
-    after the forward pass and a non-finite value skips backward and the optimizer step (all ranks agree because the
-    value is all-reduced).  It needs the partial losses, i.e. it implies `log`."""
+    check_forward_nan: the reference's guard (:414-416) -- a non-finite sum of the all-reduced image + text losses skips
+    the optimizer step WITHOUT touching the loss scale (all ranks agree because the value is all-reduced).  It needs the
+    partial losses, i.e. it implies `log`.  The reference reads the value on the host between forward and backward; with the
+    fused optimizer (one host read per step: the gradient statistics) the flag rides in that read instead -- backward is
+    enqueued at once (the GPU queue is not drained at the forward / backward boundary: 0.8 ms per 4B step,
+    profiles/r04_step_idle_gaps_4B_fp16.txt) and on a non-finite forward its gradients are simply discarded: same
+    parameters, same loss scale, same return value as the reference's early return."""
     log = log or check_forward_nan
     lm_loss, _, img_loss, txt_loss = forward_step(batch, model, txt_loss_scale, is_sparse=is_sparse, log=log,
                                                   world_size=world_size)
+    tot, deferred = None, False
     if check_forward_nan:
         tot = img_loss + txt_loss
-        if not bool(torch.isfinite(tot).all().item()):
+        deferred = fp16 and hasattr(optimizer, 'defer_forward_nan_flag')
+        if deferred:
+            optimizer.defer_forward_nan_flag(tot)
+        elif not bool(torch.isfinite(tot).all().item()):
             print('Skipping backward and optimizer step for nan or inf in forwarding!')
             if hasattr(model, 'needs_reduction'):
                 model.needs_reduction = False
             return tot.detach(), 1
     lm_loss = backward_step(optimizer, model, lm_loss, clip_grad, fp16, world_size=world_size, reduce_loss=log)
+    if deferred and optimizer.forward_was_nan():
+        print('Skipping backward and optimizer step for nan or inf in forwarding!')
+        return tot.detach(), 1
     optimizer.step()
     skipped = 0
     if not (fp16 and optimizer.overflow):

@@ -966,3 +966,52 @@ def test_two_rank_sharded_optimizer_step_on_one_gpu(golden_dir):
             p.join(300)
         for r in range(2):
             assert ret.get(r) is not None and ret[r][0] == "ok", f"rank {r}: {ret.get(r)}"
+
+
+def test_forward_nan_guard_skips_the_step_without_touching_the_loss_scale(golden_dir):
+    """pretrain_gpt2.py:414-416: a non-finite forward loss skips backward and the optimizer step and leaves the loss scale
+    alone.  Here the flag travels with the optimizer's single host read (backward is enqueued, its gradients discarded):
+    parameters, fp32 masters, Adam moments and the loss scale must be untouched, the step reported as skipped, and the next
+    clean step must behave as if the poisoned one had not happened."""
+    from cogview_amd import training
+    from cogview_amd.fp16 import FP16_Optimizer
+    from cogview_amd.model import gpt2_get_params_for_weight_decay_optimization
+    from cogview_amd.optim import FusedAdam
+    g = _golden(golden_dir)
+    S_, B_ = int(g["cfg"][5]), int(g["cfg"][6])
+
+    def build():
+        model = _build(g, torch.float16)
+        groups = gpt2_get_params_for_weight_decay_optimization(model.module)
+        for grp in groups:
+            for p in grp["params"]:
+                if not hasattr(p, "model_parallel"):
+                    p.model_parallel = False
+        opt = FP16_Optimizer(FusedAdam(groups, lr=1e-3, weight_decay=0.01), dynamic_loss_scale=True,
+                             dynamic_loss_args={"init_scale": 2 ** 10})
+        return model, opt
+
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    batch = (g["tokens"].cuda(), g["labels"].cuda(), g["loss_mask"].cuda(), 0, pos)
+    model, opt = build()
+    ref_model, ref_opt = build()
+    training.train_step(batch, model, opt, clip_grad=1.0, check_forward_nan=True)
+    training.train_step(batch, ref_model, ref_opt, clip_grad=1.0, check_forward_nan=True)
+    before = [p.detach().clone() for p in model.module.parameters()]
+    scale0 = opt.loss_scale
+    w = model.module.transformer.layers[1].mlp.dense_4h_to_h.bias
+    keep = w.detach().clone()
+    with torch.no_grad():
+        w[3] = float("nan")
+    loss, skipped = training.train_step(batch, model, opt, clip_grad=1.0, check_forward_nan=True)
+    assert skipped == 1 and not torch.isfinite(loss).all()
+    assert opt.loss_scale == scale0
+    with torch.no_grad():
+        w.copy_(keep)
+    for p, b0 in zip(model.module.parameters(), before):
+        assert torch.equal(p.detach(), b0)
+    loss2, sk2 = training.train_step(batch, model, opt, clip_grad=1.0, check_forward_nan=True)
+    lossr, skr = training.train_step(batch, ref_model, ref_opt, clip_grad=1.0, check_forward_nan=True)
+    assert sk2 == 0 and skr == 0 and loss2.item() == lossr.item()
+    for p, q in zip(model.module.parameters(), ref_model.module.parameters()):
+        assert torch.equal(p.detach(), q.detach())
