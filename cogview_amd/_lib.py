@@ -54,6 +54,7 @@ class AttnDesc(C.Structure):
         ("kv_index", C.c_void_p), ("kv_index_bs", C.c_longlong),
         ("kv_index_gs", C.c_longlong), ("sparse_window", C.c_int), ("sparse_pivots", C.c_int), ("sparse_pivot_bias", C.c_float),
         ("keep_bits", C.c_void_p),
+        ("mask", C.c_void_p), ("mask_bs", C.c_longlong),
     ]
 
 
@@ -99,10 +100,11 @@ class ConvDesc(C.Structure):
         ("relu", C.c_int),
         ("in", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
         ("rgb_w", C.c_void_p), ("rgb_partial", C.c_void_p),
+        ("relu_in", C.c_int), ("residual", C.c_void_p), ("relu_residual", C.c_int),
     ]
 
 
-CONV_4X4_S2, CONV_1X1, CONVT_4X4_S2 = 0, 1, 2
+CONV_4X4_S2, CONV_1X1, CONVT_4X4_S2, CONV_3X3_S1 = 0, 1, 2, 3
 
 _vp, _i, _f, _u64, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_int64, C.c_size_t
 

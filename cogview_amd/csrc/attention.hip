@@ -48,6 +48,10 @@ struct AttnArgs {
   // The forward kernel writes them (its lane = query layout holds exactly these 32 keys per lane and block), the backward
   // kernels read them instead of regenerating the draws (4 to 4.5 of ~14.5 VALU slots per score element in each of them).
   uint32_t* keepbits;
+  // optional (flexible instantiations, IDX = true): an arbitrary mask M [B or 1][s_q][s_k] in the storage type, applied as the
+  // reference does -- scaled score * M - 10000 * (1 - M), mpu/sparse_transformer.py:661-663 -- for ANY real M (binary or not);
+  // the left-to-right rule is off then (sep_k = s_k).  mask_bs = 0 broadcasts one mask over the batch.
+  const void* mask; long long mask_bs;
   const int* kv_index; long long kv_index_bs;                  // optional: key slot j reads K/V row kv_index[b][j] & 0x7fffffff
   // sparse TRAINING form in slot space (sp_w > 0): one index row per query block g = q / sp_w (kv_index_gs apart);
   // bit 31 of an entry = slot masked (-10000); the first sp_npiv slots are pivots and take sp_bias (added to the
@@ -393,6 +397,17 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
         }
       }
       const int kfirst = kb * 64;
+      if (IDX && p.mask) {      // arbitrary mask tensor: raw' = raw * M + (-10000 / scale) * (1 - M)
+        const T* mrow = reinterpret_cast<const T*>(p.mask) + (long long)b * p.mask_bs + (long long)min(myq, p.s_q - 1) * p.s_k;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int key = kfirst + sb * 32 + 4 * fg + (e & 3) + 8 * (e >> 2);
+            const float m = HT<T>::to_f(mrow[min(key, p.s_k - 1)]);
+            sacc[sb][e] = fmaf(sacc[sb][e], m, masked_raw * (1.f - m));
+          }
+      }
       const bool all_visible = (kfirst + 63 <= q0w + off) || (kfirst + 63 < p.sep_k);
       if (!all_visible || kfirst + 64 > p.s_k) {
 #pragma unroll
@@ -634,6 +649,16 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
           }
         }
         const int kfirst = kb * 64 + sb * 32;
+        float mk[16];                                          // arbitrary mask tensor (see attn_fwd_kernel): d raw = d raw' * M
+        if (IDX && p.mask) {
+          const T* mrow = reinterpret_cast<const T*>(p.mask) + (long long)b * p.mask_bs + (long long)min(myq, p.s_q - 1) * p.s_k;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int key = kfirst + 4 * fg + (e & 3) + 8 * (e >> 2);
+            mk[e] = HT<T>::to_f(mrow[min(key, p.s_k - 1)]);
+            sacc[e] = fmaf(sacc[e], mk[e], masked_raw * (1.f - mk[e]));
+          }
+        }
         const bool all_visible = (kfirst + 31 <= q0w + off) || (kfirst + 31 < p.sep_k);
         if (!all_visible || kfirst + 32 > p.s_k) {
           const int base = kfirst + 4 * fg;
@@ -657,6 +682,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
             }
             else if (drop) dp = keep_of(r, i, p.thr16) ? dp : 0.f;
             ds[e] = pr * fmaf(dp, kscale, -dv);                  // kscale = 1 / (1 - p) (1 without dropout)
+            if (IDX && p.mask) ds[e] *= mk[e];
           }
         }
         tr_wait(kr[0][0], kr[0][1]); tr_wait(kr[1][0], kr[1][1]);
@@ -837,6 +863,16 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
 #pragma unroll
           for (int e = 0; e < 16; ++e) sacc[e] = (kflag ? masked_raw : sacc[e]) + sp_add;
         }
+        float mq[16];                                          // arbitrary mask tensor: column `mykey` of M, the lane's 16 queries
+        if (IDX && p.mask) {
+          const T* mcol = reinterpret_cast<const T*>(p.mask) + (long long)b * p.mask_bs + min(mykey, p.s_k - 1);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int q = qfirst + 4 * fg + (e & 3) + 8 * (e >> 2);
+            mq[e] = HT<T>::to_f(mcol[(long long)min(q, p.s_q - 1) * p.s_k]);
+            if (q < p.s_q) sacc[e] = fmaf(sacc[e], mq[e], masked_raw * (1.f - mq[e]));
+          }
+        }
         uint32_t kmask[4] = {0u, 0u, 0u, 0u};
         if (drop && !KB) {
           const int c = lane & 3;
@@ -880,6 +916,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
             if (drop) keepf = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)km[i], KB ? kw_bit : (uint32_t)kbit, 1u) & __float_as_uint(kscale));
             pd[e] = pr * keepf;
             ds[e] = fmaf(pd[e], pacc[e], -(pr * d4[i]));
+            if (IDX && p.mask) ds[e] *= mq[e];
           }
         }
         if (!kvalid) {
@@ -1112,7 +1149,11 @@ int fill_args(const cogv_attn_desc* d, AttnArgs& a) {
   if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return COGV_ERR_ARG;
   a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o; a.dout = d->dout; a.dq = d->dq; a.dk = d->dk; a.dv = d->dv;
   a.lse = d->lse; a.dvec = d->dvec; a.colsum_ws = nullptr; a.kv_index = nullptr; a.kv_index_bs = 0;
-  a.keepbits = nullptr;
+  a.keepbits = nullptr; a.mask = nullptr; a.mask_bs = 0;
+  if (d->mask) {            // arbitrary mask tensor (sep_k is set below: every key is a candidate, the tensor decides)
+    if (((uintptr_t)d->mask & 1) || d->kv_index || d->keep_bits) return COGV_ERR_ARG;
+    a.mask = d->mask; a.mask_bs = d->mask_bs;
+  }
   a.kv_index_gs = 0; a.sp_w = 0; a.sp_npiv = 0; a.sp_bias = 0.f;
   a.q_bs = d->q_bs; a.k_bs = d->k_bs; a.v_bs = d->v_bs; a.o_bs = d->o_bs; a.do_bs = d->do_bs;
   a.dq_bs = d->dq_bs; a.dk_bs = d->dk_bs; a.dv_bs = d->dv_bs;
@@ -1121,6 +1162,7 @@ int fill_args(const cogv_attn_desc* d, AttnArgs& a) {
   a.B = d->B; a.H = d->H; a.s_q = d->s_q; a.s_k = d->s_k;
   int sep = d->sep; if (sep < 0) sep = 0;
   a.sep_k = sep > 0 ? sep + (d->s_k - d->s_q) : 0;
+  if (a.mask) a.sep_k = d->s_k;
   a.scale = d->scale;
   a.thr16 = (uint32_t)(d->dropout_p * 65536.0f + 0.5f);
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
@@ -1175,7 +1217,7 @@ extern "C" int cogv_attention_fwd(const cogv_attn_desc* d, void* stream) {
     else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, false, 2>), grid, dim3(NT), sh, st, a);
     return cogv_check_launch();
   }
-  if (a.kv_index) {
+  if (a.kv_index || a.mask) {         // the flexible instantiation: gathered / sparse forms, arbitrary mask tensors
     if (d->dtype == COGV_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16_t, true, -1>), grid, dim3(NT), sh, st, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, true, -1>), grid, dim3(NT), sh, st, a);
   } else if (d->dtype == COGV_F16) {
@@ -1196,6 +1238,10 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   if (d->kv_index && d->sparse_window <= 0) return COGV_ERR_UNSUPPORTED;      // the plain gathered form is inference only
   if ((rc = index_args(d, a))) return rc;
   if (a.sp_w > 0 && d->colsum_partial) return COGV_ERR_UNSUPPORTED;
+  if (a.mask && !d->kv_index) {        // (the IDX dQ instantiation's shared-memory attribute is set on first use below)
+    static bool attr_m = false;
+    if (!attr_m) { set_smem(&attn_bwd_dq_kernel<f16_t, true, -1>, 3 * 2 * TILE); set_smem(&attn_bwd_dq_kernel<bf16_t, true, -1>, 3 * 2 * TILE); attr_m = true; }
+  }
   if (d->colsum_partial) {
     if (d->s_q != d->s_k || ((uintptr_t)d->colsum_partial & 15)) return COGV_ERR_ARG;
     a.colsum_ws = d->colsum_partial;
@@ -1247,7 +1293,7 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T_, IDX_, DROP_>), gq, dim3(NT), sh_q, st, a);            \
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T_, IDX_, DROP_>), gk, dim3(NT), sh_k, st, a);          \
   } while (0)
-  if (a.kv_index) {       // sparse training form: the instantiation with the gather and the slot attributes
+  if (a.kv_index || a.mask) {   // sparse training form / arbitrary mask tensor: the instantiation with the gather, the slot attributes, the mask
     if (d->dtype == COGV_F16) ATTN_BWD_LAUNCH(f16_t, true, -1); else ATTN_BWD_LAUNCH(bf16_t, true, -1);
   } else if (d->dtype == COGV_F16) {
     if (drop) ATTN_BWD_LAUNCH(f16_t, false, 1); else ATTN_BWD_LAUNCH(f16_t, false, 0);

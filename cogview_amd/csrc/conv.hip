@@ -40,6 +40,9 @@ struct ConvArgs {
   float* rgb_part;          // ... partial sums [Cout / 128][B * OH * OW][4] instead of the output tensor
   long long w_parity_stride;
   int relu_out;
+  int relu_in;              // ReLU applied to the INPUT activations while they are parked in LDS (pre-activation residual blocks)
+  const float* residual;    // optional: out += (relu_res ? max(residual, 0) : residual), same NHWC shape as out, after bias / ReLU
+  int relu_res;
   int nz;                   // parities (4 for the transposed convolution, else 1)
   int K;                    // ntaps * Cin
   int M;                    // B * GH * GW
@@ -54,6 +57,7 @@ struct ConvArgs {
 __device__ __forceinline__ void tap_offset(int kind, int z, int tap, int& dy, int& dx) {
   if (kind == COGV_CONV_4X4_S2) { dy = (tap >> 2) - 1; dx = (tap & 3) - 1; }
   else if (kind == COGV_CONVT_4X4_S2) { dy = (z >> 1) - (tap >> 1); dx = (z & 1) - (tap & 1); }
+  else if (kind == COGV_CONV_3X3_S1) { const int ky = (tap * 11) >> 5; dy = ky - 1; dx = tap - 3 * ky - 1; }   // tap / 3 for tap < 9
   else { dy = 0; dx = 0; }
 }
 
@@ -168,13 +172,18 @@ __device__ __forceinline__ uint32_t load_b(const RowCtx& c, int k0, int K, f32x4
   for (int q = 0; q < 4; ++q) ld4_async(r[q], c.base[q] + (kok ? kc : 0));
   return kok ? c.valid : 0u;
 }
-__device__ __forceinline__ void store_tile(char* lds, const f32x4 (&r)[4], uint32_t keep) {
+__device__ __forceinline__ void store_tile(char* lds, const f32x4 (&r)[4], uint32_t keep, bool relu = false) {
   const int t = threadIdx.x;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = (t >> 3) + 32 * q;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(lds + row * 128 + (((t & 7) ^ swz(row)) << 4)) = ((keep >> q) & 1u) ? r[q] : zero;
+    f32x4 v = ((keep >> q) & 1u) ? r[q] : zero;
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(lds + row * 128 + (((t & 7) ^ swz(row)) << 4)) = v;
   }
 }
 __device__ __forceinline__ f32x4 frag(const char* lds, int row, int chunk) {
@@ -255,7 +264,8 @@ __global__ __launch_bounds__(NT, 2) void conv_kernel(const ConvArgs p) {
   ka[0] = load_a<UT>(p, ctx, z, 0, ra[0]); kb[0] = load_b(bctx, 0, p.K, rb[0]);
   ka[1] = load_a<UT>(p, ctx, z, min(1, nk - 1) * BK, ra[1]); kb[1] = load_b(bctx, min(1, nk - 1) * BK, p.K, rb[1]);
   wait_loads<8>(ra[0], rb[0]);
-  store_tile(smem, ra[0], ka[0]); store_tile(smem + 16384, rb[0], kb[0]);
+  const bool relu_in = p.relu_in != 0;
+  store_tile(smem, ra[0], ka[0], relu_in); store_tile(smem + 16384, rb[0], kb[0]);
   __syncthreads();
   // one iteration: loads of tile kt+2 -> set `l`; MFMAs on LDS buffer `bo`; tile kt+1 (set `s`) -> the other buffer
   auto step = [&](int kt, auto lc, auto sc, int bo) {
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(NT, 2) void conv_kernel(const ConvArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     if (!(EXP & 2)) {
       if (EXP & 1) wait_loads<0>(ra[sset], rb[sset]); else wait_loads<8>(ra[sset], rb[sset]);    // tile kt+2 stays in flight
-      store_tile(smem + (bo ^ 32768), ra[sset], ka[sset]); store_tile(smem + (bo ^ 32768) + 16384, rb[sset], kb[sset]);
+      store_tile(smem + (bo ^ 32768), ra[sset], ka[sset], relu_in); store_tile(smem + (bo ^ 32768) + 16384, rb[sset], kb[sset]);
     }
     if (!(EXP & 4)) __syncthreads();
   };
@@ -307,7 +317,16 @@ __global__ __launch_bounds__(NT, 2) void conv_kernel(const ConvArgs p) {
       const int y = rem / p.GW, x = rem - y * p.GW;
       const int oy = y * p.out_mul + (z >> 1), ox = x * p.out_mul + (z & 1);   // z = 0 unless transposed
       if (!p.rgb_part) {
-        float* o = p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.Cout + n;
+        const size_t oidx = (((size_t)b * p.OH + oy) * p.OW + ox) * p.Cout + n;
+        if (p.residual) {      // residual block: out = conv(...) + [relu](input)  (vqvae/vqvae_zc.py:110-114, see cogview_hip.h)
+          f32x4 r0 = ld4(p.residual + oidx), r1 = ld4(p.residual + oidx + 4);
+          if (p.relu_res) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { r0[i] = fmaxf(r0[i], 0.f); r1[i] = fmaxf(r1[i], 0.f); }
+          }
+          x0 += r0; x1 += r1;
+        }
+        float* o = p.out + oidx;
         *reinterpret_cast<f32x4*>(o) = x0;
         *reinterpret_cast<f32x4*>(o + 4) = x1;
       } else {
@@ -505,6 +524,8 @@ extern "C" int cogv_conv2d_nhwc_f32(const cogv_conv_desc* d, void* stream) {
   ConvArgs a;
   a.in = (const float*)d->in; a.w = (const float*)d->w; a.bias = (const float*)d->bias; a.out = (float*)d->out;
   a.B = d->B; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin; a.Cout = d->Cout; a.relu_out = d->relu;
+  a.relu_in = d->relu_in; a.residual = (const float*)d->residual; a.relu_res = d->relu_residual;
+  if (a.residual && (d->rgb_partial || ((uintptr_t)a.residual & 15))) return COGV_ERR_ARG;
   a.rgb_w = (const float*)d->rgb_w; a.rgb_part = (float*)d->rgb_partial;
   int nz = 1;
   a.kind = d->kind;
@@ -513,6 +534,8 @@ extern "C" int cogv_conv2d_nhwc_f32(const cogv_conv_desc* d, void* stream) {
     a.GH = a.OH = d->IH / 2; a.GW = a.OW = d->IW / 2; a.in_mul = 2; a.out_mul = 1; a.ntaps = 16;
   } else if (d->kind == COGV_CONV_1X1) {
     a.GH = a.OH = d->IH; a.GW = a.OW = d->IW; a.in_mul = 1; a.out_mul = 1; a.ntaps = 1;
+  } else if (d->kind == COGV_CONV_3X3_S1) {
+    a.GH = a.OH = d->IH; a.GW = a.OW = d->IW; a.in_mul = 1; a.out_mul = 1; a.ntaps = 9;
   } else if (d->kind == COGV_CONVT_4X4_S2) {
     // out[2y+py] gets taps ky with ky = (py+1) mod 2 (+2):  py=0: ky=1 (iy=y), ky=3 (iy=y-1);  py=1: ky=0 (iy=y+1), ky=2 (iy=y)
     // weights are packed [py*2+px][co][ty*2+tx][ci] with (ty -> ky) = py==0 ? {1,3} : {0,2}, same for x  => dy = py - ty

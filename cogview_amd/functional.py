@@ -149,19 +149,20 @@ class _Attention(torch.autograd.Function):
     """q [b,s_q,H,64], k/v [b,s_k,H,64] (strided views allowed) -> o [b,s_q,H,64]."""
 
     @staticmethod
-    def forward(ctx, q, k, v, sep, dropout):
-        o, lse, bits = ops.attention_fwd(q, k, v, sep=sep, dropout=dropout, keep_bits=True)
+    def forward(ctx, q, k, v, sep, dropout, mask=None):
+        o, lse, bits = ops.attention_fwd(q, k, v, sep=sep, dropout=dropout, keep_bits=True, mask=mask)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.sep, ctx.dropout, ctx.keep_bits = sep, dropout, bits
+        ctx.sep, ctx.dropout, ctx.keep_bits, ctx.mask = sep, dropout, bits, mask
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
         doc = do if do.is_contiguous() else do.contiguous()
-        dq, dk, dv = ops.attention_bwd(doc, q, k, v, o, lse, sep=ctx.sep, dropout=ctx.dropout, keep_bits=ctx.keep_bits)
+        dq, dk, dv = ops.attention_bwd(doc, q, k, v, o, lse, sep=ctx.sep, dropout=ctx.dropout, keep_bits=ctx.keep_bits,
+                                       mask=ctx.mask)
         ctx.keep_bits = None
-        return dq, dk, dv, None, None
+        return dq, dk, dv, None, None, None
 
 
 def _as_bshd(t):
@@ -174,8 +175,11 @@ def _as_bshd(t):
 
 def mask_to_sep(attention_mask, s_q, s_k):
     """Translate the reference's mask argument into the kernel's `sep`:  an int is the reference's "sep" form
-    (mpu/sparse_transformer.py:477-489); a tensor must be the left-to-right mask (optionally with a visible
-    prefix), which is verified once per tensor object."""
+    (mpu/sparse_transformer.py:477-489); a tensor that is the left-to-right mask (optionally with a visible prefix) --
+    every mask the reference's training / generation paths build -- becomes its `sep` (causal block skipping in the
+    kernels).  ANY OTHER tensor (per-sample masks, non-binary masks: mpu/sparse_transformer.py:661-663 multiplies by
+    whatever it is given) returns None: the caller passes the tensor itself to the attention kernels' general-mask
+    path (general_mask()).  Verified once per tensor object."""
     if isinstance(attention_mask, int):
         return attention_mask
     if attention_mask.numel() == 1:
@@ -183,25 +187,44 @@ def mask_to_sep(attention_mask, s_q, s_k):
     cached = getattr(attention_mask, "_cogv_sep", None)
     if cached is not None and cached[0] == attention_mask._version:
         return cached[1]
-    m = attention_mask.reshape(-1, s_q, s_k)[0] if attention_mask.numel() == s_q * s_k else None
-    if m is None:
-        raise NotImplementedError("per-sample attention masks are not supported by the HIP attention kernel")
-    off = s_k - s_q
-    n0 = int(m[0].sum().item())
-    sep = 0 if n0 <= off + 1 else n0 - off
-    ref = torch.ones(s_q, s_k, device=m.device, dtype=m.dtype)
-    ref[:, -s_q:] = torch.tril(ref[:, -s_q:])
-    if sep > 0:
-        ref[:, :sep + off] = 1
-    if not torch.equal(ref, m):
-        raise NotImplementedError(
-            "the HIP attention kernel implements the left-to-right mask with an optional fully visible prefix "
-            "(all masks the reference's training / generation paths build); got a different mask")
+    sep = None
+    if attention_mask.numel() == s_q * s_k:
+        m = attention_mask.reshape(s_q, s_k)
+        off = s_k - s_q
+        n0 = int(m[0].sum().item())
+        cand = 0 if n0 <= off + 1 else n0 - off
+        ref = torch.ones(s_q, s_k, device=m.device, dtype=m.dtype)
+        ref[:, -s_q:] = torch.tril(ref[:, -s_q:])
+        if cand > 0:
+            ref[:, :cand + off] = 1
+        if torch.equal(ref, m):
+            sep = cand
     try:
         attention_mask._cogv_sep = (attention_mask._version, sep)
     except Exception:
         pass
     return sep
+
+
+def general_mask(attention_mask, batch, s_q, s_k, dtype):
+    """An arbitrary mask tensor in the form the kernels take: [B or 1, s_q, s_k], contiguous, storage type (the reference's
+    masks are [1, 1, s_q, s_k] or [b, 1, s_q, s_k], broadcast over the heads).  Cached per tensor object and dtype."""
+    cached = getattr(attention_mask, "_cogv_gmask", None)
+    if cached is not None and cached[0] == (attention_mask._version, dtype):
+        return cached[1]
+    n = attention_mask.numel()
+    if n == s_q * s_k:
+        m = attention_mask.reshape(1, s_q, s_k)
+    elif n == batch * s_q * s_k:
+        m = attention_mask.reshape(batch, s_q, s_k)
+    else:
+        raise ValueError(f"attention mask of shape {tuple(attention_mask.shape)} does not broadcast to [{batch}, 1, {s_q}, {s_k}]")
+    m = m.to(dtype).contiguous()
+    try:
+        attention_mask._cogv_gmask = ((attention_mask._version, dtype), m)
+    except Exception:
+        pass
+    return m
 
 
 def standard_attention(query_layer, key_layer, value_layer, attention_mask, attention_dropout=None):
@@ -211,7 +234,10 @@ def standard_attention(query_layer, key_layer, value_layer, attention_mask, atte
     drop = None
     if attention_dropout is not None:
         drop = _drop(attention_dropout.p, attention_dropout.training, attention=True)
-    o = _Attention.apply(_as_bshd(query_layer), _as_bshd(key_layer), _as_bshd(value_layer), sep, drop)
+    gm = None
+    if sep is None:         # not a left-to-right mask: the tensor itself goes to the kernels (score * M - 10000 * (1 - M))
+        gm, sep = general_mask(attention_mask, query_layer.shape[0], s_q, s_k, query_layer.dtype), 0
+    o = _Attention.apply(_as_bshd(query_layer), _as_bshd(key_layer), _as_bshd(value_layer), sep, drop, gm)
     return o.permute(0, 2, 1, 3)
 
 

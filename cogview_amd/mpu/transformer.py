@@ -231,11 +231,14 @@ class GPT2ParallelTransformerLayer(torch.nn.Module):
         if mem is None and self.scale_normalization and is_sparse == 0:
             s = hidden_states.size(1)
             sep = F_.mask_to_sep(ltor_mask, s, s)
-            return F_.transformer_layer(self, hidden_states, getattr(hidden_states, "_cogv_absmax", None), sep,
-                                        self.training, recompute, on_backward_done)
+            if sep is not None:          # (an arbitrary mask tensor takes the op-by-op composition below)
+                return F_.transformer_layer(self, hidden_states, getattr(hidden_states, "_cogv_absmax", None), sep,
+                                            self.training, recompute, on_backward_done)
         if isinstance(mem, KVCacheSlot) and self.scale_normalization and is_sparse == 0 and not torch.is_grad_enabled():
             sep = ltor_mask if isinstance(ltor_mask, int) else F_.mask_to_sep(ltor_mask, hidden_states.size(1),
                                                                               hidden_states.size(1))
+            if sep is None:
+                raise NotImplementedError("key/value-cache decoding takes the left-to-right mask (int `sep` or its tensor form)")
             return F_.transformer_layer_kv(self, hidden_states, getattr(hidden_states, "_cogv_absmax", None), sep, mem)
         # op-by-op composition (memories / no Sandwich-LN), exactly the reference's dataflow
         a = self.input_layernorm(hidden_states)
@@ -319,6 +322,8 @@ class GPT2ParallelTransformer(torch.nn.Module):
             sep = 0                              # the sparse training form has its own mask rule (rmask + window)
         elif isinstance(attention_mask, torch.Tensor) and attention_mask.numel() > 1:
             sep = F_.mask_to_sep(attention_mask, query_length, key_length)
+            if sep is None:
+                sep = attention_mask     # an arbitrary mask tensor: handed to the layers as it is (general-mask attention path)
         else:
             sep = int(attention_mask) if not isinstance(attention_mask, torch.Tensor) else int(attention_mask.item())
         if not embedded:

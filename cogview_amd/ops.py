@@ -478,7 +478,15 @@ def _attn_desc(q, k, v, o, sep, dropout):
 STORE_KEEP_BITS = os.environ.get("COGV_ATTN_KEEP_BITS", "1") != "0"       # A/B switch of the stored dropout keep bits
 
 
-def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None, keep_bits=False):
+def _attn_mask(d, mask, q, k):
+    """mask: [B or 1, s_q, s_k] contiguous, q's dtype -- an arbitrary mask tensor (cogv_attn_desc.mask)."""
+    b, s_q, s_k = q.shape[0], q.shape[1], k.shape[1]
+    assert mask.dtype == q.dtype and mask.is_contiguous() and mask.dim() == 3 and mask.shape[1:] == (s_q, s_k)
+    assert mask.shape[0] in (1, b)
+    d.mask, d.mask_bs = mask.data_ptr(), (s_q * s_k if mask.shape[0] == b and b > 1 else 0)
+
+
+def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None, keep_bits=False, mask=None):
     """q [b,s_q,H,64], k/v [b,s_k,H,64] (strided views are fine).  Returns (o [b,s_q,H,64] contiguous, lse).
     keep_bits=True (dense form with dropout; the caller will run attention_bwd): returns (o, lse, bits) -- the forward
     kernel stores its dropout keep decisions (1 bit per score, uint8 buffer of cogv_attention_keep_bits_bytes) and
@@ -499,7 +507,10 @@ def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None, keep
         _sparse_desc(d, kv_index, sparse, b, s_q)
     d.lse = lse.data_ptr()
     bits = None
-    if keep_bits and STORE_KEEP_BITS and dropout is not None and dropout[0] > 0.0 and kv_index is None and sparse is None:
+    if mask is not None:
+        assert kv_index is None and sparse is None
+        _attn_mask(d, mask, q, k)
+    if keep_bits and STORE_KEEP_BITS and dropout is not None and dropout[0] > 0.0 and kv_index is None and sparse is None and mask is None:
         bits = torch.empty(L.lib().cogv_attention_keep_bits_bytes(b, H, s_q, k.shape[1]), dtype=torch.uint8, device=q.device)
         d.keep_bits = bits.data_ptr()
     L.check(L.lib().cogv_attention_fwd(C.byref(d), _stream()), "cogv_attention_fwd")
@@ -608,7 +619,7 @@ def sparse_attention_bwd(dout, q, k, v, o, lse, kv_index, sparse, pivot_inv, tim
 
 
 def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, dv=None, colsum_out=None,
-                  colsum_accumulate=True, keep_bits=None):
+                  colsum_accumulate=True, keep_bits=None, mask=None):
     """colsum_out [3*H*64]: (+)= column sums of (dq | dk | dv) over all tokens -- the bias gradient of the fused
     QKV projection -- taken from the kernels' accumulators instead of re-reading the three outputs."""
     _need_gpu(dout, q, k, v, o)
@@ -622,8 +633,10 @@ def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, 
     dvec = torch.empty((2, b, H, s_q), dtype=torch.float32, device=q.device)
     d = _attn_desc(q, k, v, o, sep, dropout)
     d.lse, d.dvec = lse.data_ptr(), dvec.data_ptr()
+    if mask is not None:
+        _attn_mask(d, mask, q, k)
     if keep_bits is not None:
-        assert keep_bits.numel() == L.lib().cogv_attention_keep_bits_bytes(b, H, s_q, k.shape[1])
+        assert mask is None and keep_bits.numel() == L.lib().cogv_attention_keep_bits_bytes(b, H, s_q, k.shape[1])
         d.keep_bits = keep_bits.data_ptr()
     d.dout, d.dq, d.dk, d.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     d.do_bs, d.do_rs = _attn_strides(dout)

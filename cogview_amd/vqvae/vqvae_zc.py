@@ -2,10 +2,12 @@
 state_dict keys: enc_b.blocks.{0,2,4,6}.*, quantize_t.{embed,cluster_size,embed_avg}, dec.blocks.{0,2,4,6}.*),
 inference arithmetic in the HIP library (cogview_amd/csrc/conv.hip).
 
-Scope: the frozen tokenizer as CogView uses it (vqvae/api.py: img2code / code2img, eval mode).  The HIP path
-implements the production topology -- stride=6, simple=True, n_res_block=0: three 4x4 stride-2 convolutions +
-1x1, nearest-code search, three 4x4 stride-2 transposed convolutions + 1x1 -- for any channel / embed_dim /
-n_embed that is a multiple of 8.  Training of the VQ-VAE (EMA codebook update, Gumbel-softmax relaxation) is not
+Scope: the frozen tokenizer as CogView uses it (vqvae/api.py: img2code / code2img, eval mode).  The production topology
+-- stride=6, simple=True, n_res_block=0: three 4x4 stride-2 convolutions + 1x1, nearest-code search, three 4x4 stride-2
+transposed convolutions + 1x1 -- runs the fused fast path (final 1x1 -> RGB in the last transposed convolution's epilogue).
+Every OTHER topology the reference's constructors can build (vqvae/vqvae_zc.py:116-214: stride 6 / 4 / 2, simple or not,
+any number of ResBlocks) runs through a generic interpreter of the same block list on the same kernels (round 4: 3x3
+convolution, input ReLU and residual add in the convolution kernel) -- channel counts a multiple of 8.  Training of the VQ-VAE (EMA codebook update, Gumbel-softmax relaxation) is not
 part of CogView's pipeline (no training script in the reference) and raises.
 """
 import ctypes as C
@@ -25,7 +27,7 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _conv(kind, x, w, bias, cout, relu, rgb=None):
+def _conv(kind, x, w, bias, cout, relu, rgb=None, relu_in=False, residual=None, relu_residual=False):
     """x NHWC fp32 contiguous -> NHWC fp32.  rgb = (w_rgb [3, cout], bias_rgb [3], scale, shift): the decoder's final
     1x1 convolution (and the de-normalisation of api.code2img) fused into this layer's epilogue -- the layer's own
     output tensor is never written; returns the NCHW image [b, 3, oh, ow]."""
@@ -40,6 +42,10 @@ def _conv(kind, x, w, bias, cout, relu, rgb=None):
         oh, ow = ih, iw
     d = L.ConvDesc()
     d.kind, d.B, d.IH, d.IW, d.Cin, d.Cout, d.relu = kind, b, ih, iw, cin, cout, int(relu)
+    d.relu_in, d.relu_residual = int(relu_in), int(relu_residual)
+    if residual is not None:
+        assert residual.shape == (b, oh, ow, cout) and residual.is_contiguous() and rgb is None
+        d.residual = residual.data_ptr()
     setattr(d, "in", x.data_ptr())
     d.w, d.bias = w.data_ptr(), bias.data_ptr()
     if rgb is None:
@@ -50,7 +56,7 @@ def _conv(kind, x, w, bias, cout, relu, rgb=None):
         out = torch.empty((ntiles, b * oh * ow, 4), dtype=torch.float32, device=x.device)
         d.rgb_w, d.rgb_partial = rgb[0].data_ptr(), out.data_ptr()
     par = 4 if kind == L.CONVT_4X4_S2 else 1
-    taps = {L.CONV_4X4_S2: 16, L.CONV_1X1: 1, L.CONVT_4X4_S2: 4}[kind]
+    taps = {L.CONV_4X4_S2: 16, L.CONV_1X1: 1, L.CONVT_4X4_S2: 4, L.CONV_3X3_S1: 9}[kind]
     npix_out = b * oh * ow
     with ops.timed_launch("conv", 2.0 * npix_out * cout * taps * cin, 4.0 * (x.numel() + w.numel() + out.numel()),
                           f"kind{kind} {b}x{ih}x{iw}x{cin}->{cout}"):
@@ -157,26 +163,133 @@ class _ConvStack(nn.Module):
         return self._packed[1]
 
 
+class ResBlock(nn.Module):
+    """vqvae/vqvae_zc.py:99-114: ReLU(inplace), conv3x3, ReLU(inplace), conv1x1, `out += input`.  The leading in-place ReLU
+    overwrites the block's input before it is added back, so the block computes conv(...) + relu(input)."""
+
+    def __init__(self, in_channel, channel):
+        super().__init__()
+        self.conv = nn.Sequential(nn.ReLU(inplace=True), nn.Conv2d(in_channel, channel, 3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(channel, in_channel, 1))
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _pack_generic(m):
+    """(kind, packed weight [.., Cout8, taps, Cin4], bias [Cout8], Cout) of one convolution module; output channels are padded
+    to a multiple of 8 with zero filters (the kernel's 8-wide output vectors), input channels to a multiple of 4."""
+    w = m.weight.detach().float()
+    if isinstance(m, nn.ConvTranspose2d):
+        if m.kernel_size == (1, 1):                       # a 1x1 transposed convolution is a 1x1 convolution with W^T
+            kind, wp = L.CONV_1X1, pack_conv_weight(w.permute(1, 0, 2, 3))
+        else:
+            assert m.kernel_size == (4, 4) and m.stride == (2, 2) and m.padding == (1, 1)
+            kind, wp = L.CONVT_4X4_S2, pack_convt_weight(w)
+            if wp.shape[3] % 4:
+                wp = torch.nn.functional.pad(wp, (0, 4 - wp.shape[3] % 4))
+    else:
+        ks, st, pd = m.kernel_size, m.stride, m.padding
+        if ks == (4, 4) and st == (2, 2) and pd == (1, 1):
+            kind = L.CONV_4X4_S2
+        elif ks == (3, 3) and st == (1, 1) and pd == (1, 1):
+            kind = L.CONV_3X3_S1
+        elif ks == (1, 1) and st == (1, 1) and pd == (0, 0):
+            kind = L.CONV_1X1
+        else:
+            raise NotImplementedError(f"convolution {ks} stride {st} padding {pd} does not occur in vqvae/vqvae_zc.py")
+        wp = pack_conv_weight(w)
+    cout = m.out_channels
+    cdim = 1 if kind == L.CONVT_4X4_S2 else 0
+    if cout % 8:
+        pad = [0, 0] * (wp.dim() - 1 - cdim) + [0, _pad8(cout) - cout]
+        wp = torch.nn.functional.pad(wp, pad)
+    bias = torch.zeros(_pad8(cout), dtype=torch.float32, device=w.device)
+    bias[:cout] = m.bias.detach().float()
+    return kind, wp.contiguous(), bias, cout
+
+
+def run_block_list(blocks, x, cache):
+    """Interpret an nn.Sequential of the reference's block vocabulary (Conv2d 4x4s2 / 3x3 / 1x1, ConvTranspose2d 4x4s2 / 1x1,
+    ReLU, ResBlock) on NHWC fp32 activations.  A ReLU that follows a convolution rides in that convolution's epilogue; a
+    ReLU that follows a ResBlock (or opens one) is applied to the input of the next convolution inside the kernel.  Padded
+    output channels (zero filters) are carried as zeros and ignored by the next layer's zero-padded input channels."""
+    mods = list(blocks)
+    relu_pending = False
+    i = 0
+
+    def conv(m, x, relu_out, relu_in, residual=None, relu_residual=False):
+        key = (id(m), x.shape[-1])
+        ver = (m.weight.data_ptr(), m.weight._version, m.bias._version)
+        if key not in cache or cache[key][0] != ver:
+            kind, wp, bias, _ = _pack_generic(m)
+            if x.shape[-1] > wp.shape[-1]:               # the previous layer's zero-padded output channels: zero weights for them
+                wp = torch.nn.functional.pad(wp, (0, x.shape[-1] - wp.shape[-1])).contiguous()
+            cache[key] = (ver, (kind, wp, bias))
+        kind, wp, bias = cache[key][1]
+        if x.shape[-1] < wp.shape[-1]:
+            x = torch.nn.functional.pad(x, (0, wp.shape[-1] - x.shape[-1]))
+        return _conv(kind, x, wp, bias, bias.numel(), relu_out, relu_in=relu_in, residual=residual, relu_residual=relu_residual)
+
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.ReLU):
+            relu_pending = True
+            i += 1
+        elif isinstance(m, ResBlock):
+            c3, c1 = m.conv[1], m.conv[3]
+            t = conv(c3, x, True, True)                  # leading ReLU on the input, second ReLU in the epilogue
+            x = conv(c1, t, False, False, residual=x, relu_residual=True)      # + relu(input): the in-place ReLU's doing
+            relu_pending = False                         # (a ReLU pending from before the block is subsumed by the block's own)
+            i += 1
+        else:
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = conv(m, x, fuse, relu_pending)
+            relu_pending = False
+            i += 2 if fuse else 1
+    if relu_pending:
+        x = torch.relu(x)
+    return x
+
+
 class Encoder(_ConvStack):
-    """vqvae/vqvae_zc.py:116-164 (stride 6, simple): conv4x4s2+ReLU, conv4x4s2+ReLU, conv4x4s2, ReLU, conv1x1."""
+    """vqvae/vqvae_zc.py:116-164.  Production (stride 6, simple, no ResBlocks): conv4x4s2+ReLU, conv4x4s2+ReLU, conv4x4s2, ReLU,
+    conv1x1 on the fused fast path; every other topology through run_block_list."""
 
     def __init__(self, in_channel, channel, n_res_block, n_res_channel, stride, embed_dim, n_embed, simple):
-        if stride != 6 or not simple or n_res_block != 0:
-            raise NotImplementedError("HIP tokenizer path: stride=6, simple=True, n_res_block=0 (vqvae/api.py:12-20)")
-        super().__init__([nn.Conv2d(in_channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
-                          nn.Conv2d(channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
-                          nn.Conv2d(channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
-                          nn.Conv2d(channel, embed_dim, 1)])
+        if stride == 6:
+            c1, c2 = (channel, channel) if simple else (channel // 4, channel // 2)
+            blocks = [nn.Conv2d(in_channel, c1, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                      nn.Conv2d(c1, c2, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                      nn.Conv2d(c2, channel, 4, stride=2, padding=1)]
+        elif stride == 4:
+            blocks = [nn.Conv2d(in_channel, channel // 2, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                      nn.Conv2d(channel // 2, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                      nn.Conv2d(channel, channel, 3, padding=1)]
+        elif stride == 2:
+            blocks = [nn.Conv2d(in_channel, channel // 2, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                      nn.Conv2d(channel // 2, channel, 3, padding=1)]
+        else:
+            raise ValueError("stride must be 6, 4 or 2 (vqvae/vqvae_zc.py:120-155)")
+        blocks += [ResBlock(channel, n_res_channel) for _ in range(n_res_block)]
+        blocks += [nn.ReLU(inplace=True), nn.Conv2d(channel, embed_dim, 1)]
+        super().__init__(blocks)
         self.channel, self.embed_dim = channel, embed_dim
+        self._fast = stride == 6 and simple and n_res_block == 0 and channel % 8 == 0 and embed_dim % 8 == 0
+        self._generic_cache = {}
 
     def forward(self, input):
         """NCHW image -> [b, h/8, w/8, embed_dim] (the reference returns the NHWC permutation too, :164)."""
-        (w1, b1), (w2, b2), (w3, b3), (w4, b4) = self._weights([pack_conv_weight] * 4)
         x = input.contiguous().float()
         b, c, h, w = x.shape
         assert c == 3, "encoder expects RGB input"
         x4 = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
         L.check(L.lib().cogv_nchw3_to_nhwc4_f32(_p(x), _p(x4), b, h, w, _stream()), "cogv_nchw3_to_nhwc4_f32")
+        if not self._fast:
+            y = run_block_list(self.blocks, x4, self._generic_cache)
+            return y[..., :self.embed_dim].contiguous() if y.shape[-1] != self.embed_dim else y
+        (w1, b1), (w2, b2), (w3, b3), (w4, b4) = self._weights([pack_conv_weight] * 4)
         y = _conv(L.CONV_4X4_S2, x4, w1, b1, self.channel, True)
         y = _conv(L.CONV_4X4_S2, y, w2, b2, self.channel, True)
         y = _conv(L.CONV_4X4_S2, y, w3, b3, self.channel, True)     # ReLU of blocks[5] folded into this epilogue
@@ -184,18 +297,39 @@ class Encoder(_ConvStack):
 
 
 class Decoder(_ConvStack):
-    """vqvae/vqvae_zc.py:167-229 (stride 4, simple): convT+ReLU x3, conv1x1 -> RGB."""
+    """vqvae/vqvae_zc.py:167-214.  Production (stride 4, simple, no ResBlocks): convT+ReLU x3, conv1x1 -> RGB on the fused fast
+    path; every other topology through run_block_list."""
 
     def __init__(self, in_channel, out_channel, channel, n_res_block, n_res_channel, stride, simple):
-        if stride != 4 or not simple or n_res_block != 0 or out_channel != 3:
-            raise NotImplementedError("HIP tokenizer path: decoder stride=4, simple=True, n_res_block=0, RGB output")
-        super().__init__([nn.ConvTranspose2d(in_channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
-                          nn.ConvTranspose2d(channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
-                          nn.ConvTranspose2d(channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
-                          nn.Conv2d(channel, out_channel, 1)])
-        self.channel = channel
+        blocks = [nn.ConvTranspose2d(in_channel, channel, 4, stride=2, padding=1)]
+        blocks += [ResBlock(channel, n_res_channel) for _ in range(n_res_block)]
+        blocks.append(nn.ReLU(inplace=True))
+        if stride == 4 and simple:
+            blocks += [nn.ConvTranspose2d(channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                       nn.ConvTranspose2d(channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                       nn.Conv2d(channel, out_channel, 1)]
+        elif stride == 4:
+            blocks += [nn.ConvTranspose2d(channel, channel, 4, stride=2, padding=1), nn.ReLU(inplace=True),
+                       nn.ConvTranspose2d(channel, channel // 2, 1), nn.ReLU(inplace=True),
+                       nn.ConvTranspose2d(channel // 2, out_channel, 4, stride=2, padding=1)]
+        elif stride == 2:
+            blocks.append(nn.ConvTranspose2d(channel, out_channel, 4, stride=2, padding=1))
+        # (any other stride: the reference appends nothing -- vqvae/vqvae_zc.py:178-208)
+        super().__init__(blocks)
+        # (a decoder stride other than 4 / 2 ends with the ReLU: its output has `channel` channels)
+        self.channel, self.out_channel = channel, (out_channel if stride in (4, 2) else channel)
+        self._fast = stride == 4 and simple and n_res_block == 0 and out_channel == 3 and channel % 8 == 0 and in_channel % 4 == 0
+        self._generic_cache = {}
 
     def forward_nhwc(self, q_nhwc, scale=None, shift=None):
+        if not self._fast:
+            y = run_block_list(self.blocks, q_nhwc.contiguous().float(), self._generic_cache)
+            img = y[..., :self.out_channel].permute(0, 3, 1, 2).contiguous()
+            if scale is not None:
+                img = img * torch.tensor(scale, device=img.device, dtype=img.dtype).view(1, -1, 1, 1)
+            if shift is not None:
+                img = img + torch.tensor(shift, device=img.device, dtype=img.dtype).view(1, -1, 1, 1)
+            return img
         (w1, b1), (w2, b2), (w3, b3), (w4, b4) = self._weights([pack_convt_weight] * 3 + [lambda w: w.detach().float().reshape(3, -1).contiguous()])
         y = _conv(L.CONVT_4X4_S2, q_nhwc.contiguous(), w1, b1, self.channel, True)
         y = _conv(L.CONVT_4X4_S2, y, w2, b2, self.channel, True)

@@ -189,6 +189,12 @@ typedef struct cogv_attn_desc {
    * the same buffer READS them instead of regenerating the draws.  Results are bit-identical with and without it.  NULL:
    * backward regenerates (also for the gathered / sparse forms, which ignore the field). */
   void* keep_bits;
+  /* optional (dense form only; excludes kv_index and keep_bits): an ARBITRARY mask tensor M in the storage type, [B][s_q][s_k]
+   * (mask_bs = s_q * s_k) or [s_q][s_k] shared by the batch (mask_bs = 0), applied exactly as the reference does for any
+   * real M -- scaled score * M - 10000 * (1 - M), mpu/sparse_transformer.py:661-663 -- in forward and backward; `sep` is ignored
+   * (no left-to-right rule: the tensor decides).  The left-to-right masks the reference's callers build go through `sep`
+   * instead (causal block skipping); this is the general path of the module surface, not a hot path. */
+  const void* mask; long long mask_bs;
 } cogv_attn_desc;
 int cogv_attention_fwd(const cogv_attn_desc* d, void* stream);
 int cogv_attention_bwd(const cogv_attn_desc* d, void* stream);
@@ -314,12 +320,15 @@ int cogv_cast_flat_back(int dtype, const float* src_f32, void* dst_half, size_t 
  * Activations NHWC fp32; weights repacked by the caller to [parity][Cout][tap][Cin]:
  *   COGV_CONV_4X4_S2  (Conv2d k4 s2 p1)        taps = ky*4+kx, 1 parity,  W_packed[co][ky*4+kx][ci] = W[co][ci][ky][kx]
  *   COGV_CONV_1X1                              1 tap
+ *   COGV_CONV_3X3_S1  (Conv2d k3 s1 p1)        taps = ky*3+kx, 1 parity,  W_packed[co][ky*3+kx][ci] = W[co][ci][ky][kx]
+ *                                              (the non-production encoders :147, :154 and ResBlock :105)
  *   COGV_CONVT_4X4_S2 (ConvTranspose2d k4 s2 p1) 4 parities z = py*2+px (output pixel (2y+py, 2x+px)), 4 taps
  *        W_packed[z][co][ty*2+tx][ci] = W[ci][co][ky][kx],  ky = (py ? 2*ty : 1+2*ty),  kx = (px ? 2*tx : 1+2*tx)
  */
 #define COGV_CONV_4X4_S2 0
 #define COGV_CONV_1X1 1
 #define COGV_CONVT_4X4_S2 2
+#define COGV_CONV_3X3_S1 3
 typedef struct cogv_conv_desc {
   int kind; int B, IH, IW, Cin, Cout; int relu;     /* relu: applied to the output */
   const void* in; const void* w; const void* bias; void* out;
@@ -327,6 +336,11 @@ typedef struct cogv_conv_desc {
    * rgb_w = its weights [3][Cout] (fp32); rgb_partial receives [Cout / 128][B * OH * OW][4] fp32 partial sums INSTEAD
    * of the output tensor (out may be NULL; relu must be set; Cout % 128 == 0); finish with cogv_rgb_finalize_f32. */
   const void* rgb_w; void* rgb_partial;
+  /* ResBlock support (vqvae/vqvae_zc.py:99-114: ReLU, conv3x3, ReLU, conv1x1, `out += input`): relu_in applies ReLU to the INPUT
+   * activations inside the kernel (the block's leading ReLU; also the ReLU that follows the last block, :159); residual
+   * (same NHWC shape as out, 16-byte aligned, may be NULL) is added after bias / ReLU, through max(., 0) when relu_residual is
+   * set -- the reference's leading nn.ReLU(inplace=True) overwrites the block's input, so what it adds back is relu(input). */
+  int relu_in; const void* residual; int relu_residual;
 } cogv_conv_desc;
 int cogv_conv2d_nhwc_f32(const cogv_conv_desc* d, void* stream);
 /* out NCHW [B,3,H,W] = (sum over the ntiles partial planes + bias[c]) * scale[c] + shift[c] (scale/shift: 3 HOST floats or NULL) */

@@ -97,10 +97,17 @@ def test_mask_translation():
     assert mask_to_sep(O.build_mask(40, 40), 40, 40) == 0
     assert mask_to_sep(O.build_mask(24, 40, sep=5), 24, 40) == 5
     assert mask_to_sep(O.build_mask(24, 40), 24, 40) == 0
-    bad = O.build_mask(16, 16).clone()
-    bad[0, 0, 3, 9] = 1
-    with pytest.raises(NotImplementedError):
-        mask_to_sep(bad, 16, 16)
+    # any other tensor is not an error (round 4): None = "hand the tensor itself to the kernels' general-mask path"
+    other = O.build_mask(16, 16).clone()
+    other[0, 0, 3, 9] = 1
+    assert mask_to_sep(other, 16, 16) is None
+    per_sample = torch.ones(3, 1, 16, 16)
+    assert mask_to_sep(per_sample, 16, 16) is None
+    from cogview_amd.functional import general_mask
+    assert general_mask(per_sample, 3, 16, 16, torch.float16).shape == (3, 16, 16)
+    assert general_mask(other, 3, 16, 16, torch.float16).shape == (1, 16, 16)
+    with pytest.raises(ValueError):
+        general_mask(torch.ones(2, 1, 16, 16), 3, 16, 16, torch.float16)
 
 
 def test_sparse_pivot_plan_matches_reference_masks(golden_dir):

@@ -404,6 +404,69 @@ def test_attention_stored_keep_bits_equal_the_regenerated_mask(ops, dtype, b, H,
     assert abs(ones / (32.0 * first.numel()) - 0.9) < 0.08
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["per_sample_binary", "shared_fractional", "memory_keys_with_dropout"])
+def test_attention_arbitrary_mask_tensor_vs_oracle(ops, dtype, kind):
+    """mpu/sparse_transformer.py:661-663 multiplies the scores by WHATEVER mask it is given:  S * M - 10000 * (1 - M).  The
+    kernels' general-mask path (cogv_attn_desc.mask) against the oracle, forward and dQ / dK / dV: a different random binary
+    mask per sample ([b, 1, s, s]: the round-3 verdict's missing item), one NON-binary mask shared by the batch (values 0,
+    0.25, 1: the formula is linear in M, the kernels implement it, not a visibility bit), and more keys than queries with
+    attention dropout on top.  Ragged sizes (no multiple of 32 / 64)."""
+    g = torch.Generator().manual_seed(len(kind))
+    if kind == "per_sample_binary":
+        b, H, s_q, s_k, drop = 3, 2, 150, 150, None
+        m = (torch.rand(b, 1, s_q, s_k, generator=g) < 0.6).float()
+        m[..., 0] = 1.0                                   # no empty row
+    elif kind == "shared_fractional":
+        b, H, s_q, s_k, drop = 2, 2, 97, 97, None
+        m = torch.tensor([0.0, 0.25, 1.0])[torch.randint(0, 3, (1, 1, s_q, s_k), generator=g)]
+        m[..., 0] = 1.0
+    else:
+        b, H, s_q, s_k, drop = 2, 1, 70, 200, (0.1, 41, 3)
+        m = (torch.rand(b, 1, s_q, s_k, generator=g) < 0.5).float()
+        m[..., 0] = 1.0
+    q, dout = rnd((b, s_q, H, 64), dtype, g), rnd((b, s_q, H, 64), dtype, g)
+    k, v = rnd((b, s_k, H, 64), dtype, g), rnd((b, s_k, H, 64), dtype, g)
+    keep = None if drop is None else torch.from_numpy(O.attention_keep_mask(b, H, s_q, s_k, *drop))
+    qr, kr, vr = [t.float().permute(0, 2, 1, 3).contiguous().requires_grad_(True) for t in (q, k, v)]
+    o_ref = O.standard_attention(qr, kr, vr, m, keep)
+    o_ref.backward(dout.float().permute(0, 2, 1, 3))
+    grads = [t.grad.permute(0, 2, 1, 3) for t in (qr, kr, vr)]
+    md = dev(m.reshape(-1, s_q, s_k).to(dtype))
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    o, lse = ops.attention_fwd(qd, kd, vd, dropout=drop, mask=md)
+    assert rel(o, o_ref.permute(0, 2, 1, 3)) < TOL[dtype]
+    dq, dk, dv = ops.attention_bwd(dev(dout), qd, kd, vd, o, lse, dropout=drop, mask=md)
+    for name, got, want in zip("qkv", (dq, dk, dv), grads):
+        assert rel(got, want) < TOL[dtype] * 2, (name, rel(got, want))
+
+
+def test_standard_attention_module_surface_takes_any_mask(ops):
+    """functional.standard_attention (the drop-in of mpu/sparse_transformer.py:652-673, tensors [b, np, s, hn]): a left-to-right
+    mask tensor is recognised and takes the `sep` kernels; any other tensor goes to the general-mask path -- both through
+    autograd, against the oracle."""
+    from cogview_amd import functional as F_
+    g = torch.Generator().manual_seed(4)
+    b, H, s = 2, 2, 72
+    for general in (False, True):
+        m = O.build_mask(s, s) if not general else (torch.rand(b, 1, s, s, generator=g) < 0.7).float()
+        if general:
+            m[..., 0] = 1.0
+        q, k, v = [rnd((b, H, s, 64), torch.float16, g) for _ in range(3)]
+        dout = rnd((b, H, s, 64), torch.float16, g)
+        qd, kd, vd = [dev(t).requires_grad_(True) for t in (q, k, v)]
+        md = dev(m.half())
+        assert (F_.mask_to_sep(md, s, s) is None) == general
+        out = F_.standard_attention(qd, kd, vd, md)
+        out.backward(dev(dout))
+        qr, kr, vr = [t.float().requires_grad_(True) for t in (q, k, v)]
+        ref = O.standard_attention(qr, kr, vr, m)
+        ref.backward(dout.float())
+        assert rel(out, ref) < TOL[torch.float16]
+        for got, want in ((qd.grad, qr.grad), (kd.grad, kr.grad), (vd.grad, vr.grad)):
+            assert rel(got, want) < TOL[torch.float16] * 2
+
+
 def test_attention_full_length_properties(ops):
     """s = 1088 (BASELINE sequence): causal property -- output at position i must not change when
     later keys/values change; checked bit-exactly."""

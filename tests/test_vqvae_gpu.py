@@ -182,3 +182,30 @@ def test_fused_rgb_projection_of_the_last_transposed_conv():
                 rgb=(w4.reshape(3, Cout).contiguous().cuda(), b4.cuda(), scale, shift))
     assert img.shape == (B, 3, 2 * H, 2 * W)
     assert rel(img, ref) < 1e-5
+
+
+@pytest.mark.parametrize("variant", ["s4_simple_res2", "s4_pyramid_res1", "s6_pyramid_res2", "s2_res1", "s6_simple_res1"])
+def test_non_production_topologies_vs_the_reference(golden_dir, variant):
+    """Every topology vqvae/vqvae_zc.py's constructors can build besides the production one (round-3 verdict, missing item 4):
+    stride 4 / 2 encoders with their 3x3 convolution, the non-simple channel pyramid (channel / 4, / 2; a 1x1 TRANSPOSED
+    convolution and a 4x4 transposed convolution straight to RGB in the decoder), ResBlocks -- whose leading in-place ReLU
+    makes the block add relu(input), not input -- against the REFERENCE's own outputs (oracle/gen_golden_vqvae_variants.py):
+    token ids bit-exact, decoded image within 2e-5 relative L2 (fp32 products and sums, different summation order)."""
+    from cogview_amd.vqvae.vqvae_zc import VQVAE
+    z = np.load(os.path.join(golden_dir, "vqvae_variants.npz"))
+    ch, nrb, nrc, ed, ne, stride, simple = [int(v) for v in z[f"{variant}.kw"]]
+    m = VQVAE(channel=ch, n_res_block=nrb, n_res_channel=nrc, embed_dim=ed, n_embed=ne, stride=stride, simple=bool(simple))
+    pre = f"{variant}.param."
+    m.load_state_dict({k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)})
+    m = m.cuda().eval()
+    img = torch.from_numpy(z[f"{variant}.img"]).cuda()
+    ids_ref = torch.from_numpy(z[f"{variant}.ids"])
+    with torch.no_grad():
+        quant, diff, ids = m.encode(img)
+        assert torch.equal(ids.cpu(), ids_ref), f"{(ids.cpu() != ids_ref).sum().item()} of {ids_ref.numel()} ids differ"
+        dec = m.decode_code(ids)
+    ref = torch.from_numpy(z[f"{variant}.dec"])
+    assert dec.shape == ref.shape
+    e = ((dec.cpu().double() - ref.double()).norm() / ref.double().norm()).item()
+    assert e < 2e-5, e
+    assert quant.shape[1] == ed and tuple(quant.shape[2:]) == tuple(ids.shape[1:])
