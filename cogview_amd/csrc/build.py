@@ -42,6 +42,8 @@ def sources():
 # instantiated: the generation-4 GEMM kernel's 2 dtypes x 4 layouts build as eight objects in parallel
 # (gemm.hip -DCOGV_W4_TU=k defines only cogv_w4_launch_k).
 EXTRA_UNITS = [("gemm.hip", f"gemm_w4_{k}.o", [f"-DCOGV_W4_TU={k}"]) for k in range(8)]
+# the skinny-M kernels of the decode step, one unit per dtype (gemv.hip is empty without the macro)
+EXTRA_UNITS += [("gemv.hip", f"gemv_{k}.o", [f"-DCOGV_GEMV_TU={k}"]) for k in range(2)]
 
 
 def units():

@@ -203,7 +203,7 @@ def test_gemm_stored_gelu_derivative_epilogues(ops, dtype, M, N, K):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M", [1, 3, 8])
-@pytest.mark.parametrize("N,K", [(768, 512), (2560, 2560), (136, 1024)])
+@pytest.mark.parametrize("N,K", [(768, 512), (2560, 2560), (136, 1024), (24, 2560), (40, 4096), (264, 1536), (2560, 10240), (64, 10752)])
 def test_gemm_skinny_m_decode_shapes(ops, dtype, M, N, K):
     """M <= 8 (one row per beam in a decode step) runs the HBM-streaming matrix-vector kernel; it must agree with the
     tile kernels' results (explicit kernel_variant) and the oracle through the same fused epilogues."""
@@ -822,7 +822,8 @@ def test_attention_output_projection_with_combine_prologue(ops, dtype, b, H, cap
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,K,N,post,gelu", [(1, 512, 768, False, False), (3, 1024, 512, True, True), (8, 2560, 1024, True, False),
-                                              (2, 4096, 256, True, True), (5, 512, 64, False, True)])
+                                              (2, 4096, 256, True, True), (5, 512, 64, False, True), (1, 2560, 7680, True, False),
+                                              (2, 2560, 24, False, True), (4, 1536, 136, True, False), (1, 1024, 40, True, True)])
 def test_gemv_with_layernorm_prologue(ops, dtype, M, K, N, post, gelu):
     """cogv_gemv_ln == the unfused chain of the same library (Sandwich-LN kernels, then the GEMV with the same epilogue)
     and the oracle's definition (mpu/sparse_transformer.py:326-341): t = residual + LN_post(z), x_in = LN_pre(t),

@@ -171,7 +171,8 @@ def test_embedding_backward_is_deterministic_and_rounds_once(ops, dtype, d32):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,K,N,post,gelu", [(1, 512, 768, False, False), (3, 1024, 512, True, True), (8, 2560, 1024, True, False),
-                                              (2, 4096, 256, True, True)])
+                                              (2, 4096, 256, True, True), (1, 2560, 7680, True, False), (2, 2560, 24, False, True),
+                                              (4, 1536, 136, True, False), (1, 1024, 40, False, True)])
 def test_gemv_layernorm_prologue_on_the_fp32_stream(ops, dtype, M, K, N, post, gelu):
     """cogv_gemv_ln with stream_f32: residual / t (and the plain input) are fp32 rows; t = residual + LN_post(z) without
     intermediate roundings == what the Sandwich-LN kernel writes in its stream-out form, bit for bit."""
