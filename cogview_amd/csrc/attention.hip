@@ -1012,23 +1012,34 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs p) {
   const int t = threadIdx.x, dch = t & 7, kg = t >> 3, lane = t & 63, wave = t >> 6;
   const int split = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
   const int hp = p.H * HD;
-  const long long pos = *p.pos;
   const T* qrow = reinterpret_cast<const T*>(p.qkv) + b * p.qkv_bs + head * HD + dch * 8;
   float q8[8], kn[8], vn[8];
   unpack8<T>(*reinterpret_cast<const u32x4*>(qrow), q8);
   const u32x4 knew = *reinterpret_cast<const u32x4*>(qrow + hp), vnew = *reinterpret_cast<const u32x4*>(qrow + 2 * hp);
   T* crow = reinterpret_cast<T*>(p.cache) + b * p.cache_bs + head * HD + dch * 8;
-  float sc[4]; u32x4 v8[4];
+  float sc[4]; u32x4 v8[4], kc8[4];
   float m_loc = -INFINITY;
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     const long long key = (long long)split * 128 + ps * 32 + kg;
+    // the cache rows are requested whatever *pos says (slots past it hold stale or no data and are replaced below; a key past
+    // the capacity re-reads the last row): the position is a device scalar, and loads that waited for it would start one
+    // memory latency late -- the launch is a chain of latencies, not of bytes
+    const long long krow = key < p.cap ? key : p.cap - 1;
+    kc8[ps] = *reinterpret_cast<const u32x4*>(crow + krow * p.cache_rs);
+    v8[ps] = *reinterpret_cast<const u32x4*>(crow + krow * p.cache_rs + hp);
+  }
+  const long long pos = *p.pos;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const long long key = (long long)split * 128 + ps * 32 + kg;
     const bool valid = key <= pos && key < p.cap;
-    u32x4 k8 = knew; v8[ps] = vnew;
-    if (valid && key != pos) {
-      k8 = *reinterpret_cast<const u32x4*>(crow + key * p.cache_rs);
-      v8[ps] = *reinterpret_cast<const u32x4*>(crow + key * p.cache_rs + hp);
-    } else if (valid) {                      // the new token's own slot: store it for the steps to come
+    const bool cached = valid && key != pos;
+    // (bit masks, not a select: the compiler turns a select of a loaded value into a branch and sinks the load into it)
+    const uint32_t mk = cached ? 0xffffffffu : 0u;
+    const u32x4 k8 = (kc8[ps] & mk) | (knew & ~mk);
+    v8[ps] = (v8[ps] & mk) | (vnew & ~mk);
+    if (valid && !cached) {                  // the new token's own slot: store it for the steps to come
       *reinterpret_cast<u32x4*>(crow + key * p.cache_rs) = knew;
       *reinterpret_cast<u32x4*>(crow + key * p.cache_rs + hp) = vnew;
     }
@@ -1081,6 +1092,11 @@ __global__ __launch_bounds__(64) void attn_decode_combine_kernel(const DecodeArg
   // lane i holds split i's (max, sum): one independent load each instead of a chain of dependent ones (nsplit <= 32)
   const float mi = t < p.nsplit ? base[t * 66] : -INFINITY;
   const float li = t < p.nsplit ? base[t * 66 + 1] : 0.f;
+  // the partial outputs of up to 16 splits are requested together with the statistics (clamped index: unconditional), so the
+  // launch pays one memory round trip instead of two
+  float ov[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ov[i] = base[(i < p.nsplit ? i : p.nsplit - 1) * 66 + 2 + t];
   float M = mi;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
@@ -1091,8 +1107,13 @@ __global__ __launch_bounds__(64) void attn_decode_combine_kernel(const DecodeArg
   wgt[t] = w;
   __syncthreads();
   float O = 0.f;
+  if (p.nsplit <= 16) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O = i < p.nsplit ? fmaf(ov[i], wgt[i], O) : O;         // same order as the loop below
+  } else {
 #pragma unroll 8
-  for (int i = 0; i < p.nsplit; ++i) O = fmaf(base[i * 66 + 2 + t], wgt[i], O);
+    for (int i = 0; i < p.nsplit; ++i) O = fmaf(base[i * 66 + 2 + t], wgt[i], O);
+  }
   reinterpret_cast<T*>(p.out)[b * p.out_bs + head * HD + t] = HT<T>::from_f(O / L);
 }
 

@@ -1915,7 +1915,7 @@ __global__ __launch_bounds__(256) void gemv_ln_kernel(const GemvLnArgs q) {
       rr[m][u] = (ok && m < p.M && (has_post || SF)) ? SR::ld(has_post ? q.res : q.z, (size_t)m * K + v * 8) : SR::zero();
     }
   }
-  const float zamax = q.z_absmax ? *q.z_absmax : 0.f;
+  float zamax = q.z_absmax ? *q.z_absmax : 0.f;
   // sums over the workgroup of up to 2 * MT values at once (one LDS round for all rows)
   auto block_sums = [&](float (&a)[MT]) {
 #pragma unroll
@@ -1938,6 +1938,14 @@ __global__ __launch_bounds__(256) void gemv_ln_kernel(const GemvLnArgs q) {
       else unpack8<T>(zr[m][u], tv[m][u]);
     }
   if (has_post) {                 // t = residual + LN_post(z), rounded where ln_fwd_kernel rounds
+    if (!q.z_absmax) {            // max |z| over all rows taken here (see gemv2_ln_kernel)
+      uint32_t zpk = 0u;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) zpk = absmax_pk8(zpk, zr[m][u]);
+      zamax = absmax_pk_block<T>(zpk, redm);
+    }
     const float c = zamax * 0.125f;
     const float eps_p = q.eps * c * c;
     float s[MT], qq[MT];
@@ -2457,7 +2465,7 @@ extern "C" int cogv_gemv_ln(const cogv_gemm_desc* d, const cogv_ln_prologue* ln,
   if (d->trans_a || d->trans_b || a.g.M > GEMV_MAX_M || (a.g.K & 511) || a.g.K > 4096 || (a.g.N & 7) || (a.g.ldb & 7)) return COGV_ERR_UNSUPPORTED;
   if (d->flags & (COGV_EPI_COLSUM | COGV_EPI_ACCUM | COGV_EPI_DGELU | COGV_EPI_MULAUX | COGV_EPI_DROPOUT) || d->out_f32 || d->splitk > 1) return COGV_ERR_UNSUPPORTED;
   if (!ln->z || !ln->gamma || !ln->beta) return COGV_ERR_ARG;
-  if (ln->gamma_post && (!ln->beta_post || !ln->residual || !ln->z_absmax)) return COGV_ERR_ARG;
+  if (ln->gamma_post && (!ln->beta_post || !ln->residual)) return COGV_ERR_ARG;
   if (((uintptr_t)ln->z | (uintptr_t)ln->gamma | (uintptr_t)ln->beta | (uintptr_t)ln->gamma_post | (uintptr_t)ln->beta_post |
        (uintptr_t)ln->residual | (uintptr_t)ln->t_out) & 15) return COGV_ERR_ARG;
   a.z = ln->z; a.z_absmax = ln->z_absmax; a.gamma_p = ln->gamma_post; a.beta_p = ln->beta_post; a.res = ln->residual;

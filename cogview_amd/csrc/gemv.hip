@@ -65,8 +65,15 @@ __device__ __forceinline__ void gv2_compute(const u32x4 (&w)[KCMAX * J], const T
 }
 
 // wave sums -> LDS -> lane 0 of wave g runs the fused epilogue on columns n0 + 8g .. + 7 (g < 4J / 8), rows in order
+// The tail of these launches is a chain of dependent latencies on one lane, so the bias it needs is requested ahead
+// (bias_pre: gv2_bias).  A requested abs-max (COGV_EPI_ABSMAX) still costs the tail a memory-side read + atomic per finishing
+// lane; the decode chain does not ask for it any more (the consuming launch's LayerNorm prologue takes max|z| itself:
+// cogv_ln_prologue.z_absmax = NULL).  Measured with one returning-nothing atomic per lane instead of atomic_max_nonneg's
+// "read first": the 320 workgroups of the 4h -> h launch finish together and their same-address atomics serialise,
+// 14.6 -> 16.2 us (profiles/r04_decode_gemv2_kernel_stats*.csv).
 template <typename T, int J, int MT>
-__device__ __forceinline__ void gv2_finish(const GemmArgs& p, float (&acc)[MT][J], float (*outp)[4 * J], int n0, int lane, int wave) {
+__device__ __forceinline__ void gv2_finish(const GemmArgs& p, float (&acc)[MT][J], float (*outp)[4 * J], int n0, int lane, int wave,
+                                           const u32x4& bias_pre) {
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -84,7 +91,7 @@ __device__ __forceinline__ void gv2_finish(const GemmArgs& p, float (&acc)[MT][J
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = outp[m][wave * 8 + i];
-        am = absmax_pk(am, epilogue8<T>(p, m, n, v));
+        am = absmax_pk(am, epilogue8<T>(p, m, n, v, &bias_pre));
       }
       if (p.flags & COGV_EPI_ABSMAX) {
         const uint32_t wv = max(am & 0xffffu, am >> 16);
@@ -96,6 +103,26 @@ __device__ __forceinline__ void gv2_finish(const GemmArgs& p, float (&acc)[MT][J
 
 // the wave's first weight row: N % 8 == 0 and J | 8, so a wave's J columns are all inside N or all outside; a wave outside
 // re-reads the last J rows (its results are never stored)
+// a zero the compiler cannot see through, in a vector register: added to a wave-uniform address it keeps the load on the
+// vector memory path (see gv2_bias)
+__device__ __forceinline__ int gv2_vzero() {
+  int zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+  return zero;
+}
+
+// bias of the 8 columns lane 0 of this wave finishes (gv2_finish), requested with the kernel's first loads.  Unconditional:
+// without a bias (or in a wave that finishes nothing) a valid stand-in address is read and the value ignored.
+template <typename T>
+__device__ __forceinline__ u32x4 gv2_bias(const GemmArgs& p, int n0, int wave) {
+  const int n = n0 + wave * 8;
+  const T* src = (p.flags & COGV_EPI_BIAS) ? reinterpret_cast<const T*>(p.bias) : reinterpret_cast<const T*>(p.B);
+  // through the VECTOR memory path (an offset the compiler cannot see through): as a wave-uniform address this would become a
+  // scalar load, and the scalar counter has to reach zero -- for the kernel arguments -- before the first weight load can be
+  // issued: the weight stream would start one memory latency late
+  return gload16(src + (n < p.N ? n : p.N - 8) + gv2_vzero());
+}
+
 template <int J>
 __device__ __forceinline__ int gv2_first_row(int n0, int wave, int N) {
   const int nw = n0 + wave * J;
@@ -125,6 +152,7 @@ __global__ __launch_bounds__(256) void gemv2_kernel(const GemmArgs p) {
       if (v < nvec) xr[m][u] = gload16(A + (size_t)row * p.lda + v * 8);
     }
   }
+  const u32x4 bias_pre = gv2_bias<T>(p, n0, wave);
   const T* Bw = reinterpret_cast<const T*>(p.B) + (size_t)gv2_first_row<J>(n0, wave, p.N) * p.ldb;
   u32x4 w[KCMAX * J];
   gv2_issue<T, J, KCMAX, 0, KCMAX * J, GUARD>(w, Bw, (size_t)p.ldb, kc, lane);
@@ -142,7 +170,7 @@ __global__ __launch_bounds__(256) void gemv2_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[m][j] = 0.f;
   gv2_compute<T, J, KCMAX, MT, GUARD>(w, xs, K, kc, lane, acc);
-  gv2_finish<T, J, MT>(p, acc, outp, n0, lane, wave);
+  gv2_finish<T, J, MT>(p, acc, outp, n0, lane, wave, bias_pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -199,6 +227,7 @@ __global__ __launch_bounds__(256) void gemv2_attn_kernel(const GemmArgs p, const
     }
   }
   gv2_issue<T, J, KCMAX, PRE, NS, GUARD>(w, Bw, (size_t)p.ldb, kc, lane);
+  const u32x4 bias_pre = gv2_bias<T>(p, n0, wave);
   __syncthreads();
   float acc[MT][J];
 #pragma unroll
@@ -206,7 +235,7 @@ __global__ __launch_bounds__(256) void gemv2_attn_kernel(const GemmArgs p, const
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[m][j] = 0.f;
   gv2_compute<T, J, KCMAX, MT, GUARD>(w, xs, K, kc, lane, acc);
-  gv2_finish<T, J, MT>(p, acc, outp, n0, lane, wave);
+  gv2_finish<T, J, MT>(p, acc, outp, n0, lane, wave, bias_pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -215,8 +244,10 @@ __global__ __launch_bounds__(256) void gemv2_attn_kernel(const GemmArgs p, const
 // of mpu/sparse_transformer.py:314-342 inside every workgroup; same arithmetic and rounding points).  K <= 4096: a thread owns
 // the 8-element vectors v = tid and tid + 256.  With up to two rows the whole weight stream of the wave is requested in
 // front of the prologue; with more rows the prologue's registers leave room for the first 8 slots only.
+// (one row: three waves per SIMD -- 168 registers -- so that the 640 workgroups of the h -> 4h launch are resident at once)
 template <typename T, int MT, bool SF, int J, int KCMAX, bool GUARD>
-__global__ __launch_bounds__(256) void gemv2_ln_kernel(const GemvLnArgs q) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3 : 1)))
+void gemv2_ln_kernel(const GemvLnArgs q) {
   typedef Row8<T, SF> SR;                // a stream row slice
   extern __shared__ __attribute__((aligned(16))) char gv2_smem[];           // x_in [MT][K] as T
   __shared__ float part[4][MT][8];
@@ -257,12 +288,14 @@ __global__ __launch_bounds__(256) void gemv2_ln_kernel(const GemvLnArgs q) {
       rr[m][u] = SR::ld(rsrc, (size_t)row * K + v * 8);
     }
   }
-  const float zamax = q.z_absmax ? *q.z_absmax : 0.f;
+  // (the published abs-max of z: a vector load as well, for gv2_bias's reason)
+  const float zamax_raw = *((const COGV_GLOBAL float*)(q.z_absmax ? q.z_absmax : reinterpret_cast<const float*>(q.gamma)) + gv2_vzero());
   const int n0 = blockIdx.x * 4 * J;
   const T* Bw = reinterpret_cast<const T*>(p.B) + (size_t)gv2_first_row<J>(n0, wave, p.N) * p.ldb;
   constexpr int NS = KCMAX * J, PRE = MT <= 2 ? NS : (NS < 8 ? NS : 8);
   u32x4 w[NS];
   gv2_issue<T, J, KCMAX, 0, PRE, GUARD>(w, Bw, (size_t)p.ldb, kc, lane);
+  float zamax = q.z_absmax ? zamax_raw : 0.f;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const bool ok = u ? ok1 : ok0;
@@ -298,6 +331,16 @@ __global__ __launch_bounds__(256) void gemv2_ln_kernel(const GemvLnArgs q) {
       else unpack8<T>(zr[m][u], tv[m][u]);
     }
   if (has_post) {                 // t = residual + LN_post(z), rounded where ln_fwd_kernel rounds
+    if (!q.z_absmax) {
+      // max |z| over all rows taken HERE instead of published by z's producer: the vectors are in registers anyway, and the
+      // producer (a skinny-M launch whose workgroups all finish together) is spared a burst of same-address atomics in its tail
+      uint32_t zpk = 0u;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) zpk = absmax_pk8(zpk, zr[m][u]);        // rows >= M and vectors past K are zero
+      zamax = absmax_pk_block<T>(zpk, redm);
+    }
     const float c = zamax * 0.125f;
     const float eps_p = q.eps * c * c;
     float s[MT], qq[MT];
@@ -411,6 +454,9 @@ __global__ __launch_bounds__(256) void gemv2_ln_kernel(const GemvLnArgs q) {
     }
   }
   gv2_issue<T, J, KCMAX, PRE, NS, GUARD>(w, Bw, (size_t)p.ldb, kc, lane);
+  // the epilogue's bias: requested here, behind the weights (it is needed after the last of them; the prologue's registers are
+  // free again), still far ahead of its use
+  const u32x4 bias_pre = gv2_bias<T>(p, n0, wave);
   __syncthreads();
   // ---- the matrix-vector product proper
   float acc[MT][J];
@@ -419,7 +465,7 @@ __global__ __launch_bounds__(256) void gemv2_ln_kernel(const GemvLnArgs q) {
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[m][j] = 0.f;
   gv2_compute<T, J, KCMAX, MT, GUARD>(w, xs, K, kc, lane, acc);
-  gv2_finish<T, J, MT>(p, acc, outp, n0, lane, wave);
+  gv2_finish<T, J, MT>(p, acc, outp, n0, lane, wave, bias_pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

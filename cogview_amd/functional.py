@@ -773,21 +773,23 @@ def decode_chain(tr, h0, absmax0, slots, emb_weight):
                              layer.input_layernorm.bias, eps, z_absmax, post, res, want_t=post is not None)
         if x is None:
             x = z
-        slot_ao = ops.new_absmax_slot(dev)
+        # (round 4) the Sandwich scale of the two branch outputs, max|ao| and max|mo|, is taken by the CONSUMING launch's LayerNorm
+        # prologue from the vector it holds anyway (z_absmax=None) instead of being published by the producing matrix-vector
+        # launch through an atomic: same value, and the producers' workgroups -- which all finish together -- end without a
+        # burst of same-address atomics
         if hp % 512 == 0 and _decode_fuse_combine():
             # the key splits' partials are combined in the prologue of the attention-output GEMV (one launch less)
             parts = ops.attention_decode(qkv.view(b, 1, 3 * hp), slot.cache, slot.pos_index, npp, combine=False)
-            ao = ops.gemv_attn(parts, b, npp, slot.cache.shape[1], att_m.dense.weight, bias=att_m.dense.bias, absmax=slot_ao)
+            ao = ops.gemv_attn(parts, b, npp, slot.cache.shape[1], att_m.dense.weight, bias=att_m.dense.bias)
         else:
             att = ops.attention_decode(qkv.view(b, 1, 3 * hp), slot.cache, slot.pos_index, npp)
-            ao = ops.gemm(att.view(b, hp), att_m.dense.weight, bias=att_m.dense.bias, absmax=slot_ao)
+            ao = ops.gemm(att.view(b, hp), att_m.dense.weight, bias=att_m.dense.bias)
         slot.out = slot.cache
         g, y = ops.gemv_ln(ao, mlp_m.dense_h_to_4h.weight, mlp_m.dense_h_to_4h.bias, layer.post_attention_layernorm.weight,
-                           layer.post_attention_layernorm.bias, eps, slot_ao,
+                           layer.post_attention_layernorm.bias, eps, None,
                            (layer.third_layernorm.weight, layer.third_layernorm.bias), x, want_t=True, gelu=True)
-        slot_mo = ops.new_absmax_slot(dev)
-        mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias, absmax=slot_mo)
-        z, z_absmax, post, res = mo, slot_mo, (layer.fourth_layernorm.weight, layer.fourth_layernorm.bias), y
+        mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias)
+        z, z_absmax, post, res = mo, None, (layer.fourth_layernorm.weight, layer.fourth_layernorm.bias), y
     fl = tr.final_layernorm
     logits, _ = ops.gemv_ln(z, emb_weight, None, fl.weight, fl.bias, fl.eps, z_absmax, post, res)
     return logits.view(b, 1, emb_weight.shape[0])

@@ -106,7 +106,8 @@ int cogv_gemm_pick_splitk_tiles(int tiles_256x256, int K);
  * i.e. mpu/sparse_transformer.py:326-341 -- `x + LN3(attn)` feeding `LN2`, or `y + LN4(mlp)` feeding the next layer's
  * `LN1` / the final LayerNorm -- fused into the GEMV that consumes it (every workgroup recomputes the few-KB vectors;
  * four Sandwich-LN launches per layer disappear from a decode step).  |t|max is taken over all M rows.  z_absmax: device
- * scalar with max|z| (required with a post-LN; for a plain input it is used as |t|max when given). */
+ * scalar with max|z| as z's producer published it (COGV_EPI_ABSMAX), or NULL: the kernel then takes max|z| itself (post-LN
+ * form; same value, no atomics in the producer's tail) / max|t| (plain input). */
 typedef struct cogv_ln_prologue {
   const void* z; const float* z_absmax;
   const void* gamma_post; const void* beta_post; const void* residual; void* t_out;

@@ -851,6 +851,10 @@ def test_gemv_with_layernorm_prologue(ops, dtype, M, K, N, post, gelu):
                          residual=resd if post else None, want_t=post, gelu=gelu, absmax=slot)
     if post:
         assert torch.equal(t, t_ref), "the residual stream written by workgroup 0 must equal the LayerNorm kernel's"
+        # max|z| taken inside the kernel (z_absmax=None: what the decode chain does) == the published scalar, bit for bit
+        out2, t2 = ops.gemv_ln(zd, dev(w), dev(bias), dev(gn), dev(bn), eps, z_absmax=None, post=(dev(gp), dev(bp)), residual=resd,
+                               want_t=True, gelu=gelu)
+        assert torch.equal(out2, out) and torch.equal(t2, t)
     assert rel(out, out_ref.float().cpu()) < 2e-3 if dtype == torch.float16 else rel(out, out_ref.float().cpu()) < 1.5e-2
     assert abs(slot.item() - slot_ref.item()) <= 2e-2 * max(1.0, slot_ref.item())
     # oracle definition

@@ -196,6 +196,9 @@ def test_gemv_layernorm_prologue_on_the_fp32_stream(ops, dtype, M, K, N, post, g
                          residual=resd if post else None, want_t=post, gelu=gelu)
     if post:
         assert t.dtype == torch.float32 and rel(t, t_ref) < 1e-6
+        out2, t2 = ops.gemv_ln(zd, w.cuda(), bias.cuda(), gn.cuda(), bn.cuda(), eps, z_absmax=None, post=(gp.cuda(), bp.cuda()),
+                               residual=resd, want_t=True, gelu=gelu)                 # max|z| taken inside the kernel
+        assert torch.equal(out2, out) and torch.equal(t2, t)
     assert out.dtype == dtype
     assert rel(out, out_ref) < (2e-3 if dtype == torch.float16 else 1.5e-2)
     tf = (res + O.sandwich_layernorm(z.float(), gp.float(), bp.float(), eps)) if post else z
