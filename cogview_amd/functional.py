@@ -408,6 +408,11 @@ class _Embedding(torch.autograd.Function):
         for q in (pw if dpos is not None else None, w if dtab is not None else None):
             if q is not None and getattr(q, "_cogv_arena", None) is not None:
                 q._cogv_arena[0].ensure_zeroed(q)         # the kernel adds its sums to the table: zero an untouched one first
+        # SINGLE-STREAM ASSUMPTION: the segment-sum kernel read-modify-writes the table's gradient rows without atomics (that is
+        # what makes it deterministic), so nothing else may touch dtab / dpos while it runs.  Backward runs on one stream (the
+        # data-parallel exchange only reads a bucket after on_backward_done recorded its event); the tied logits GEMM's weight
+        # gradient lands in the same rows EARLIER on that stream.  Hot ids (a pad token repeated ~1k times) are summed row by
+        # row by one workgroup per 2048-column slab: correct, input-dependent tail of ~0.1 ms (embedding row).
         ops.embedding_bwd(dout, ids, dtab, ctx.vocab_start, pos_ids, dpos, dropout=ctx.drop)
         return None, None, None, None, None, None, None
 

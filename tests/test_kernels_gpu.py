@@ -170,6 +170,31 @@ def test_gemm_gelu_dgelu_epilogues(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(320, 512, 128), (1088, 2560, 256), (5, 512, 1024)])
+def test_gelu_epilogue_forms_differ_by_at_most_one_rounding_of_the_preactivation(ops, dtype, M, N, K):
+    """The three GeLU epilogue forms and their rounding points ("Rounding points of GeLU"): the training form
+    (stored derivative, COGV_EPI_GELU_DAUX) and the inference form (nothing stored) evaluate the activation on the fp32
+    pre-activation -- identical bits; the stored-pre-activation form (and the reference: fp16 Linear output, then gelu,
+    mpu/sparse_transformer.py:172-179, :239-244) evaluates it on the pre-activation ROUNDED to the storage type.  The two families
+    therefore differ by at most the effect of that one rounding: |d gelu| <= max|gelu'| (1.13) * half an ulp of the pre-activation,
+    plus the output's own rounding -- bounded here element by element."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, bias = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 0.2), rnd((N,), dtype, g)
+    daux = torch.empty((M, N), dtype=dtype, device="cuda")
+    aux = torch.empty((M, N), dtype=dtype, device="cuda")
+    train = ops.gemm(dev(a), dev(w), bias=dev(bias), gelu=True, gelu_daux=daux)
+    infer = ops.gemm(dev(a), dev(w), bias=dev(bias), gelu=True)
+    stored = ops.gemm(dev(a), dev(w), bias=dev(bias), gelu=True, gelu_aux=aux)
+    assert torch.equal(train, infer)
+    eps = 2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8            # half an ulp, relative
+    u = aux.float().abs()
+    bound = 1.13 * eps * u + eps * stored.float().abs() * 2 + 1e-7          # pre-activation rounding through gelu' + two output roundings
+    diff = (train.float() - stored.float()).abs()
+    assert bool((diff <= bound).all()), float((diff - bound).max())
+    assert rel(train, stored) < (6e-4 if dtype == torch.float16 else 5e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(320, 512, 128), (1088, 1024, 256), (300, 136, 72)])
 def test_gemm_stored_gelu_derivative_epilogues(ops, dtype, M, N, K):
     """COGV_EPI_GELU_DAUX / COGV_EPI_MULAUX (the fused layer's pair): the forward epilogue stores gelu'(pre-activation)

@@ -16,7 +16,9 @@ tokens = torch.randint(0, 58219, (1, pre + steps), device="cuda")
 pos = torch.arange(pre + steps, device="cuda").unsqueeze(0)
 from cogview_amd.generation import GraphDecoder
 model = FP16_Module(GPT2Model(L, V, h, heads, 0.1, 0.1, 0.1, 1089, 1089, False).cuda(), dtype=torch.bfloat16, keep_half_outputs=True).eval()
-dec = GraphDecoder(model, batch=1, capacity=1152)
+B = int(os.environ.get("MB_DECODE_BATCH", "1"))
+tokens, pos = tokens.expand(B, -1).contiguous(), pos.expand(B, -1).contiguous()
+dec = GraphDecoder(model, batch=B, capacity=1152)
 with torch.no_grad():
     dec.prefill(tokens[:, :pre], pos[:, :pre])
     for mode in ("eager fixed-capacity step", "captured graph"):
@@ -29,7 +31,7 @@ with torch.no_grad():
             lg = dec.step(tokens[:, pre:pre + 1], pos[:, pre:pre + 1])
             nxt = lg[:, -1].float().argmax(-1)                   # consume the logits on the device, as a sampler would
         torch.cuda.synchronize(); dt = (time.time() - t0) / 20
-        print(f"GraphDecoder {mode}: decode {dt*1e3:.2f} ms/token at memory length ~{pre}", flush=True)
+        print(f"GraphDecoder {mode}: decode {dt*1e3:.2f} ms/token at memory length ~{pre}" + (f" (batch {B})" if B > 1 else ""), flush=True)
 del model, dec
 torch.cuda.empty_cache()
 if os.environ.get("MB_DECODE_GRAPH_ONLY") == "1":
