@@ -16,10 +16,14 @@
 // The small loads go first so that the prologue starts as soon as THEY arrive and runs while the weights stream in.
 // The per-lane accumulation runs over the chunks in ascending order (fp32 fmaf chain), then one DPP wave sum per
 // (row, column): no cross-wave reduction.  Lane 0 of the first NW * J / 8 waves runs the shared fused epilogue on 8 columns.
-// One row (M = 1): workgroups of NW = 4 waves; 2 .. 8 rows: NW = 8 waves -- the LayerNorm prologue then holds ONE 8-element
-// vector per thread and row instead of two, so that its registers leave room for the weight requests and a workgroup per CU
-// (the whole launch) is resident; with 4 waves the two-row form already fell to two waves per SIMD and a second round of
-// workgroups (profiles/r04_decode_batch_2_4_8_gemv2_ab.log: 2.78 ms per token at one row, 4.34 at two).
+// That is the form for ONE row (FormV: fp32 fmaf chains on the vector ALU).  With 2 .. 8 rows its accumulators, unpacked x rows
+// and weight slots no longer fit next to each other: the kernels fell to one or two waves per SIMD, a second round of
+// workgroups, and in places spilled INSIDE the request phase (profiles/r04_decode_batch_*: 2.77 ms per token at one row, 3.48 /
+// 4.88 / 9.29 at 2 / 4 / 8).  Rows 2 .. 8 therefore take FormM: the same weight stream, but the products go to the matrix
+// core -- v_mfma_f32_16x16x32 with the WEIGHTS as the A operand (a lane's 16-byte load IS its fragment: column n0 + lane % 16,
+// contraction slots 8 (lane / 16) ..), the x rows as B (from LDS, rows past M are don't-care columns of the result) and a
+// 16 x 16 accumulator of 4 registers per lane whatever the row count.  A workgroup owns 16 columns; its waves split the 32-deep
+// contraction steps (in pairs: one 128-byte line of a weight row) round robin and their partial tiles meet in LDS in wave order.
 // The three kernels use the same association for the same K, so the combine-prologue form and the two-launch form of the
 // attention-output projection still agree bit for bit (tests/test_kernels_gpu.py).
 //
@@ -33,51 +37,6 @@
 
 namespace {
 
-// slot s of a wave = (chunk c = s / J, column j = s % J): chunk-major, the order the dot products consume them.  Columns past N
-// (a wave at the ragged end of the matrix) re-read the last row; their results are never stored.
-template <typename T, int J, int KCMAX, int S0, int S1, bool GUARD>
-__device__ __forceinline__ void gv2_issue(u32x4 (&w)[KCMAX * J], const T* B, size_t ldb, int nw, int N, int kc, int lane) {
-#pragma unroll
-  for (int s = S0; s < S1; ++s) {
-    const int c = s / J, j = s % J;
-    const int n = nw + j < N ? nw + j : N - 1;
-    if (!GUARD || c < kc) w[s] = gload16(B + (size_t)n * ldb + c * 512 + lane * 8);
-  }
-}
-
-// acc[m][j] += sum over this lane's 8 elements of every chunk: x rows from LDS (16 bytes per lane and row, conflict-free).
-// Rows in groups of four (the unpacked x of eight rows next to the weight slots would not fit the register file of a
-// 512-thread workgroup); a column's sum is the same fmaf chain whatever the grouping.
-template <typename T, int J, int KCMAX, int MT, bool GUARD>
-__device__ __forceinline__ void gv2_compute(const u32x4 (&w)[KCMAX * J], const T* xs, int K, int kc, int lane, float (&acc)[MT][J]) {
-  constexpr int MG = MT < 4 ? MT : 4;
-#pragma unroll
-  for (int c = 0; c < KCMAX; ++c) {
-    if (!GUARD || c < kc) {
-#pragma unroll
-      for (int m0 = 0; m0 < MT; m0 += MG) {
-        float x[MG][8];
-#pragma unroll
-        for (int m = 0; m < MG; ++m) unpack8<T>(*reinterpret_cast<const u32x4*>(xs + (size_t)(m0 + m) * K + c * 512 + lane * 8), x[m]);
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-          float wf[8];
-          unpack8<T>(w[c * J + j], wf);
-#pragma unroll
-          for (int m = 0; m < MG; ++m) {
-            float t = acc[m0 + m][j];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t = fmaf(x[m][e], wf[e], t);
-            acc[m0 + m][j] = t;
-          }
-        }
-        // (four and eight rows: keep the scheduler from hoisting every chunk's LDS reads to the top -- 160 registers of x)
-        if (MT >= 4) __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-}
-
 // a zero the compiler cannot see through, in a vector register: added to a wave-uniform address it keeps the load on the
 // vector memory path (see gv2_bias)
 __device__ __forceinline__ int gv2_vzero() {
@@ -86,68 +45,187 @@ __device__ __forceinline__ int gv2_vzero() {
   return zero;
 }
 
-// bias of the 8 columns lane 0 of this wave finishes (gv2_finish), requested ahead of its use.  Unconditional: without a bias
-// (or in a wave that finishes nothing) a valid stand-in address is read and the value ignored.
+// bias of the 8 columns n .. n + 7 a finishing lane will need, requested ahead of its use.  Unconditional: without a bias (or
+// in a lane that finishes nothing) a valid stand-in address is read and the value ignored.
+// Through the VECTOR memory path (an offset the compiler cannot see through): as a wave-uniform address this would become a
+// scalar load, and the scalar counter has to reach zero -- for the kernel arguments -- before the first weight load can be
+// issued: the weight stream would start one memory latency late.
 template <typename T>
-__device__ __forceinline__ u32x4 gv2_bias(const GemmArgs& p, int n0, int wave) {
-  const int n = n0 + wave * 8;
+__device__ __forceinline__ u32x4 gv2_bias(const GemmArgs& p, int n) {
   const T* src = (p.flags & COGV_EPI_BIAS) ? reinterpret_cast<const T*>(p.bias) : reinterpret_cast<const T*>(p.B);
-  // through the VECTOR memory path (an offset the compiler cannot see through): as a wave-uniform address this would become a
-  // scalar load, and the scalar counter has to reach zero -- for the kernel arguments -- before the first weight load can be
-  // issued: the weight stream would start one memory latency late
   return gload16(src + (n < p.N ? n : p.N - 8) + gv2_vzero());
 }
 
-// wave sums -> LDS -> lane 0 of wave g runs the fused epilogue on columns n0 + 8g .. + 7 (g < NW * J / 8), rows in order.
-// The tail of these launches is a chain of dependent latencies on one lane, so the bias it needs is requested ahead
-// (bias_pre: gv2_bias).  A requested abs-max (COGV_EPI_ABSMAX) still costs the tail a memory-side read + atomic per finishing
-// lane; the decode chain does not ask for it any more (the consuming launch's LayerNorm prologue takes max|z| itself:
-// cogv_ln_prologue.z_absmax = NULL).  Measured with one returning-nothing atomic per lane instead of atomic_max_nonneg's
-// "read first": the 320 workgroups of the 4h -> h launch finish together and their same-address atomics serialise,
-// 14.6 -> 16.2 us (profiles/r04_decode_gemv2_kernel_stats*.csv).
-template <typename T, int J, int MT, int NW>
-__device__ __forceinline__ void gv2_finish(const GemmArgs& p, float (&acc)[MT][J], float (*outp)[NW * J], int n0, int lane, int wave,
-                                           const u32x4& bias_pre) {
+// =====================================================================================================================
+// FormV: one row (MT = 1; the row-count template parameter is kept general).  A wave owns J whole columns.
+template <typename T, int J, int KCMAX, bool GUARD_, int MT, int NW_>
+struct FormV {
+  static constexpr int NW = NW_, COLS = NW_ * J, XPAD = 0, NS = KCMAX * J, XCHUNKS = KCMAX;
+  static constexpr bool GUARD = GUARD_;
+  struct Regs { u32x4 w[NS]; };
+  struct Shared { float outp[MT][NW_ * J]; };
+  // slot s of a wave = (chunk c = s / J, column j = s % J): chunk-major, the order the dot products consume them.  Columns
+  // past N (a wave at the ragged end of the matrix) re-read the last row; their results are never stored.
+  template <int S0, int S1>
+  static __device__ __forceinline__ void issue(Regs& r, const GemmArgs& p, int n0, int K, int wave, int lane) {
+    const T* B = reinterpret_cast<const T*>(p.B);
+    const int nw = n0 + wave * J, kc = K >> 9;
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const float t = wave_sum_uniform(acc[m][j]);
-      if (lane == 0) outp[m][wave * J + j] = t;
+    for (int s = S0; s < S1; ++s) {
+      const int c = s / J, j = s % J;
+      const int n = nw + j < p.N ? nw + j : p.N - 1;
+      if (!GUARD || c < kc) r.w[s] = gload16(B + (size_t)n * p.ldb + c * 512 + lane * 8);
     }
-  __syncthreads();
-  constexpr int NG = (NW * J) / 8;
-  if (lane == 0 && wave < NG) {
-    const int n = n0 + wave * 8;
-    if (n < p.N) {
-      uint32_t am = 0u;
-      for (int m = 0; m < p.M && m < MT; ++m) {
-        float v[8];
+  }
+  static __device__ __forceinline__ u32x4 bias(const GemmArgs& p, int n0, int wave, int lane) { return gv2_bias<T>(p, n0 + wave * 8); }
+  // acc[m][j] += sum over this lane's 8 elements of every chunk (ascending): x rows from LDS, 16 bytes per lane and row; then
+  // one DPP wave sum per (row, column), LDS, and lane 0 of wave g runs the fused epilogue on columns n0 + 8g .. + 7.
+  // The tail of these launches is a chain of dependent latencies on one lane, so the bias it needs is requested ahead.  A
+  // requested abs-max (COGV_EPI_ABSMAX) still costs the tail a memory-side read + atomic per finishing lane; the decode chain
+  // does not ask for it any more (cogv_ln_prologue.z_absmax = NULL).  Measured with one returning-nothing atomic per lane
+  // instead of atomic_max_nonneg's "read first": the 320 workgroups of the 4h -> h launch finish together and their
+  // same-address atomics serialise, 14.6 -> 16.2 us (profiles/r04_decode_gemv2_kernel_stats*.csv).
+  static __device__ __forceinline__ void product(const Regs& r, const GemmArgs& p, const T* xs, int XS, int K, Shared& sh, int n0, int wave,
+                                                 int lane, const u32x4& bias_pre) {
+    const int kc = K >> 9;
+    float acc[MT][J];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = outp[m][wave * 8 + i];
-        am = absmax_pk(am, epilogue8<T>(p, m, n, v, &bias_pre));
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < J; ++j) acc[m][j] = 0.f;
+#pragma unroll
+    for (int c = 0; c < KCMAX; ++c) {
+      if (!GUARD || c < kc) {
+        float x[MT][8];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) unpack8<T>(*reinterpret_cast<const u32x4*>(xs + (size_t)m * XS + c * 512 + lane * 8), x[m]);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          float wf[8];
+          unpack8<T>(r.w[c * J + j], wf);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            float t = acc[m][j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t = fmaf(x[m][e], wf[e], t);
+            acc[m][j] = t;
+          }
+        }
       }
-      if (p.flags & COGV_EPI_ABSMAX) {
-        const uint32_t wv = max(am & 0xffffu, am >> 16);
-        atomic_max_nonneg(p.absmax, bits_to_f<T>((uint16_t)wv));
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const float t = wave_sum_uniform(acc[m][j]);
+        if (lane == 0) sh.outp[m][wave * J + j] = t;
+      }
+    __syncthreads();
+    constexpr int NG = (NW_ * J) / 8;
+    if (lane == 0 && wave < NG) {
+      const int n = n0 + wave * 8;
+      if (n < p.N) {
+        uint32_t am = 0u;
+        for (int m = 0; m < p.M && m < MT; ++m) {
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = sh.outp[m][wave * 8 + i];
+          am = absmax_pk(am, epilogue8<T>(p, m, n, v, &bias_pre));
+        }
+        if (p.flags & COGV_EPI_ABSMAX) {
+          const uint32_t wv = max(am & 0xffffu, am >> 16);
+          atomic_max_nonneg(p.absmax, bits_to_f<T>((uint16_t)wv));
+        }
       }
     }
   }
-}
+};
+
+// =====================================================================================================================
+// FormM: 2 .. 8 rows on the matrix core.  A workgroup owns 16 columns; wave w takes the contraction-step PAIRS q = w, w + NW, ..
+// (steps 2q and 2q + 1: 64 consecutive elements = one 128-byte line of each of the 16 weight rows), L = K / 32 / NW loads
+// of 16 bytes per lane, all requested at the top like FormV's slots.
+//   A operand = weights: lane l supplies row (l & 15) -> column n0 + (l & 15), contraction slots 8 (l >> 4) .. + 7 of the step
+//   B operand = x:       lane l supplies column (l & 15) -> row m = l & 15 (lanes past the row count re-read the last row: those
+//                        result columns are never looked at), the same contraction slots, from LDS (rows padded by 16 bytes
+//                        so that the rows of one step fall into different banks)
+//   D: lane l holds C[m = l & 15][n0 + 4 (l >> 4) + i], i = 0 .. 3.
+// The waves' partial tiles are summed in wave order (deterministic), regrouped through LDS into 8 consecutive columns per
+// (row, half) and finished by lanes 0 .. 2M - 1 of wave 0 in parallel.
+template <typename T, int NW_, int LMAX, bool GUARD_, int MT>
+struct FormM {
+  static constexpr int NW = NW_, COLS = 16, XPAD = 8, NS = LMAX, XCHUNKS = (LMAX * NW_ * 32 + 511) / 512;
+  static constexpr bool GUARD = GUARD_;
+  struct Regs { u32x4 w[LMAX]; };
+  struct Shared { f32x4 red[NW_][64]; float outp[16][16]; uint32_t am[64]; };
+  static __device__ __forceinline__ int kstep(int wave, int i) { return 2 * (wave + NW_ * (i >> 1)) + (i & 1); }
+  template <int S0, int S1>
+  static __device__ __forceinline__ void issue(Regs& r, const GemmArgs& p, int n0, int K, int wave, int lane) {
+    const int L = K / (32 * NW_);
+    const int n = n0 + (lane & 15) < p.N ? n0 + (lane & 15) : p.N - 1;
+    const T* row = reinterpret_cast<const T*>(p.B) + (size_t)n * p.ldb + (lane >> 4) * 8;
+#pragma unroll
+    for (int i = S0; i < S1; ++i)
+      if (!GUARD || i < L) r.w[i] = gload16(row + 32 * kstep(wave, i));
+  }
+  // lanes 0 .. 15 of wave 0 finish: lane t -> row t >> 1, columns n0 + 8 (t & 1) ..
+  static __device__ __forceinline__ u32x4 bias(const GemmArgs& p, int n0, int wave, int lane) { return gv2_bias<T>(p, n0 + (lane & 1) * 8); }
+  static __device__ __forceinline__ void product(const Regs& r, const GemmArgs& p, const T* xs, int XS, int K, Shared& sh, int n0, int wave,
+                                                 int lane, const u32x4& bias_pre) {
+    typedef typename HT<T>::v8 v8;
+    const int L = K / (32 * NW_);
+    const int mrow = (lane & 15) < MT ? (lane & 15) : MT - 1;
+    const T* xrow = xs + (size_t)mrow * XS + (lane >> 4) * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) {
+      if (!GUARD || i < L) {
+        const v8 b = *reinterpret_cast<const v8*>(xrow + 32 * kstep(wave, i));
+        acc = HT<T>::mfma16(__builtin_bit_cast(v8, r.w[i]), b, acc);
+      }
+    }
+    sh.red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      f32x4 s = sh.red[0][lane];
+#pragma unroll
+      for (int w = 1; w < NW_; ++w) s += sh.red[w][lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sh.outp[lane & 15][(lane >> 4) * 4 + i] = s[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int m = lane >> 1, n = n0 + (lane & 1) * 8;
+      uint32_t am = 0u;
+      if (m < p.M && m < MT && n < p.N) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = sh.outp[m][(lane & 1) * 8 + i];
+        am = epilogue8<T>(p, m, n, v, &bias_pre);
+      }
+      if (p.flags & COGV_EPI_ABSMAX) {
+        uint32_t wv = max(am & 0xffffu, am >> 16);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wv = max(wv, (uint32_t)__shfl_xor((int)wv, o, 64));
+        if (lane == 0) atomic_max_nonneg(p.absmax, bits_to_f<T>((uint16_t)wv));
+      }
+    }
+  }
+};
 
 // ---------------------------------------------------------------------------------------------------------------------
 // plain form: X = A (rows of the storage type, a few KB, L2-resident)
-template <typename T, int J, int KCMAX, bool GUARD, int MT, int NW>
-__global__ __launch_bounds__(NW * 64) void gemv2_kernel(const GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char gv2_smem[];      // x [MT][K] as T
-  __shared__ float outp[MT][NW * J];
+template <typename T, typename F, int MT>
+__global__ __launch_bounds__(F::NW * 64) void gemv2_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char gv2_smem[];      // x [MT][K + pad] as T
+  __shared__ typename F::Shared sh;
   T* xs = reinterpret_cast<T*>(gv2_smem);
-  constexpr int NT = NW * 64;
+  constexpr int NT = F::NW * 64;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int K = GUARD ? p.K : KCMAX * 512, kc = K >> 9, nvec = K >> 3;
-  const int n0 = blockIdx.x * NW * J;
+  const int K = F::GUARD ? p.K : F::XCHUNKS * 512, nvec = K >> 3, XS = K + F::XPAD;
+  const int n0 = blockIdx.x * F::COLS;
   // x rows first: the copy to LDS below waits for these loads only
-  constexpr int XV = (KCMAX * 64 + NT - 1) / NT;
+  constexpr int XV = (F::XCHUNKS * 64 + NT - 1) / NT;
   u32x4 xr[MT][XV];
   const T* A = reinterpret_cast<const T*>(p.A);
 #pragma unroll
@@ -159,24 +237,18 @@ __global__ __launch_bounds__(NW * 64) void gemv2_kernel(const GemmArgs p) {
       if (v < nvec) xr[m][u] = gload16(A + (size_t)row * p.lda + v * 8);
     }
   }
-  const u32x4 bias_pre = gv2_bias<T>(p, n0, wave);
-  u32x4 w[KCMAX * J];
-  gv2_issue<T, J, KCMAX, 0, KCMAX * J, GUARD>(w, reinterpret_cast<const T*>(p.B), (size_t)p.ldb, n0 + wave * J, p.N, kc, lane);
+  const u32x4 bias_pre = F::bias(p, n0, wave, lane);
+  typename F::Regs w;
+  F::template issue<0, F::NS>(w, p, n0, K, wave, lane);
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int u = 0; u < XV; ++u) {
       const int v = threadIdx.x + NT * u;
-      if (v < nvec) *reinterpret_cast<u32x4*>(xs + (size_t)m * K + v * 8) = xr[m][u];
+      if (v < nvec) *reinterpret_cast<u32x4*>(xs + (size_t)m * XS + v * 8) = xr[m][u];
     }
   __syncthreads();
-  float acc[MT][J];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int j = 0; j < J; ++j) acc[m][j] = 0.f;
-  gv2_compute<T, J, KCMAX, MT, GUARD>(w, xs, K, kc, lane, acc);
-  gv2_finish<T, J, MT, NW>(p, acc, outp, n0, lane, wave, bias_pre);
+  F::product(w, p, xs, XS, K, sh, n0, wave, lane, bias_pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -184,19 +256,18 @@ __global__ __launch_bounds__(NW * 64) void gemv2_kernel(const GemmArgs p) {
 // gemm.hip for the partials' layout and the arithmetic: same association, att rounded to the storage type).  The waves
 // share the combine (chunk c belongs to wave c % NW) and hand the combined vector over in LDS.  Only the first weight slots
 // are requested in front of the combine: its reads of the partials would queue behind every load issued before them.
-template <typename T, int J, int KCMAX, bool GUARD, int MT, int NW>
-__global__ __launch_bounds__(NW * 64) void gemv2_attn_kernel(const GemmArgs p, const float* __restrict__ part_ws, int H, int nsplit) {
+template <typename T, typename F, int MT>
+__global__ __launch_bounds__(F::NW * 64) void gemv2_attn_kernel(const GemmArgs p, const float* __restrict__ part_ws, int H, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) char gv2_smem[];
-  __shared__ float outp[MT][NW * J];
+  __shared__ typename F::Shared sh;
   T* xs = reinterpret_cast<T*>(gv2_smem);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int K = GUARD ? p.K : KCMAX * 512, kc = K >> 9;
-  const int n0 = blockIdx.x * NW * J;
-  const T* B = reinterpret_cast<const T*>(p.B);
-  constexpr int NS = KCMAX * J, PRE = NS < 8 ? NS : 8;
-  u32x4 w[NS];
-  gv2_issue<T, J, KCMAX, 0, PRE, GUARD>(w, B, (size_t)p.ldb, n0 + wave * J, p.N, kc, lane);
-  for (int c = wave; c < kc; c += NW) {
+  const int K = F::GUARD ? p.K : F::XCHUNKS * 512, kc = K >> 9, XS = K + F::XPAD;
+  const int n0 = blockIdx.x * F::COLS;
+  constexpr int PRE = F::NS < 8 ? F::NS : 8;
+  typename F::Regs w;
+  F::template issue<0, PRE>(w, p, n0, K, wave, lane);
+  for (int c = wave; c < kc; c += F::NW) {
     const int k = (c << 9) + lane * 8;
     const int head = k >> 6, dd = k & 63;
 #pragma unroll
@@ -229,19 +300,13 @@ __global__ __launch_bounds__(NW * 64) void gemv2_attn_kernel(const GemmArgs p, c
       float x[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = o[e] / L;
-      *reinterpret_cast<u32x4*>(xs + (size_t)m * K + k) = pack8<T>(x);      // the attention output in its storage type
+      *reinterpret_cast<u32x4*>(xs + (size_t)m * XS + k) = pack8<T>(x);     // the attention output in its storage type
     }
   }
-  gv2_issue<T, J, KCMAX, PRE, NS, GUARD>(w, B, (size_t)p.ldb, n0 + wave * J, p.N, kc, lane);
-  const u32x4 bias_pre = gv2_bias<T>(p, n0, wave);
+  F::template issue<PRE, F::NS>(w, p, n0, K, wave, lane);
+  const u32x4 bias_pre = F::bias(p, n0, wave, lane);
   __syncthreads();
-  float acc[MT][J];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int j = 0; j < J; ++j) acc[m][j] = 0.f;
-  gv2_compute<T, J, KCMAX, MT, GUARD>(w, xs, K, kc, lane, acc);
-  gv2_finish<T, J, MT, NW>(p, acc, outp, n0, lane, wave, bias_pre);
+  F::product(w, p, xs, XS, K, sh, n0, wave, lane, bias_pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -251,20 +316,21 @@ __global__ __launch_bounds__(NW * 64) void gemv2_attn_kernel(const GemmArgs p, c
 // NV = 512 / threads 8-element vectors (two with 4 waves, one with 8).  With up to two rows the whole weight stream of the wave
 // is requested in front of the prologue; with more rows the prologue's registers leave room for the first 8 slots only.
 // (one row: three waves per SIMD -- 168 registers -- so that the 640 workgroups of the h -> 4h launch are resident at once)
-template <typename T, int MT, bool SF, int J, int KCMAX, bool GUARD, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3 : 1)))
+template <typename T, typename F, int MT, bool SF>
+__global__ __launch_bounds__(F::NW * 64) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 3 : 1)))
 void gemv2_ln_kernel(const GemvLnArgs q) {
   typedef Row8<T, SF> SR;                // a stream row slice
-  extern __shared__ __attribute__((aligned(16))) char gv2_smem[];           // x_in [MT][K] as T
+  constexpr int NW = F::NW;
+  extern __shared__ __attribute__((aligned(16))) char gv2_smem[];           // x_in [MT][K + pad] as T
   __shared__ float part[NW][MT][2];
-  __shared__ float outp[MT][NW * J];
+  __shared__ typename F::Shared sh;
   __shared__ uint32_t redm[16];
   __shared__ float s_amax;
   constexpr int NT = NW * 64, NV = 512 / NT;
   const GemmArgs& p = q.g;
   T* xs = reinterpret_cast<T*>(gv2_smem);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int K = GUARD ? p.K : KCMAX * 512, kc = K >> 9, nvec = K >> 3;
+  const int K = F::GUARD ? p.K : F::XCHUNKS * 512, nvec = K >> 3, XS = K + F::XPAD;
   const float inv_k = 1.0f / (float)K;
   const bool has_post = q.gamma_p != nullptr;
   int vv[NV]; bool okv[NV];
@@ -297,11 +363,10 @@ void gemv2_ln_kernel(const GemvLnArgs q) {
   }
   // (the published abs-max of z: a vector load as well, for gv2_bias's reason)
   const float zamax_raw = *((const COGV_GLOBAL float*)(q.z_absmax ? q.z_absmax : reinterpret_cast<const float*>(q.gamma)) + gv2_vzero());
-  const int n0 = blockIdx.x * NW * J;
-  const T* B = reinterpret_cast<const T*>(p.B);
-  constexpr int NS = KCMAX * J, PRE = MT <= 2 ? NS : (NS < 8 ? NS : 8);
-  u32x4 w[NS];
-  gv2_issue<T, J, KCMAX, 0, PRE, GUARD>(w, B, (size_t)p.ldb, n0 + wave * J, p.N, kc, lane);
+  const int n0 = blockIdx.x * F::COLS;
+  constexpr int PRE = MT <= 2 ? F::NS : (F::NS < 8 ? F::NS : 8);
+  typename F::Regs w;
+  F::template issue<0, PRE>(w, p, n0, K, wave, lane);
   float zamax = q.z_absmax ? zamax_raw : 0.f;
 #pragma unroll
   for (int u = 0; u < NV; ++u) {
@@ -459,86 +524,76 @@ void gemv2_ln_kernel(const GemvLnArgs q) {
           float o[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] = (tv[m][u][i] - mean) * rstd * gn[u][i] + bn[u][i];
-          *reinterpret_cast<u32x4*>(xs + (size_t)m * K + vv[u] * 8) = pack8<T>(o);
+          *reinterpret_cast<u32x4*>(xs + (size_t)m * XS + vv[u] * 8) = pack8<T>(o);
         }
       }
     }
   }
-  gv2_issue<T, J, KCMAX, PRE, NS, GUARD>(w, B, (size_t)p.ldb, n0 + wave * J, p.N, kc, lane);
+  F::template issue<PRE, F::NS>(w, p, n0, K, wave, lane);
   // the epilogue's bias: requested here, behind the weights (it is needed after the last of them; the prologue's registers are
   // free again), still far ahead of its use
-  const u32x4 bias_pre = gv2_bias<T>(p, n0, wave);
+  const u32x4 bias_pre = F::bias(p, n0, wave, lane);
   __syncthreads();
   // ---- the matrix-vector product proper
-  float acc[MT][J];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int j = 0; j < J; ++j) acc[m][j] = 0.f;
-  gv2_compute<T, J, KCMAX, MT, GUARD>(w, xs, K, kc, lane, acc);
-  gv2_finish<T, J, MT, NW>(p, acc, outp, n0, lane, wave, bias_pre);
+  F::product(w, p, xs, XS, K, sh, n0, wave, lane, bias_pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// host side: the (J, chunks) class of a contraction length.  Exact classes for the widths of the model family (h = 1024:
-// K = 1024 / 4096; h = 2560: K = 2560 / 10240); any other multiple of 512 takes the guarded two-column form.  One row runs in
-// workgroups of 4 waves, 2 .. 8 rows in workgroups of 8 (GV2_NW).
+// host side.  One row: FormV, (J, chunks) classes -- exact for the widths of the model family (h = 1024: K = 1024 / 4096;
+// h = 2560: K = 2560 / 10240), any other multiple of 512 takes the guarded two-column form.  2 .. 8 rows: FormM, the waves of a
+// workgroup by K (4 up to 2560, 8 up to 5120, 16 up to 10240): at most 20 loads per lane.
 using TT = std::conditional<COGV_GEMV_TU != 0, f16_t, bf16_t>::type;
 
 inline int gv2_mt(int M) { return M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8; }
 // x rows in LDS (dynamic) + the kernels' static arrays stay inside the 64 KB a workgroup gets without an attribute; larger
-// row blocks (K = 10240 with more than two rows, K = 4096 with eight) go to the first-generation kernels
-constexpr size_t GV2_MAX_SHMEM = 60 * 1024;
-// waves per workgroup by row count, as measured on the captured 4B step (profiles/r04_decode_batch_*): 2 rows 4.34 ms per token
-// with 4 waves / 4.68 with 8; 4 rows 5.63 / 4.90; 8 rows 9.36 / 18.97 (8 waves: 256 registers per lane, spills)
-#define GV2_MT_SWITCH(mt, CALL)  \
-  do {                           \
-    if ((mt) == 1) { CALL(1, 4); }  \
-    else if ((mt) == 2) { CALL(2, 4); } \
-    else if ((mt) == 4) { CALL(4, 8); } \
-    else { CALL(8, 4); }            \
+// row blocks (K = 10240 with more than two rows) go to the first-generation kernels
+constexpr size_t GV2_MAX_SHMEM = 56 * 1024;
+
+template <int J, int KCMAX, bool G> using FV = FormV<TT, J, KCMAX, G, 1, 4>;
+template <int NW, int LMAX, bool G, int MT> using FM = FormM<TT, NW, LMAX, G, MT>;
+
+// CALL(F, MT) for 2 / 4 / 8 rows with FormM<NW, LMAX, G, MT>
+#define GV2_M_SWITCH(mt, CALL, NW_, LMAX_, G_)                        \
+  do {                                                                \
+    if ((mt) == 2) { CALL((FM<NW_, LMAX_, G_, 2>), 2); }              \
+    else if ((mt) == 4) { CALL((FM<NW_, LMAX_, G_, 4>), 4); }         \
+    else { CALL((FM<NW_, LMAX_, G_, 8>), 8); }                        \
   } while (0)
 
 }  // namespace
 
 #define GV2_CAT2(a, b) a##b
 #define GV2_CAT(a, b) GV2_CAT2(a, b)
+#define GV2_UNWRAP(...) __VA_ARGS__
 
 // C = epilogue(A B^T), M <= 8.  COGV_ERR_UNSUPPORTED: the caller falls back to the first-generation kernel.
 extern "C" __attribute__((visibility("hidden"))) int GV2_CAT(cogv_gemv2_launch_, COGV_GEMV_TU)(const void* args, void* stream) {
   const GemmArgs& a = *reinterpret_cast<const GemmArgs*>(args);
-  const int mt = gv2_mt(a.M);
-  const size_t shmem = (size_t)mt * a.K * 2;
-  if (a.M < 1 || a.M > GEMV_MAX_M || (a.K & 511) || a.K > 10240 || (a.N & 7) || shmem > GV2_MAX_SHMEM) return COGV_ERR_UNSUPPORTED;
+  const int mt = gv2_mt(a.M), kc = a.K >> 9;
+  if (a.M < 1 || a.M > GEMV_MAX_M || (a.K & 511) || a.K > 10240 || (a.N & 7)) return COGV_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define GV2_PLAIN(J_, KC_, G_, MT_, NW_)                                                                                   \
-  hipLaunchKernelGGL((gemv2_kernel<TT, J_, KC_, G_, MT_, NW_>), dim3((a.N + NW_ * J_ - 1) / (NW_ * J_)), dim3(NW_ * 64), shmem, st, a)
-#define C1024(MT_, NW_) GV2_PLAIN(8, 2, false, MT_, NW_)
-#define C2560(MT_, NW_) GV2_PLAIN(4, 5, false, MT_, NW_)
-// (K = 4096 / 10240: 16 / 40 weight slots per wave next to the accumulators -- 4 waves per workgroup whatever the row count, so
-//  that the register file of the workgroup can take what 512-thread workgroups could only spill)
-#define C4096(MT_, NW_) GV2_PLAIN(2, 8, false, MT_, 4)
-#define C10240(MT_, NW_) GV2_PLAIN(2, 20, false, MT_, 4)
-// K = 10240 with 2 rows: ONE column per wave (20 slots = 80 registers), 8 waves -- the two-column form needed 160 registers
-// of weights next to the row staging and spilled INSIDE the request phase (a spilled slot is waited for, stored, reloaded: the
-// 4h -> h launch of a two-row step took 34.8 us against 14.1 with one row).  Four rows (80 KB of x, and 640 B of spills per
-// lane even in this form) stay with the first generation.
-#define C10240W(MT_) GV2_PLAIN(1, 20, false, MT_, 8)
-#define CGEN(MT_, NW_) GV2_PLAIN(2, 20, true, MT_, NW_)
-  if (a.K == 1024) GV2_MT_SWITCH(mt, C1024);
-  else if (a.K == 2560) GV2_MT_SWITCH(mt, C2560);
-  else if (a.K == 4096) GV2_MT_SWITCH(mt, C4096);
-  else if (a.K == 10240) {
-    if (mt == 1) { C10240(1, 4); }
-    else { C10240W(2); }                 // mt <= 2 by the LDS bound
+#define GV2_PLAIN(F_, MT_)                                                                                                   \
+  do {                                                                                                                       \
+    typedef GV2_UNWRAP F_ FF;                                                                                                \
+    const size_t shmem = (size_t)MT_ * (a.K + FF::XPAD) * 2;                                                                 \
+    if (shmem > GV2_MAX_SHMEM) return COGV_ERR_UNSUPPORTED;                                                                  \
+    hipLaunchKernelGGL((gemv2_kernel<TT, FF, MT_>), dim3((a.N + FF::COLS - 1) / FF::COLS), dim3(FF::NW * 64), shmem, st, a); \
+  } while (0)
+  if (mt == 1) {
+    if (a.K == 1024) GV2_PLAIN((FV<8, 2, false>), 1);
+    else if (a.K == 2560) GV2_PLAIN((FV<4, 5, false>), 1);
+    else if (a.K == 4096) GV2_PLAIN((FV<2, 8, false>), 1);
+    else if (a.K == 10240) GV2_PLAIN((FV<2, 20, false>), 1);
+    else GV2_PLAIN((FV<2, 20, true>), 1);
+  } else {
+    if (a.K == 1024) GV2_M_SWITCH(mt, GV2_PLAIN, 4, 8, false);
+    else if (a.K == 2560) GV2_M_SWITCH(mt, GV2_PLAIN, 4, 20, false);
+    else if (a.K == 4096) GV2_M_SWITCH(mt, GV2_PLAIN, 8, 16, false);
+    else if (a.K == 10240) GV2_M_SWITCH(mt, GV2_PLAIN, 16, 20, false);
+    else if (kc <= 5) GV2_M_SWITCH(mt, GV2_PLAIN, 4, 20, true);
+    else if (kc <= 10) GV2_M_SWITCH(mt, GV2_PLAIN, 8, 20, true);
+    else return COGV_ERR_UNSUPPORTED;
   }
-  else GV2_MT_SWITCH(mt, CGEN);
-#undef C1024
-#undef C2560
-#undef C4096
-#undef C10240
-#undef C10240W
-#undef CGEN
 #undef GV2_PLAIN
   return COGV_OK;
 }
@@ -546,49 +601,59 @@ extern "C" __attribute__((visibility("hidden"))) int GV2_CAT(cogv_gemv2_launch_,
 extern "C" __attribute__((visibility("hidden"))) int GV2_CAT(cogv_gemv2_attn_launch_, COGV_GEMV_TU)(const void* args, const float* partials, int heads,
                                                                                                   int nsplit, void* stream) {
   const GemmArgs& a = *reinterpret_cast<const GemmArgs*>(args);
-  const int mt = gv2_mt(a.M);
-  const size_t shmem = (size_t)mt * a.K * 2;
-  if (a.M < 1 || a.M > GEMV_MAX_M || (a.K & 511) || a.K > 10240 || (a.N & 7) || shmem > GV2_MAX_SHMEM || nsplit > 32) return COGV_ERR_UNSUPPORTED;
+  const int mt = gv2_mt(a.M), kc = a.K >> 9;
+  if (a.M < 1 || a.M > GEMV_MAX_M || (a.K & 511) || a.K > 10240 || (a.N & 7) || nsplit > 32) return COGV_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define GV2_ATTN(J_, KC_, G_, MT_, NW_)                                                                                    \
-  hipLaunchKernelGGL((gemv2_attn_kernel<TT, J_, KC_, G_, MT_, NW_>), dim3((a.N + NW_ * J_ - 1) / (NW_ * J_)), dim3(NW_ * 64), shmem, st, \
-                     a, partials, heads, nsplit)
-#define C1024(MT_, NW_) GV2_ATTN(8, 2, false, MT_, NW_)
-#define C2560(MT_, NW_) GV2_ATTN(4, 5, false, MT_, NW_)
-#define CGEN(MT_, NW_) GV2_ATTN(2, 20, true, MT_, NW_)
-  // (a column's arithmetic does not depend on the class: chunks in ascending order per lane, one wave sum -- so this form and
-  //  cogv_gemv2_launch agree bit for bit whatever class either takes)
-  if (a.K == 1024) GV2_MT_SWITCH(mt, C1024);
-  else if (a.K == 2560) GV2_MT_SWITCH(mt, C2560);
-  else GV2_MT_SWITCH(mt, CGEN);
-#undef C1024
-#undef C2560
-#undef CGEN
+#define GV2_ATTN(F_, MT_)                                                                                                         \
+  do {                                                                                                                            \
+    typedef GV2_UNWRAP F_ FF;                                                                                                     \
+    const size_t shmem = (size_t)MT_ * (a.K + FF::XPAD) * 2;                                                                      \
+    if (shmem > GV2_MAX_SHMEM) return COGV_ERR_UNSUPPORTED;                                                                       \
+    hipLaunchKernelGGL((gemv2_attn_kernel<TT, FF, MT_>), dim3((a.N + FF::COLS - 1) / FF::COLS), dim3(FF::NW * 64), shmem, st, a,  \
+                       partials, heads, nsplit);                                                                                  \
+  } while (0)
+  // (the same classes as cogv_gemv2_launch for every (K, M): the combine-prologue form and the two-launch form of the projection
+  //  agree bit for bit -- in FormV a column's arithmetic does not even depend on the class)
+  if (mt == 1) {
+    if (a.K == 1024) GV2_ATTN((FV<8, 2, false>), 1);
+    else if (a.K == 2560) GV2_ATTN((FV<4, 5, false>), 1);
+    else GV2_ATTN((FV<2, 20, true>), 1);
+  } else {
+    if (a.K == 1024) GV2_M_SWITCH(mt, GV2_ATTN, 4, 8, false);
+    else if (a.K == 2560) GV2_M_SWITCH(mt, GV2_ATTN, 4, 20, false);
+    else if (a.K == 4096 || a.K == 10240) return COGV_ERR_UNSUPPORTED;     // (exact FormM classes of the plain form: not instantiated here)
+    else if (kc <= 5) GV2_M_SWITCH(mt, GV2_ATTN, 4, 20, true);
+    else if (kc <= 10) GV2_M_SWITCH(mt, GV2_ATTN, 8, 20, true);
+    else return COGV_ERR_UNSUPPORTED;
+  }
 #undef GV2_ATTN
   return COGV_OK;
 }
 
 extern "C" __attribute__((visibility("hidden"))) int GV2_CAT(cogv_gemv2_ln_launch_, COGV_GEMV_TU)(const void* args, int stream_f32, void* stream) {
   const GemvLnArgs& a = *reinterpret_cast<const GemvLnArgs*>(args);
-  const int mt = gv2_mt(a.g.M);
-  const size_t shmem = (size_t)mt * a.g.K * 2;
-  if (a.g.M < 1 || a.g.M > GEMV_MAX_M || (a.g.K & 511) || a.g.K > 4096 || (a.g.N & 7) || shmem > GV2_MAX_SHMEM) return COGV_ERR_UNSUPPORTED;
+  const int mt = gv2_mt(a.g.M), kc = a.g.K >> 9;
+  if (a.g.M < 1 || a.g.M > GEMV_MAX_M || (a.g.K & 511) || a.g.K > 4096 || (a.g.N & 7)) return COGV_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define GV2_LN(J_, KC_, G_, MT_, NW_)                                                                                          \
+#define GV2_LN(F_, MT_)                                                                                                          \
   do {                                                                                                                           \
-    const dim3 grid((a.g.N + NW_ * J_ - 1) / (NW_ * J_)), block(NW_ * 64);                                                       \
-    if (stream_f32) hipLaunchKernelGGL((gemv2_ln_kernel<TT, MT_, true, J_, KC_, G_, NW_>), grid, block, shmem, st, a);           \
-    else hipLaunchKernelGGL((gemv2_ln_kernel<TT, MT_, false, J_, KC_, G_, NW_>), grid, block, shmem, st, a);                     \
+    typedef GV2_UNWRAP F_ FF;                                                                                                    \
+    const size_t shmem = (size_t)MT_ * (a.g.K + FF::XPAD) * 2;                                                                   \
+    if (shmem > GV2_MAX_SHMEM) return COGV_ERR_UNSUPPORTED;                                                                      \
+    const dim3 grid((a.g.N + FF::COLS - 1) / FF::COLS), block(FF::NW * 64);                                                      \
+    if (stream_f32) hipLaunchKernelGGL((gemv2_ln_kernel<TT, FF, MT_, true>), grid, block, shmem, st, a);                         \
+    else hipLaunchKernelGGL((gemv2_ln_kernel<TT, FF, MT_, false>), grid, block, shmem, st, a);                                   \
   } while (0)
-#define C1024(MT_, NW_) GV2_LN(8, 2, false, MT_, NW_)
-#define C2560(MT_, NW_) GV2_LN(4, 5, false, MT_, NW_)
-#define CGEN(MT_, NW_) GV2_LN(2, 8, true, MT_, NW_)
-  if (a.g.K == 1024) GV2_MT_SWITCH(mt, C1024);
-  else if (a.g.K == 2560) GV2_MT_SWITCH(mt, C2560);
-  else GV2_MT_SWITCH(mt, CGEN);
-#undef C1024
-#undef C2560
-#undef CGEN
+  if (mt == 1) {
+    if (a.g.K == 1024) GV2_LN((FV<8, 2, false>), 1);
+    else if (a.g.K == 2560) GV2_LN((FV<4, 5, false>), 1);
+    else GV2_LN((FormV<TT, 2, 8, true, 1, 4>), 1);
+  } else {
+    if (a.g.K == 1024) GV2_M_SWITCH(mt, GV2_LN, 4, 8, false);
+    else if (a.g.K == 2560) GV2_M_SWITCH(mt, GV2_LN, 4, 20, false);
+    else if (kc <= 5) GV2_M_SWITCH(mt, GV2_LN, 4, 20, true);
+    else GV2_M_SWITCH(mt, GV2_LN, 8, 20, true);
+  }
 #undef GV2_LN
   return COGV_OK;
 }
