@@ -142,65 +142,72 @@ struct FormV {
 };
 
 // =====================================================================================================================
-// FormM: 2 .. 8 rows on the matrix core.  A workgroup owns 16 columns; wave w takes the contraction-step PAIRS q = w, w + NW, ..
-// (steps 2q and 2q + 1: 64 consecutive elements = one 128-byte line of each of the 16 weight rows), L = K / 32 / NW loads
-// of 16 bytes per lane, all requested at the top like FormV's slots.
+// FormM: 2 .. 8 rows on the matrix core.  A workgroup owns TW tiles of 16 columns, NWK waves per tile: wave kw of a tile takes the
+// contraction-step PAIRS q = kw, kw + NWK, .. (steps 2q and 2q + 1: 64 consecutive elements = one 128-byte line of each of the
+// 16 weight rows), L = K / 32 / NWK loads of 16 bytes per lane, all requested at the top like FormV's slots.
 //   A operand = weights: lane l supplies row (l & 15) -> column n0 + (l & 15), contraction slots 8 (l >> 4) .. + 7 of the step
 //   B operand = x:       lane l supplies column (l & 15) -> row m = l & 15 (lanes past the row count re-read the last row: those
 //                        result columns are never looked at), the same contraction slots, from LDS (rows padded by 16 bytes
 //                        so that the rows of one step fall into different banks)
 //   D: lane l holds C[m = l & 15][n0 + 4 (l >> 4) + i], i = 0 .. 3.
 // The waves' partial tiles are summed in wave order (deterministic), regrouped through LDS into 8 consecutive columns per
-// (row, half) and finished by lanes 0 .. 2M - 1 of wave 0 in parallel.
-template <typename T, int NW_, int LMAX, bool GUARD_, int MT>
+// (row, half) and finished by lanes 0 .. 2M - 1 of the tile's first wave in parallel.
+// TW = 2 (eight waves, 32 columns) serves the LayerNorm-prologue kernel at 4 and 8 rows: one 8-element vector per thread and row
+// in the prologue instead of two, and half as many workgroups recomputing it.
+template <typename T, int NWK, int TW, int LMAX, bool GUARD_, int MT>
 struct FormM {
-  static constexpr int NW = NW_, COLS = 16, XPAD = 8, NS = LMAX, XCHUNKS = (LMAX * NW_ * 32 + 511) / 512;
+  static constexpr int NW = NWK * TW, COLS = 16 * TW, XPAD = 8, NS = LMAX, XCHUNKS = (LMAX * NWK * 32 + 511) / 512;
   static constexpr bool GUARD = GUARD_;
   struct Regs { u32x4 w[LMAX]; };
-  struct Shared { f32x4 red[NW_][64]; float outp[16][16]; uint32_t am[64]; };
-  static __device__ __forceinline__ int kstep(int wave, int i) { return 2 * (wave + NW_ * (i >> 1)) + (i & 1); }
+  struct Shared { f32x4 red[NW][64]; float outp[TW][16][16]; };
+  static __device__ __forceinline__ int kstep(int kw, int i) { return 2 * (kw + NWK * (i >> 1)) + (i & 1); }
   template <int S0, int S1>
   static __device__ __forceinline__ void issue(Regs& r, const GemmArgs& p, int n0, int K, int wave, int lane) {
-    const int L = K / (32 * NW_);
-    const int n = n0 + (lane & 15) < p.N ? n0 + (lane & 15) : p.N - 1;
+    const int L = K / (32 * NWK), kw = wave % NWK, nt = n0 + (wave / NWK) * 16 + (lane & 15);
+    const int n = nt < p.N ? nt : p.N - 1;
     const T* row = reinterpret_cast<const T*>(p.B) + (size_t)n * p.ldb + (lane >> 4) * 8;
 #pragma unroll
     for (int i = S0; i < S1; ++i)
-      if (!GUARD || i < L) r.w[i] = gload16(row + 32 * kstep(wave, i));
+      if (!GUARD || i < L) r.w[i] = gload16(row + 32 * kstep(kw, i));
   }
-  // lanes 0 .. 15 of wave 0 finish: lane t -> row t >> 1, columns n0 + 8 (t & 1) ..
-  static __device__ __forceinline__ u32x4 bias(const GemmArgs& p, int n0, int wave, int lane) { return gv2_bias<T>(p, n0 + (lane & 1) * 8); }
-  static __device__ __forceinline__ void product(const Regs& r, const GemmArgs& p, const T* xs, int XS, int K, Shared& sh, int n0, int wave,
-                                                 int lane, const u32x4& bias_pre) {
+  // lanes 0 .. 15 of a tile's first wave finish: lane t -> row t >> 1, columns (tile) + 8 (t & 1) ..
+  static __device__ __forceinline__ u32x4 bias(const GemmArgs& p, int n0, int wave, int lane) {
+    return gv2_bias<T>(p, n0 + (wave / NWK) * 16 + (lane & 1) * 8);
+  }
+  // steps I0 .. I1 - 1 of this wave; xs holds the x rows from contraction index kofs on
+  template <int I0, int I1>
+  static __device__ __forceinline__ void accumulate(const Regs& r, const T* xs, int XS, int K, int kofs, int wave, int lane, f32x4& acc) {
     typedef typename HT<T>::v8 v8;
-    const int L = K / (32 * NW_);
+    const int L = K / (32 * NWK), kw = wave % NWK;
     const int mrow = (lane & 15) < MT ? (lane & 15) : MT - 1;
-    const T* xrow = xs + (size_t)mrow * XS + (lane >> 4) * 8;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const T* xrow = xs + (size_t)mrow * XS + (lane >> 4) * 8 - kofs;
 #pragma unroll
-    for (int i = 0; i < LMAX; ++i) {
+    for (int i = I0; i < I1; ++i) {
       if (!GUARD || i < L) {
-        const v8 b = *reinterpret_cast<const v8*>(xrow + 32 * kstep(wave, i));
+        const v8 b = *reinterpret_cast<const v8*>(xrow + 32 * kstep(kw, i));
         acc = HT<T>::mfma16(__builtin_bit_cast(v8, r.w[i]), b, acc);
       }
     }
+  }
+  static __device__ __forceinline__ void finish(f32x4 acc, const GemmArgs& p, Shared& sh, int n0, int wave, int lane, const u32x4& bias_pre) {
+    const int tile = wave / NWK, kw = wave % NWK;
     sh.red[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0) {
-      f32x4 s = sh.red[0][lane];
+    if (kw == 0) {
+      f32x4 s = sh.red[tile * NWK][lane];
 #pragma unroll
-      for (int w = 1; w < NW_; ++w) s += sh.red[w][lane];
+      for (int w = 1; w < NWK; ++w) s += sh.red[tile * NWK + w][lane];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sh.outp[lane & 15][(lane >> 4) * 4 + i] = s[i];
+      for (int i = 0; i < 4; ++i) sh.outp[tile][lane & 15][(lane >> 4) * 4 + i] = s[i];
     }
     __syncthreads();
-    if (wave == 0) {
-      const int m = lane >> 1, n = n0 + (lane & 1) * 8;
+    if (kw == 0) {
+      const int m = lane >> 1, n = n0 + tile * 16 + (lane & 1) * 8;
       uint32_t am = 0u;
       if (m < p.M && m < MT && n < p.N) {
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = sh.outp[m][(lane & 1) * 8 + i];
+        for (int i = 0; i < 8; ++i) v[i] = sh.outp[tile][m][(lane & 1) * 8 + i];
         am = epilogue8<T>(p, m, n, v, &bias_pre);
       }
       if (p.flags & COGV_EPI_ABSMAX) {
@@ -210,6 +217,12 @@ struct FormM {
         if (lane == 0) atomic_max_nonneg(p.absmax, bits_to_f<T>((uint16_t)wv));
       }
     }
+  }
+  static __device__ __forceinline__ void product(const Regs& r, const GemmArgs& p, const T* xs, int XS, int K, Shared& sh, int n0, int wave,
+                                                 int lane, const u32x4& bias_pre) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    accumulate<0, LMAX>(r, xs, XS, K, 0, wave, lane, acc);
+    finish(acc, p, sh, n0, wave, lane, bias_pre);
   }
 };
 
@@ -249,6 +262,57 @@ __global__ __launch_bounds__(F::NW * 64) void gemv2_kernel(const GemmArgs p) {
     }
   __syncthreads();
   F::product(w, p, xs, XS, K, sh, n0, wave, lane, bias_pre);
+}
+
+// plain form in TWO contraction halves (FormM, exact-K classes): x rows of K = 10240 with 4 / 8 rows are 80 / 160 KB -- more LDS
+// than a workgroup can have next to anything else.  A wave's loads 0 .. L/2 - 1 lie in the first half of K and the others in
+// the second (its step pairs ascend with the load index), so the rows are staged half by half: all weights are requested at
+// the top as ever; the second half of x follows them in the memory queue, i.e. arrives right behind the last weight.
+template <typename T, typename F, int MT>
+__global__ __launch_bounds__(F::NW * 64) void gemv2_k2_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char gv2_smem[];      // x [MT][K / 2 + pad] as T
+  __shared__ typename F::Shared sh;
+  T* xs = reinterpret_cast<T*>(gv2_smem);
+  constexpr int NT = F::NW * 64, K = F::XCHUNKS * 512, KH = K / 2, XS = KH + F::XPAD, NVEC = KH >> 3, XV = (NVEC + NT - 1) / NT;
+  static_assert(!F::GUARD && F::NS % 4 == 0, "exact classes with an even number of step pairs per wave");
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x * F::COLS;
+  const T* A = reinterpret_cast<const T*>(p.A);
+  u32x4 xr[MT][XV];
+  auto fetch = [&](int kofs) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int row = m < p.M ? m : p.M - 1;
+#pragma unroll
+      for (int u = 0; u < XV; ++u) {
+        const int v = threadIdx.x + NT * u;
+        if (v < NVEC) xr[m][u] = gload16(A + (size_t)row * p.lda + kofs + v * 8);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int u = 0; u < XV; ++u) {
+        const int v = threadIdx.x + NT * u;
+        if (v < NVEC) *reinterpret_cast<u32x4*>(xs + (size_t)m * XS + v * 8) = xr[m][u];
+      }
+  };
+  fetch(0);
+  const u32x4 bias_pre = F::bias(p, n0, wave, lane);
+  typename F::Regs w;
+  F::template issue<0, F::NS>(w, p, n0, K, wave, lane);
+  stage();
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  F::template accumulate<0, F::NS / 2>(w, xs, XS, K, 0, wave, lane, acc);
+  fetch(KH);
+  __syncthreads();                       // every wave is done with the first half of x
+  stage();
+  __syncthreads();
+  F::template accumulate<F::NS / 2, F::NS>(w, xs, XS, K, KH, wave, lane, acc);
+  F::finish(acc, p, sh, n0, wave, lane, bias_pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -550,14 +614,14 @@ inline int gv2_mt(int M) { return M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8; }
 constexpr size_t GV2_MAX_SHMEM = 56 * 1024;
 
 template <int J, int KCMAX, bool G> using FV = FormV<TT, J, KCMAX, G, 1, 4>;
-template <int NW, int LMAX, bool G, int MT> using FM = FormM<TT, NW, LMAX, G, MT>;
+template <int NWK, int LMAX, bool G, int MT, int TW = 1> using FM = FormM<TT, NWK, TW, LMAX, G, MT>;
 
-// CALL(F, MT) for 2 / 4 / 8 rows with FormM<NW, LMAX, G, MT>
-#define GV2_M_SWITCH(mt, CALL, NW_, LMAX_, G_)                        \
-  do {                                                                \
-    if ((mt) == 2) { CALL((FM<NW_, LMAX_, G_, 2>), 2); }              \
-    else if ((mt) == 4) { CALL((FM<NW_, LMAX_, G_, 4>), 4); }         \
-    else { CALL((FM<NW_, LMAX_, G_, 8>), 8); }                        \
+// CALL(F, MT) for 2 / 4 / 8 rows with FormM<NWK, TW, LMAX, G, MT>: TW4 = tiles per workgroup at 4 and 8 rows
+#define GV2_M_SWITCH(mt, CALL, NWK_, LMAX_, G_, TW4_)                       \
+  do {                                                                      \
+    if ((mt) == 2) { CALL((FM<NWK_, LMAX_, G_, 2>), 2); }                   \
+    else if ((mt) == 4) { CALL((FM<NWK_, LMAX_, G_, 4, TW4_>), 4); }        \
+    else { CALL((FM<NWK_, LMAX_, G_, 8, TW4_>), 8); }                       \
   } while (0)
 
 }  // namespace
@@ -579,6 +643,21 @@ extern "C" __attribute__((visibility("hidden"))) int GV2_CAT(cogv_gemv2_launch_,
     if (shmem > GV2_MAX_SHMEM) return COGV_ERR_UNSUPPORTED;                                                                  \
     hipLaunchKernelGGL((gemv2_kernel<TT, FF, MT_>), dim3((a.N + FF::COLS - 1) / FF::COLS), dim3(FF::NW * 64), shmem, st, a); \
   } while (0)
+  // the two-halves kernel: LDS for half the row length; above 64 KB in all (8 rows of K = 10240: 82 KB + 17 KB static) by attribute
+#define GV2_PLAIN_K2(F_, MT_)                                                                                                \
+  do {                                                                                                                       \
+    typedef GV2_UNWRAP F_ FF;                                                                                                \
+    const size_t shmem = (size_t)MT_ * (a.K / 2 + FF::XPAD) * 2;                                                             \
+    static bool attr = false;                                                                                                \
+    if (!attr) {                                                                                                             \
+      if (shmem > GV2_MAX_SHMEM &&                                                                                           \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv2_k2_kernel<TT, FF, MT_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)shmem) != hipSuccess)                                                                    \
+        return COGV_ERR_UNSUPPORTED;                                                                                         \
+      attr = true;                                                                                                           \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((gemv2_k2_kernel<TT, FF, MT_>), dim3((a.N + FF::COLS - 1) / FF::COLS), dim3(FF::NW * 64), shmem, st, a); \
+  } while (0)
   if (mt == 1) {
     if (a.K == 1024) GV2_PLAIN((FV<8, 2, false>), 1);
     else if (a.K == 2560) GV2_PLAIN((FV<4, 5, false>), 1);
@@ -586,15 +665,20 @@ extern "C" __attribute__((visibility("hidden"))) int GV2_CAT(cogv_gemv2_launch_,
     else if (a.K == 10240) GV2_PLAIN((FV<2, 20, false>), 1);
     else GV2_PLAIN((FV<2, 20, true>), 1);
   } else {
-    if (a.K == 1024) GV2_M_SWITCH(mt, GV2_PLAIN, 4, 8, false);
-    else if (a.K == 2560) GV2_M_SWITCH(mt, GV2_PLAIN, 4, 20, false);
-    else if (a.K == 4096) GV2_M_SWITCH(mt, GV2_PLAIN, 8, 16, false);
-    else if (a.K == 10240) GV2_M_SWITCH(mt, GV2_PLAIN, 16, 20, false);
-    else if (kc <= 5) GV2_M_SWITCH(mt, GV2_PLAIN, 4, 20, true);
-    else if (kc <= 10) GV2_M_SWITCH(mt, GV2_PLAIN, 8, 20, true);
+    if (a.K == 1024) GV2_M_SWITCH(mt, GV2_PLAIN, 4, 8, false, 1);
+    else if (a.K == 2560) GV2_M_SWITCH(mt, GV2_PLAIN, 4, 20, false, 1);
+    else if (a.K == 4096) GV2_M_SWITCH(mt, GV2_PLAIN, 8, 16, false, 1);
+    else if (a.K == 10240) {
+      if (mt == 2) GV2_PLAIN((FM<16, 20, false, 2>), 2);
+      else if (mt == 4) GV2_PLAIN_K2((FM<16, 20, false, 4>), 4);
+      else GV2_PLAIN_K2((FM<16, 20, false, 8>), 8);
+    }
+    else if (kc <= 5) GV2_M_SWITCH(mt, GV2_PLAIN, 4, 20, true, 1);
+    else if (kc <= 10) GV2_M_SWITCH(mt, GV2_PLAIN, 8, 20, true, 1);
     else return COGV_ERR_UNSUPPORTED;
   }
 #undef GV2_PLAIN
+#undef GV2_PLAIN_K2
   return COGV_OK;
 }
 
@@ -619,11 +703,11 @@ extern "C" __attribute__((visibility("hidden"))) int GV2_CAT(cogv_gemv2_attn_lau
     else if (a.K == 2560) GV2_ATTN((FV<4, 5, false>), 1);
     else GV2_ATTN((FV<2, 20, true>), 1);
   } else {
-    if (a.K == 1024) GV2_M_SWITCH(mt, GV2_ATTN, 4, 8, false);
-    else if (a.K == 2560) GV2_M_SWITCH(mt, GV2_ATTN, 4, 20, false);
+    if (a.K == 1024) GV2_M_SWITCH(mt, GV2_ATTN, 4, 8, false, 1);
+    else if (a.K == 2560) GV2_M_SWITCH(mt, GV2_ATTN, 4, 20, false, 1);
     else if (a.K == 4096 || a.K == 10240) return COGV_ERR_UNSUPPORTED;     // (exact FormM classes of the plain form: not instantiated here)
-    else if (kc <= 5) GV2_M_SWITCH(mt, GV2_ATTN, 4, 20, true);
-    else if (kc <= 10) GV2_M_SWITCH(mt, GV2_ATTN, 8, 20, true);
+    else if (kc <= 5) GV2_M_SWITCH(mt, GV2_ATTN, 4, 20, true, 1);
+    else if (kc <= 10) GV2_M_SWITCH(mt, GV2_ATTN, 8, 20, true, 1);
     else return COGV_ERR_UNSUPPORTED;
   }
 #undef GV2_ATTN
@@ -649,10 +733,10 @@ extern "C" __attribute__((visibility("hidden"))) int GV2_CAT(cogv_gemv2_ln_launc
     else if (a.g.K == 2560) GV2_LN((FV<4, 5, false>), 1);
     else GV2_LN((FormV<TT, 2, 8, true, 1, 4>), 1);
   } else {
-    if (a.g.K == 1024) GV2_M_SWITCH(mt, GV2_LN, 4, 8, false);
-    else if (a.g.K == 2560) GV2_M_SWITCH(mt, GV2_LN, 4, 20, false);
-    else if (kc <= 5) GV2_M_SWITCH(mt, GV2_LN, 4, 20, true);
-    else GV2_M_SWITCH(mt, GV2_LN, 8, 20, true);
+    if (a.g.K == 1024) GV2_M_SWITCH(mt, GV2_LN, 4, 8, false, 2);
+    else if (a.g.K == 2560) GV2_M_SWITCH(mt, GV2_LN, 4, 20, false, 2);
+    else if (kc <= 5) GV2_M_SWITCH(mt, GV2_LN, 4, 20, true, 2);
+    else GV2_M_SWITCH(mt, GV2_LN, 8, 20, true, 1);
   }
 #undef GV2_LN
   return COGV_OK;
