@@ -391,6 +391,7 @@ void gemv2_ln_kernel(const GemvLnArgs q) {
   __shared__ uint32_t redm[16];
   __shared__ float s_amax;
   constexpr int NT = NW * 64, NV = 512 / NT;
+  static_assert(NW == 4 || NW == 8, "the prologue's block sums pair 4 or 8 wave partials");
   const GemmArgs& p = q.g;
   T* xs = reinterpret_cast<T*>(gv2_smem);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
