@@ -510,3 +510,71 @@ def test_save_checkpoint_waits_for_the_sharded_parameter_gather(tmp_path):
     sd = torch.load(utils.get_checkpoint_name(str(tmp_path), 5), map_location="cpu", weights_only=False)
     assert sd["iteration"] == 5 and set(sd["module"]) == {"weight", "bias"}
     assert open(utils.get_checkpoint_tracker_filename(str(tmp_path))).read() == "5"
+
+
+def test_decode_chain_launch_sequence_and_absmax_contract(monkeypatch):
+    """functional.decode_chain on recording stubs (no GPU): per layer QKV matrix-vector launch with its LayerNorm prologue |
+    decode attention | attention-output projection | h -> 4h with prologue + GeLU | 4h -> h, then the tied-logits launch --
+    (mpu/sparse_transformer.py:314-342 per generated token) -- and the round-4 contract of the Sandwich scale: the branch
+    outputs are produced WITHOUT an abs-max slot (no atomics in the producers' tails) and every post-LN prologue is asked to
+    take max|z| itself (z_absmax=None); only the first layer's plain input carries the scalar its producer published."""
+    from cogview_amd import functional as F_
+    from cogview_amd.model import GPT2Model
+    L_, V_, H_, NH_, B_ = 3, 256, 512, 8, 2
+    m = GPT2Model(L_, V_, H_, NH_, 0.0, 0.0, 0.0, 64, 64, False).half()
+    tr = m.transformer
+    calls = []
+
+    class Ops:
+        @staticmethod
+        def gemv_ln(z, w, bias, gamma, beta, eps, z_absmax=None, post=None, residual=None, want_t=False, gelu=False, absmax=None):
+            calls.append(("gemv_ln", tuple(w.shape), z_absmax is None, post is not None, gelu, absmax is None))
+            out = torch.zeros(z.shape[0], w.shape[0], dtype=w.dtype)
+            return out, (torch.zeros(z.shape, dtype=torch.float32) if (post is not None and want_t) else None)
+
+        @staticmethod
+        def attention_decode(qkv, cache, pos_index, heads, combine=True):
+            calls.append(("attention_decode", combine))
+            return torch.zeros(qkv.shape[0], 1, heads * 64, dtype=qkv.dtype)
+
+        @staticmethod
+        def gemm(a, b, bias=None, absmax=None, **kw):
+            calls.append(("gemm", tuple(b.shape), absmax is None))
+            return torch.zeros(a.shape[0], b.shape[0], dtype=b.dtype)
+
+        @staticmethod
+        def gemv_attn(*a, **kw):
+            raise AssertionError("the two-launch form was requested")
+
+        @staticmethod
+        def new_absmax_slot(dev):
+            raise AssertionError("the decode chain must not allocate abs-max slots any more")
+
+    monkeypatch.setattr(F_, "ops", Ops)
+    monkeypatch.setattr(F_, "_DECODE_FUSE_ENV", "0")                # the captured graph's form: combine kernel + plain projection
+
+    class Slot:
+        def __init__(self):
+            self.cache = torch.zeros(B_, 128, 2 * H_, dtype=torch.float16)
+            self.pos_index = torch.zeros((), dtype=torch.int64)
+            self.out = None
+
+    slots = [Slot() for _ in range(L_)]
+    h0 = torch.zeros(B_, 1, H_, dtype=torch.float32)
+    absmax0 = torch.ones(1)
+    logits = F_.decode_chain(tr, h0, absmax0, slots, m.word_embeddings.weight)
+    assert logits.shape == (B_, 1, V_)
+    per_layer = [("gemv_ln", (3 * H_, H_)), ("attention_decode",), ("gemm", (H_, H_)), ("gemv_ln", (4 * H_, H_)), ("gemm", (H_, 4 * H_))]
+    assert len(calls) == L_ * 5 + 1
+    for li in range(L_):
+        c = calls[5 * li:5 * li + 5]
+        assert [x[0] for x in c] == [p[0] for p in per_layer]
+        assert c[0][1] == per_layer[0][1] and c[2][1] == per_layer[2][1] and c[3][1] == per_layer[3][1] and c[4][1] == per_layer[4][1]
+        # QKV launch: plain input with the published scalar in layer 0, post-LN form with in-kernel max|z| afterwards
+        assert c[0][2] == (li > 0) and c[0][3] == (li > 0) and not c[0][4]
+        assert c[1] == ("attention_decode", True)
+        assert c[2][2] and c[4][2], "branch outputs are produced without an abs-max slot"
+        assert c[3][2] and c[3][3] and c[3][4], "h -> 4h: post-LN prologue, max|z| in the kernel, GeLU epilogue"
+    last = calls[-1]
+    assert last[0] == "gemv_ln" and last[1] == (V_, H_) and last[2] and last[3]
+    assert all(s.out is s.cache for s in slots)
