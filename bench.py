@@ -75,8 +75,56 @@ def flops_per_token(L, h, V, s=ROW - 1):
     return 3.0 * (L * (24.0 * h * h + 4.0 * s * h) + 2.0 * h * V)
 
 
+def flops_per_token_causal(L, h, V, s=ROW - 1):
+    """SURVEY.md section 8(d)'s "causal-discounted variant": the two attention products (4 s h per token and layer, forward)
+    counted over the visible half of the score matrix only, (s + 1) / 2s of it -- 24.35 GFLOP/token at 4B against 25.148."""
+    return 3.0 * (L * (24.0 * h * h + 4.0 * s * h * (s + 1) / (2.0 * s)) + 2.0 * h * V)
+
+
+def hardware_flops_per_token(L, h, V, s=ROW - 1, recompute=False):
+    """What the kernels EXECUTE per token: the attention products over the 64 x 64 score blocks the kernels visit (a block on
+    the diagonal is computed whole: nb (nb + 1) / 2 of nb^2 blocks, nb = ceil(s / 64): 153 / 289 at s = 1088), and, with
+    activation recompute, a second forward pass of every layer ("hardware FLOPs if recompute is on")."""
+    nb = (s + 63) // 64
+    att = 4.0 * (64.0 * 64.0 * nb * (nb + 1) / 2.0) / s * h      # per token and layer, forward: 2 products x 2 flops, h = heads x 64
+    layer_fwd = 24.0 * h * h + att
+    return 3.0 * (L * layer_fwd + 2.0 * h * V) + (L * layer_fwd if recompute else 0.0)
+
+
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s HBM3E peak (6.3 TB/s is what a float4 copy reaches)
+
+
+def by_family(stats, step_ms_sampled):
+    """roofline.by_family: every kernel family bracketed by HIP events in the sampled steps (ops.timed_launch), each against
+    the roofline that bounds it -- attention on EXECUTED FLOPs (visited 64 x 64 blocks; backward = 2.5 x forward) against the
+    dense MFMA peak, the HBM-bound families on their algorithmic bytes against the 8 TB/s peak."""
+    out = {}
+    bv = stats["by_variant"]
+    g = stats["gemm"]
+    out["gemm"] = {"bound": "mfma", "achieved": g["tflops"], "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": g["tflops"] / PEAK_MFMA_TFLOPS,
+                   "launches": g["launches"], "share_of_step_time": g["total_ms"] / step_ms_sampled}
+    for fam in ("attention", "layernorm", "adamw", "grad_stats"):
+        v = bv.get(fam)
+        if v is None:
+            continue
+        if fam == "attention":
+            out[fam] = {"bound": "mfma", "achieved": v["tflops"], "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s (executed: visited 64x64 blocks)",
+                        "frac": v["tflops"] / PEAK_MFMA_TFLOPS}
+        else:
+            out[fam] = {"bound": "hbm", "achieved": v["algo_gbytes_per_s"], "peak": PEAK_HBM_GBS, "unit": "GB/s (algorithmic bytes)",
+                        "frac": v["algo_gbytes_per_s"] / PEAK_HBM_GBS}
+        out[fam].update(launches=v["launches"], avg_launch_ms=v["avg_ms"], share_of_step_time=v["total_ms"] / step_ms_sampled)
+    out["by_launch"] = {k: v for k, v in stats["by_shape"].items() if k.split(" ")[0] in ("attention", "layernorm", "adamw")}
+    return out
+
+
 def gemm_flops(M, N, K):
     return 2.0 * M * N * K
+
+
+def ops_gemm_families():
+    from cogview_amd import ops
+    return ops.GEMM_FAMILIES
 
 
 def cpu_baseline(L, h, heads, sample_layers=4, row=ROW):
@@ -319,18 +367,30 @@ def run_gpt(args, dtype_name, world, rank, mp, parity=False):
         "model_tflops_per_gpu": value / world * fpt / 1e12,
         "mfma_roofline_frac_end_to_end": value / world * fpt / 1e12 / PEAK_MFMA_TFLOPS,
     }
+    # SURVEY.md section 8(d)'s other two FLOP conventions for the same measured tokens/s: attention over the visible half of
+    # the scores only, and the FLOPs the kernels execute (visited score blocks; + the recompute forward with --checkpoint-activations)
+    fpt_c = flops_per_token_causal(L, h, vocab, s=row - 1)
+    fpt_hw = hardware_flops_per_token(L, h, vocab, s=row - 1, recompute=bool(args.checkpoint_activations))
+    out["flops_per_token"] = {"model_full_attention": fpt, "model_causal_discounted": fpt_c, "hardware_executed": fpt_hw}
+    out["model_tflops_causal_discounted"] = value / world * fpt_c / 1e12
+    out["mfma_roofline_frac_causal_discounted"] = value / world * fpt_c / 1e12 / PEAK_MFMA_TFLOPS
+    out["hardware_tflops_per_gpu"] = value / world * fpt_hw / 1e12
+    out["mfma_roofline_frac_hardware_flops"] = value / world * fpt_hw / 1e12 / PEAK_MFMA_TFLOPS
     sampled = args.steps // 4 if args.steps >= 4 else args.steps          # steps whose launches carried HIP events (timed_steps)
     if gemm_stats is not None:
+        all_stats, gemm_stats = gemm_stats, dict(gemm_stats["gemm"], by_variant={k: v for k, v in gemm_stats["by_variant"].items() if k in ops_gemm_families()},
+                                                  by_shape=gemm_stats["by_shape"])
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_w4_kernel<%s> (256x256x64 tiles, 4 waves of 128x128, persistent work queues, 16x16x32 MFMA; NT fwd, "
-                                                       "NN dgrad, TN wgrad grouped four per launch)" % dtype_name,
+                                                       "NN dgrad, TN wgrad in grouped launches of whole rounds of tiles)" % dtype_name,
                            "achieved": gemm_stats["tflops"], "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": gemm_stats["tflops"] / PEAK_MFMA_TFLOPS, "traffic": None,
                            "launches": gemm_stats["launches"], "avg_launch_ms": gemm_stats["avg_ms"],
                            "sampled_steps": sampled, "share_of_step_time": gemm_stats["total_ms"] / (elapsed / args.steps * sampled * 1e3),
                            "by_variant_tflops": gemm_stats["by_variant"]}
-        log("[bench] GEMM launches by shape (TFLOP/s, launches, avg ms):")
+        out["roofline"]["by_family"] = by_family(all_stats, elapsed / args.steps * sampled * 1e3)
+        log("[bench] launches by kernel family and shape (TFLOP/s, GB/s of algorithmic bytes, launches, avg ms):")
         for k, v in gemm_stats["by_shape"].items():
-            log(f"    {k:44s} {v['tflops']:8.1f} {v['launches']:6d} {v['avg_ms']:9.4f}")
+            log(f"    {k:72s} {v['tflops']:8.1f} {v['gbytes_per_s']:8.1f} {v['launches']:6d} {v['avg_ms']:9.4f}")
         # HBM-side traffic of the dominant kernel: measured off-line with rocprofv3 PMC passes (tools/collect_traffic.sh,
         # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read correction) for the single-GPU workloads (collected on the bf16 build).
         tpath = latest_profile("gemm_hbm_traffic_pmc_%s_b%d.json" % (args.config.split("-")[-1], args.batch))
@@ -457,7 +517,8 @@ def main():
         if args.dtype is None and world == 1 and not args.no_second_dtype:
             leg = run_gpt(args, "bf16", world, rank, mp, parity=parity)
             out["bf16_leg"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "dtype", "model_tflops_per_gpu",
-                                                   "mfma_roofline_frac_end_to_end")}
+                                                   "mfma_roofline_frac_end_to_end", "mfma_roofline_frac_causal_discounted",
+                                                   "mfma_roofline_frac_hardware_flops")}
             out["bf16_leg"]["loss"] = leg["config"]["loss"]
             out["bf16_leg"]["loss_scale"] = leg["config"]["loss_scale"]
             out["bf16_leg"]["logits_rel_l2_vs_fp32_reference"] = leg["config"]["logits_rel_l2_vs_fp32_reference"]

@@ -1026,8 +1026,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeArgs p) {
     // the capacity re-reads the last row): the position is a device scalar, and loads that waited for it would start one
     // memory latency late -- the launch is a chain of latencies, not of bytes
     const long long krow = key < p.cap ? key : p.cap - 1;
+    // (streamed once per step: non-temporal policy, like the decode step's weight rows -- gemm_shared.cuh: COGV_DECODE_NT)
+#if !defined(COGV_DECODE_NT) || COGV_DECODE_NT
+    kc8[ps] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(crow + krow * p.cache_rs));
+    v8[ps] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(crow + krow * p.cache_rs + hp));
+#else
     kc8[ps] = *reinterpret_cast<const u32x4*>(crow + krow * p.cache_rs);
     v8[ps] = *reinterpret_cast<const u32x4*>(crow + krow * p.cache_rs + hp);
+#endif
   }
   const long long pos = *p.pos;
 #pragma unroll

@@ -36,6 +36,19 @@ struct GemmArgs {
 // a generic pointer would compile to flat_load / flat_store, which also count on the LDS counter
 #define COGV_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ u32x4 gload16(const void* q) { return *(const COGV_GLOBAL u32x4*)q; }
+// streamed-once data (the weight rows of a decode step: every byte is read by ONE workgroup, once per token): the
+// non-temporal policy (global_load_dwordx4 ... nt) keeps the stream from displacing the step's small reused vectors in the
+// caches.  COGV_DECODE_NT=0 builds the default-policy loads (A/B: profiles/r05_decode_nt_ab.log).
+#ifndef COGV_DECODE_NT
+#define COGV_DECODE_NT 1
+#endif
+__device__ __forceinline__ u32x4 gload16_stream(const void* q) {
+#if COGV_DECODE_NT
+  return __builtin_nontemporal_load((const COGV_GLOBAL u32x4*)q);
+#else
+  return *(const COGV_GLOBAL u32x4*)q;
+#endif
+}
 __device__ __forceinline__ void gstore16(void* q, u32x4 v) { *(COGV_GLOBAL u32x4*)q = v; }
 __device__ __forceinline__ void gstore16(float* q, f32x4 v) { *(COGV_GLOBAL f32x4*)q = v; }
 // 16-bit C / aux stores of the non-accumulating epilogues carry the NON-TEMPORAL hint (round 4): a 32-CU XCD writes 4 MiB of C per

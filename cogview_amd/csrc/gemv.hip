@@ -74,7 +74,7 @@ struct FormV {
     for (int s = S0; s < S1; ++s) {
       const int c = s / J, j = s % J;
       const int n = nw + j < p.N ? nw + j : p.N - 1;
-      if (!GUARD || c < kc) r.w[s] = gload16(B + (size_t)n * p.ldb + c * 512 + lane * 8);
+      if (!GUARD || c < kc) r.w[s] = gload16_stream(B + (size_t)n * p.ldb + c * 512 + lane * 8);
     }
   }
   static __device__ __forceinline__ u32x4 bias(const GemmArgs& p, int n0, int wave, int lane) { return gv2_bias<T>(p, n0 + wave * 8); }
@@ -168,7 +168,7 @@ struct FormM {
     const T* row = reinterpret_cast<const T*>(p.B) + (size_t)n * p.ldb + (lane >> 4) * 8;
 #pragma unroll
     for (int i = S0; i < S1; ++i)
-      if (!GUARD || i < L) r.w[i] = gload16(row + 32 * kstep(kw, i));
+      if (!GUARD || i < L) r.w[i] = gload16_stream(row + 32 * kstep(kw, i));
   }
   // lanes 0 .. 15 of a tile's first wave finish: lane t -> row t >> 1, columns (tile) + 8 (t & 1) ..
   static __device__ __forceinline__ u32x4 bias(const GemmArgs& p, int n0, int wave, int lane) {

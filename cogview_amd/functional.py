@@ -403,6 +403,7 @@ class _Embedding(torch.autograd.Function):
     def backward(ctx, dout, _):
         ids, pos_ids = ctx.saved_tensors
         w, pw = ctx.weight, ctx.pos_weight
+        flush_weight_grads(final=True)            # a queued tied-logits gradient must land in the table's rows first
         dpos = grad_buffer(pw) if (pw is not None and pw.requires_grad) else None
         dtab = grad_buffer(w) if w.requires_grad else None
         for q in (pw if dpos is not None else None, w if dtab is not None else None):
@@ -480,7 +481,12 @@ class _Logits(torch.autograd.Function):
         d2 = dl.reshape(-1, dl.shape[-1])
         dx = _mp_allreduce(ops.gemm(d2, w, trans_b=True)).view(ctx.xshape)
         if w.requires_grad:
-            ops.gemm(d2, x2, trans_a=True, trans_b=True, out=grad_buffer(w), accumulate=grad_accumulate(w))
+            if mp_world_size_or_1() == 1 and WGRAD_QUEUE:
+                # queued: its 256 x 256 tiles ride in the free slots of the layers' grouped weight-gradient launches
+                # (_DeferredWeightGrads); d2 (the logits' gradient, 3 GB at 4B) stays alive until its last tile row is launched
+                defer_weight_grad(d2, x2, w)
+            else:
+                ops.gemm(d2, x2, trans_a=True, trans_b=True, out=grad_buffer(w), accumulate=grad_accumulate(w))
         return dx, None
 
 
@@ -601,16 +607,22 @@ def _layer_backward(layer, kp, dout, sep):
     # of that exchange, so they are launched while it runs (the reference's autograd serialises them, mpu/mappings.py:
     # 79-93 inside F.linear's backward).  Without model parallelism they stay deferred to the grouped launch.
     mp = mp_world_size_or_1()
-    wgrads = _WGRADS.problems if mp == 1 else []
+    wgrads = []                                   # model parallel only: launched behind each exchange (below)
+
+    def _wg(dy_, x_, w_):
+        if mp == 1:
+            defer_weight_grad(dy_, x_, w_, owner=layer)      # queued: the layer-group flushes launch whole rounds of tiles
+        else:
+            wgrads.append((dy_, x_, w_))
     du = ops.gemm(d_mo, W2, trans_b=True, mul_aux=kp.u, colsum_out=G(b1),       # dgrad x stored gelu' + bias grad of h->4h
                   colsum_accumulate=grad_accumulate(b1))
-    wgrads.append((d_mo, kp.g, W2))
+    _wg(d_mo, kp.g, W2)
     dc = ops.gemm(du, W1, trans_b=True)
-    wgrads.append((du, kp.c.view(rows, h), W1))
+    _wg(du, kp.c.view(rows, h), W1)
     if mp > 1:
         work = _mp_allreduce_start(dc)
         _launch_weight_grads(wgrads)                                             # overlaps the exchange of dc
-        wgrads = []
+        del wgrads[:]
         _mp_allreduce_finish(work)
     # y feeds LN2 and the second residual:  dy = dout + LN2'(dc)
     dy = ops.sandwich_ln_bwd(dc.view(b, s, h), kp.y, ln2.weight, *kp.st2, add_in=dout, dgamma=G(ln2.weight),
@@ -619,7 +631,7 @@ def _layer_backward(layer, kp, dout, sep):
     d_ao = ops.sandwich_ln_bwd(dy, kp.ao, ln3.weight, *kp.st3, dropout=kp.d_ao, dgamma=G(ln3.weight),
                                dbeta=G(ln3.bias), colsum=G(bo), accumulate=grad_accumulate(ln3.weight, ln3.bias, bo)).view(rows, h)
     d_att = ops.gemm(d_ao, Wo, trans_b=True).view(b, s, npp, 64)
-    wgrads.append((d_ao, kp.att.view(rows, hp), Wo))
+    _wg(d_ao, kp.att.view(rows, hp), Wo)
     qkv = kp.qkv
     q = qkv[:, :, 0:hp].view(b, s, npp, 64)
     k = qkv[:, :, hp:2 * hp].view(b, s, npp, 64)
@@ -631,7 +643,7 @@ def _layer_backward(layer, kp, dout, sep):
                       keep_bits=getattr(kp, "kbits", None))
     dqkv2 = dqkv.view(rows, 3 * hp)
     da = ops.gemm(dqkv2, Wq, trans_b=True)
-    wgrads.append((dqkv2, kp.a.view(rows, h), Wq))
+    _wg(dqkv2, kp.a.view(rows, h), Wq)
     if mp > 1:
         work = _mp_allreduce_start(da)
         _launch_weight_grads(wgrads)                                             # overlaps the exchange of da
@@ -641,24 +653,85 @@ def _layer_backward(layer, kp, dout, sep):
     return dx
 
 
+class _WgradEntry:
+    """One deferred weight gradient dW (+)= dY^T X, launched in chunks of whole 256-row tile rows of dW."""
+    __slots__ = ("dy", "x", "w", "owner", "t0", "trows", "tiles_n", "acc")
+
+    def __init__(self, dy, x, w, owner):
+        self.dy, self.x, self.w, self.owner = dy, x, w, owner
+        self.t0, self.acc = 0, None                                   # next tile row to launch; accumulate flag (first chunk decides)
+        self.trows, self.tiles_n = (w.shape[0] + 255) // 256, (w.shape[1] + 255) // 256
+
+    def tiles_left(self):
+        return (self.trows - self.t0) * self.tiles_n
+
+
+def plan_wgrad_chunks(entries, budget):
+    """Which tile rows of which pending problems go into the next launch.  entries: [(t0, trows, tiles_n, out_rows)] in queue
+    order; budget: tiles the launch may hold (None: everything).  Returns [(index, t0, t1)], oldest problem first, whole tile
+    rows only, at most `budget` tiles in all.  A problem whose last tile row is partial (out_rows % 256 != 0) is never cut so
+    that this row would be left on its own: the grouped kernel takes problems of at least 256 rows."""
+    out, left = [], budget
+    for i, (t0, trows, tiles_n, out_rows) in enumerate(entries):
+        if t0 >= trows:
+            continue
+        n = trows - t0
+        if left is not None:
+            n = min(n, left // tiles_n)
+            if n <= 0:
+                continue
+        t1 = t0 + n
+        if t1 == trows - 1 and out_rows % 256 != 0:                   # would strand the partial last row
+            t1 -= 1
+        if t1 <= t0 or (t1 - t0 == 1 and t1 == trows and out_rows % 256 != 0 and trows > 1):
+            continue
+        out.append((i, t0, t1))
+        if left is not None:
+            left -= (t1 - t0) * tiles_n
+    return out
+
+
 class _DeferredWeightGrads:
-    """Weight-gradient GEMMs of the fused layers waiting for a grouped launch.  A group is flushed when the layer
-    with index % WGRAD_GROUP_LAYERS == 0 finishes its backward (index 0 is the last layer backward visits, so nothing
-    is ever left behind); the data-parallel callbacks of the deferred layers run after the flush, in backward order,
-    because only then are their weight gradients complete.
-    Measured at 4B: one layer per launch is 1200 tiles = 4.7 rounds of the 256 CUs (6 % lost in the partial last
-    round) at 1328 TFLOP/s (generation-4 GEMM; 1207 with generation 3); four layers per launch (18.75 rounds, 1.3 %
-    tail) ran at 1267 (1136) TFLOP/s -- a 13 ms uninterrupted GEMM sits at the sustained power limit, while 3 ms
-    launches separated by the lighter LN / attention kernels clock higher.  Hence one layer per launch whenever a layer
-    fills the chip (wgrad_group_layers; COGV_WGRAD_GROUP_LAYERS overrides it for experiments)."""
-    __slots__ = ("problems", "callbacks")
+    """Weight-gradient GEMMs waiting for a grouped launch: a QUEUE of problems cut into launches of whole rounds.
+
+    A launch of the persistent 256 x 256-tile kernel costs ceil(tiles / 256) rounds of the 256 CUs.  One 4B layer's four weight
+    gradients are 1200 tiles = 4.69 rounds (5 paid), the tied-logits gradient 2280 tiles = 8.9 (9 paid): 249 rounds per step for
+    233.9 rounds of work.  Round 5: every flush (one per layer group, as before) launches a MULTIPLE of 256 tiles taken from the
+    head of the queue -- at most the rounds the group itself would have paid (1280 tiles at 4B, so that a launch stays as short
+    as it was: longer uninterrupted GEMMs clock lower, see below) -- and what does not fit waits for the next flush; problems are
+    cut along tile rows of dW (a column slice of dY, a row slice of dW: plain pointer offsets, every tile is computed by the same
+    kernel in the same order -> bit-identical results).  The tied-logits gradient (functional._Logits.backward) joins the queue
+    first and fills the 80 free tile slots of the first 29 layer launches (a layer's own problems are taken before it); after that
+    the launches alternate between 5 and 4 full rounds, a layer's last tile rows riding in the next layer's launch.  234 rounds instead of 249 at 4B: -9.5 ms per step.  The flush of layer index 0 (the last one backward visits),
+    the embedding's backward and the end of the autograd pass launch whatever is left.
+    The data-parallel callback of a layer runs once all of ITS problems have been launched, in backward order.
+    COGV_WGRAD_QUEUE=0: every flush launches everything it has (the round-4 behaviour).
+
+    Measured at 4B (round 3): one layer per launch at 1328 TFLOP/s (generation-4 GEMM); four layers per launch (18.75 rounds,
+    1.3 % tail) ran at 1267 TFLOP/s -- a 13 ms uninterrupted GEMM sits at the sustained power limit, while 3 ms launches
+    separated by the lighter LN / attention kernels clock higher.  Hence one layer per flush whenever a layer fills the chip
+    (wgrad_group_layers; COGV_WGRAD_GROUP_LAYERS overrides it for experiments)."""
+    __slots__ = ("entries", "callbacks", "new_tiles", "hooked")
 
     def __init__(self):
-        self.problems, self.callbacks = [], []
+        self.entries, self.callbacks, self.new_tiles, self.hooked = [], [], 0, False
+
+    def add(self, dy, x, w, owner=None):
+        e = _WgradEntry(dy, x, w, owner)
+        self.entries.append(e)
+        if owner is not None:                     # the flushed layer group's own tiles set the size of its launch
+            self.new_tiles += e.trows * e.tiles_n
+
+    # kept for callers that read the list of pending problems
+    @property
+    def problems(self):
+        return self.entries
 
 
 import os as _os
 WGRAD_GROUP_LAYERS = int(_os.environ.get("COGV_WGRAD_GROUP_LAYERS", "0"))       # 0: by tile count (wgrad_group_layers)
+WGRAD_QUEUE = _os.environ.get("COGV_WGRAD_QUEUE", "1") != "0"
+WGRAD_ROUND_TILES = 256                                                          # tile slots of one round: one 256 x 256 tile per CU
 _WGRADS = _DeferredWeightGrads()
 _WGRAD_GROUP_CACHE = {}
 
@@ -694,12 +767,65 @@ def _launch_weight_grads(probs):
         ops.gemm_grouped([(a, b, grad_buffer(w), grad_accumulate(w)) for a, b, w in probs[i:i + 16]], trans_a=True, trans_b=True)
 
 
-def flush_weight_grads():
-    probs, cbs = _WGRADS.problems, _WGRADS.callbacks
-    _WGRADS.problems, _WGRADS.callbacks = [], []
-    _launch_weight_grads(probs)
-    for cb, layer in cbs:
+def _launch_wgrad_chunks(chunks):
+    """chunks: [(entry, t0, t1)] -> grouped launches of at most 16 sub-problems (tile rows [t0, t1) of each entry's dW)."""
+    subs = []
+    for e, t0, t1 in chunks:
+        if e.acc is None:
+            e.acc = grad_accumulate(e.w)          # decided once per problem: its chunks write disjoint rows
+        r0, r1 = 256 * t0, min(256 * t1, e.w.shape[0])
+        g = grad_buffer(e.w)
+        whole = r0 == 0 and r1 == e.w.shape[0]
+        subs.append((e.dy if whole else e.dy[:, r0:r1], e.x, g if whole else g[r0:r1], e.acc))
+        e.t0 = t1
+    for i in range(0, len(subs), 16):
+        ops.gemm_grouped(subs[i:i + 16], trans_a=True, trans_b=True)
+
+
+def flush_weight_grads(final=True):
+    """Launch pending weight gradients.  final=True: all of them (the last layer of a backward pass, the embedding's backward,
+    the end of the autograd pass, tests); final=False (a layer group finished, more follow): whole rounds only -- see
+    _DeferredWeightGrads."""
+    q = _WGRADS
+    if not q.entries and not q.callbacks:
+        return
+    budget = None
+    if not final and WGRAD_QUEUE:
+        pending = sum(e.tiles_left() for e in q.entries)
+        cap = -(-q.new_tiles // WGRAD_ROUND_TILES) * WGRAD_ROUND_TILES
+        budget = min(cap, (pending // WGRAD_ROUND_TILES) * WGRAD_ROUND_TILES)
+    q.new_tiles = 0
+    if budget is None or budget > 0:
+        # the layers' own problems first (oldest first: their activations are released and their data-parallel buckets start as
+        # early as possible), then problems without an owner (the tied-logits gradient) as filler for the remaining tile slots
+        order = [e for e in q.entries if e.owner is not None] + [e for e in q.entries if e.owner is None]
+        plan = plan_wgrad_chunks([(e.t0, e.trows, e.tiles_n, e.w.shape[0]) for e in order], budget)
+        _launch_wgrad_chunks([(order[i], t0, t1) for i, t0, t1 in plan])
+    q.entries = [e for e in q.entries if e.t0 < e.trows]
+    # data-parallel callbacks, in backward order, up to the first layer that still has a problem in the queue
+    busy = {id(e.owner) for e in q.entries if e.owner is not None}
+    while q.callbacks and id(q.callbacks[0][1]) not in busy:
+        cb, layer = q.callbacks.pop(0)
         cb(layer)
+    if final:
+        q.hooked = False
+
+
+def _flush_at_end_of_backward():
+    _WGRADS.hooked = False
+    flush_weight_grads(final=True)
+
+
+def defer_weight_grad(dy, x, w, owner=None):
+    """Queue dW (+)= dY^T X for the next grouped launches.  Called inside an autograd backward pass: a callback at the end of
+    that pass launches whatever no layer flush has taken (nothing in a GPT2Model step: layer index 0 flushes everything)."""
+    _WGRADS.add(dy, x, w, owner)
+    if not _WGRADS.hooked:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end_of_backward)
+            _WGRADS.hooked = True
+        except RuntimeError:                      # not inside a backward pass (a test driving _layer_backward by hand): the
+            pass                                  # caller flushes
 
 
 class _TransformerLayer(torch.autograd.Function):
@@ -731,8 +857,9 @@ class _TransformerLayer(torch.autograd.Function):
         ctx.keep = None
         if ctx.done_cb is not None:
             _WGRADS.callbacks.append((ctx.done_cb, ctx.layer))
-        if getattr(ctx.layer, "_cogv_index", 0) % wgrad_group_layers(ctx.layer) == 0:
-            flush_weight_grads()
+        idx = getattr(ctx.layer, "_cogv_index", 0)
+        if idx % wgrad_group_layers(ctx.layer) == 0:
+            flush_weight_grads(final=(idx == 0))
         return dx, None, None, None, None, None, None
 
 

@@ -39,12 +39,13 @@ def _stream():
 _WS = {}
 
 
-def workspace(tag, nbytes, device):
-    """Stream-ordered scratch (one buffer per tag and device, grown geometrically)."""
+def workspace(tag, nbytes, device, floor=1 << 20):
+    """Stream-ordered scratch (one buffer per tag and device, grown geometrically; `floor`: smallest allocation -- 0 for the
+    small per-stream tags)."""
     key = (tag, device.index if device.index is not None else torch.cuda.current_device())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+        buf = torch.empty(max(int(nbytes * 1.25), int(floor), 256), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
 
@@ -137,22 +138,38 @@ def collect_gemm_timing():
         tot_ms += ms
         tot_fl += fl
         tot_by += nbytes
-        a = by.setdefault(variant, [0.0, 0.0, 0])
+        a = by.setdefault(variant, [0.0, 0.0, 0, 0.0])
         a[0] += fl
         a[1] += ms
         a[2] += 1
+        a[3] += nbytes
         if len(rec_i) > 5:
-            a = shapes.setdefault(f"{variant} {rec_i[5]}", [0.0, 0.0, 0])
+            a = shapes.setdefault(f"{variant} {rec_i[5]}", [0.0, 0.0, 0, 0.0])
             a[0] += fl
             a[1] += ms
             a[2] += 1
+            a[3] += nbytes
     n = max(len(rec), 1)
-    return {"launches": len(rec), "total_ms": tot_ms, "avg_ms": tot_ms / n, "algo_bytes": tot_by,
-            "tflops": tot_fl / max(tot_ms, 1e-9) / 1e9,
-            "by_variant": {k: {"tflops": v[0] / max(v[1], 1e-9) / 1e9, "launches": v[2], "avg_ms": v[1] / v[2]}
-                           for k, v in by.items()},
-            "by_shape": {k: {"tflops": round(v[0] / max(v[1], 1e-9) / 1e9, 1), "launches": v[2], "avg_ms": round(v[1] / v[2], 4)}
-                         for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])}}
+
+    def agg(keys):
+        """totals over the kernel families `keys` (the GEMM roofline counts GEMM launches only)"""
+        fl, ms, cnt, nb = (sum(by[k][i] for k in keys if k in by) for i in range(4))
+        return {"launches": cnt, "total_ms": ms, "avg_ms": ms / max(cnt, 1), "algo_bytes": nb, "tflops": fl / max(ms, 1e-9) / 1e9}
+
+    def entry(v):
+        return {"tflops": v[0] / max(v[1], 1e-9) / 1e9, "launches": v[2], "avg_ms": v[1] / v[2], "total_ms": v[1],
+                "algo_gbytes_per_s": v[3] / max(v[1], 1e-9) / 1e6}
+
+    out = agg(list(by))
+    out.update({"by_variant": {k: entry(v) for k, v in by.items()},
+                "by_shape": {k: {"tflops": round(v[0] / max(v[1], 1e-9) / 1e9, 1), "launches": v[2], "avg_ms": round(v[1] / v[2], 4),
+                                 "gbytes_per_s": round(v[3] / max(v[1], 1e-9) / 1e6, 1)}
+                             for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])},
+                "gemm": agg(GEMM_FAMILIES)})
+    return out
+
+
+GEMM_FAMILIES = ("NT_fwd", "NN_dgrad", "TN_wgrad", "TN_other")
 
 
 class timed_launch:
@@ -372,13 +389,14 @@ def gemm_grouped(problems, trans_a=True, trans_b=True, accumulate=True):
         L.check(lib.cogv_gemm_grouped(descs, len(problems), _stream()), "cogv_gemm_grouped")
         ev1.record()
         key = {(False, False): "NT_fwd", (False, True): "NN_dgrad", (True, True): "TN_wgrad"}.get((trans_a, trans_b), "TN_other")
-        _GEMM_TIMING.append((key, flops, nbytes, ev0, ev1, "grouped " + "+".join(f"{M}x{N}" for M, N, _ in shapes) + f" K={kmin}"))
+        _GEMM_TIMING.append((key, flops, nbytes, ev0, ev1, f"grouped, {tiles} tiles of 256x256 ({tiles / 256:.2f} rounds), K={kmin}"))
     else:
         L.check(lib.cogv_gemm_grouped(descs, len(problems), _stream()), "cogv_gemm_grouped")
 
 
 # ------------------------------------------------------------------------------------------ Sandwich-LN
 LN_ALL_T, LN_STREAM_IN, LN_STREAM_OUT = 0, 1, 2       # cogview_hip.h COGV_LN_*
+_LN_MODE_NAME = {0: "16-bit", 1: "stream in (fp32 -> 16-bit)", 2: "stream out (16-bit + fp32 -> fp32)"}
 
 
 def sandwich_ln_fwd(x, gamma, beta, eps, absmax_in, residual=None, absmax_out=None, save_stats=True):
@@ -408,9 +426,12 @@ def sandwich_ln_fwd(x, gamma, beta, eps, absmax_in, residual=None, absmax_out=No
     y = torch.empty((rows, h), dtype=ydt, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
-    L.check(L.lib().cogv_sandwich_ln_fwd(dt_code(gamma), _p(x2), _p(gamma), _p(beta), _p(r2), _p(y), _p(mean), _p(rstd),
-                                         _p(absmax_in), _p(absmax_out), rows, h, float(eps), mode, _stream()),
-            "cogv_sandwich_ln_fwd")
+    # algorithmic HBM bytes: x + y (+ residual), each in its own width
+    nbytes = rows * h * (x2.element_size() + y.element_size() + (r2.element_size() if r2 is not None else 0))
+    with timed_launch("layernorm", 0.0, nbytes, "ln_fwd " + _LN_MODE_NAME[mode] + (" + residual" if r2 is not None and mode == LN_ALL_T else "")):
+        L.check(L.lib().cogv_sandwich_ln_fwd(dt_code(gamma), _p(x2), _p(gamma), _p(beta), _p(r2), _p(y), _p(mean), _p(rstd),
+                                             _p(absmax_in), _p(absmax_out), rows, h, float(eps), mode, _stream()),
+                "cogv_sandwich_ln_fwd")
     return y.view(x.shape), mean, rstd
 
 
@@ -444,13 +465,34 @@ def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=
     nbytes = lib.cogv_ln_bwd_workspace_bytes(rows, h)
     ws = workspace("ln_bwd", nbytes, x.device)
     p, seed, sid = (0.0, 0, 0) if dropout is None else dropout
-    L.check(lib.cogv_sandwich_ln_bwd(dt_code(gamma), _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(a2), _p(dx),
-                                     _p(dgamma), _p(dbeta), _p(colsum), int(accumulate), rows, h, float(p), int(seed),
-                                     int(sid), _p(ws), ws.numel(), mode, _stream()), "cogv_sandwich_ln_bwd")
+    nb = rows * h * (dy2.element_size() + x2.element_size() + dx.element_size() + (a2.element_size() if a2 is not None else 0))
+    label = "ln_bwd " + _LN_MODE_NAME[mode] + (" + dropout replay" if p > 0.0 else "") + (" + add" if a2 is not None else "")
+    with timed_launch("layernorm", 0.0, nb, label):
+        L.check(lib.cogv_sandwich_ln_bwd(dt_code(gamma), _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(a2), _p(dx),
+                                         _p(dgamma), _p(dbeta), _p(colsum), int(accumulate), rows, h, float(p), int(seed),
+                                         int(sid), _p(ws), ws.numel(), mode, _stream()), "cogv_sandwich_ln_bwd")
     return dx.view(x.shape)
 
 
 # ------------------------------------------------------------------------------------------ attention
+def attention_executed_flops(b, H, s_q, s_k, sep=0, dense=True):
+    """FLOPs the forward attention kernel EXECUTES: 64 x 64 score blocks that hold at least one visible key (left-to-right rule
+    with the fully visible prefix `sep`; a masked block is skipped, a diagonal block computed whole), 2 products of
+    2 * 64 * 64 * 64 FLOPs each.  s = 1088: 153 of 289 blocks ("causal-discounted").  Forms that visit
+    every block (arbitrary mask tensors, gathered / sparse keys) count all of them."""
+    nq, nk = (s_q + 63) // 64, (s_k + 63) // 64
+    if dense:
+        off = s_k - s_q
+        sep_i = int(sep) if isinstance(sep, int) else 0
+        blocks = 0
+        for i in range(nq):
+            last_key = max(min(s_q, 64 * i + 64) - 1 + off, sep_i - 1)        # last visible key of the block's last query
+            blocks += max(0, min(nk, last_key // 64 + 1))
+    else:
+        blocks = nq * nk
+    return float(b) * H * blocks * 4.0 * 64 * 64 * 64
+
+
 def _attn_strides(t):
     # t: [b, s, heads, 64] view with d contiguous and heads packed (stride 64)
     assert t.dim() == 4 and t.shape[-1] == 64 and t.stride(3) == 1 and (t.stride(2) == 64 or t.shape[2] == 1)
@@ -513,7 +555,9 @@ def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None, keep
     if keep_bits and STORE_KEEP_BITS and dropout is not None and dropout[0] > 0.0 and kv_index is None and sparse is None and mask is None:
         bits = torch.empty(L.lib().cogv_attention_keep_bits_bytes(b, H, s_q, k.shape[1]), dtype=torch.uint8, device=q.device)
         d.keep_bits = bits.data_ptr()
-    L.check(L.lib().cogv_attention_fwd(C.byref(d), _stream()), "cogv_attention_fwd")
+    fl = 0.0 if _GEMM_TIMING is None else attention_executed_flops(b, H, s_q, d.s_k, sep, dense=(kv_index is None and sparse is None and mask is None))
+    with timed_launch("attention", fl, 0.0, f"attn_fwd {b}x{H}x{s_q}x{d.s_k}" + (" dropout" if dropout is not None else "")):
+        L.check(L.lib().cogv_attention_fwd(C.byref(d), _stream()), "cogv_attention_fwd")
     return (o, lse, bits) if keep_bits else (o, lse)
 
 
@@ -648,7 +692,10 @@ def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, 
         rows = b * ((s_q + 127) // 128)
         ws = workspace("attn_colsum", rows * 3 * H * 64 * 4, q.device)
         d.colsum_partial = ws.data_ptr()
-    L.check(L.lib().cogv_attention_bwd(C.byref(d), _stream()), "cogv_attention_bwd")
+    # 5 block products against the forward's 2
+    fl = 0.0 if _GEMM_TIMING is None else 2.5 * attention_executed_flops(b, H, s_q, k.shape[1], sep, dense=mask is None)
+    with timed_launch("attention", fl, 0.0, f"attn_bwd {b}x{H}x{s_q}x{k.shape[1]} (D, dQ, dK.dV)" + (" dropout" if dropout is not None else "")):
+        L.check(L.lib().cogv_attention_bwd(C.byref(d), _stream()), "cogv_attention_bwd")
     if fuse:
         L.check(L.lib().cogv_colsum_finalize(dt_code(q), d.colsum_partial, rows, 3 * H * 64, _p(colsum_out),
                                              int(colsum_accumulate), _stream()), "cogv_colsum_finalize")
@@ -813,9 +860,12 @@ def grad_stats(flat_grads, chunk_start, chunk_len, chunk_norm, stats):
     lib = L.lib()
     # the partial sums of the pass: scratch owned by this side of the C ABI, one buffer per (device, stream) so that two
     # streams running the pass concurrently do not share it
-    ws = workspace("grad_stats_%x" % (_stream() or 0), lib.cogv_grad_stats_workspace_bytes(), flat_grads.device)
-    L.check(lib.cogv_grad_stats(dt_code(flat_grads), _p(flat_grads), _p(chunk_start), _p(chunk_len),
-                                _p(chunk_norm), chunk_start.numel(), _p(stats), _p(ws), ws.numel(), _stream()), "cogv_grad_stats")
+    # (keyed on the stream handle as an INT: _stream() is a ctypes.c_void_p, which '%x' refuses on any non-default stream)
+    sid = int(torch.cuda.current_stream(flat_grads.device).cuda_stream or 0)
+    ws = workspace("grad_stats_%x" % sid, lib.cogv_grad_stats_workspace_bytes(), flat_grads.device, floor=0)
+    with timed_launch("grad_stats", 0.0, flat_grads.numel() * flat_grads.element_size(), "overflow flag + per-chunk sum of squares"):
+        L.check(lib.cogv_grad_stats(dt_code(flat_grads), _p(flat_grads), _p(chunk_start), _p(chunk_len),
+                                    _p(chunk_norm), chunk_start.numel(), _p(stats), _p(ws), ws.numel(), _stream()), "cogv_grad_stats")
 
 
 def adamw_step(params, grads, master, exp_avg, exp_avg_sq, chunk_start, chunk_len, chunk_group, lrs, wds, beta1,
@@ -837,7 +887,9 @@ def adamw_step(params, grads, master, exp_avg, exp_avg_sq, chunk_start, chunk_le
     d.inv_loss_scale, d.max_grad_norm = float(inv_loss_scale), float(max_grad_norm)
     d.stats = None if stats is None else stats.data_ptr()
     d.norm_sumsq_override = None if sumsq_override is None else sumsq_override.data_ptr()
-    L.check(L.lib().cogv_adamw_step(C.byref(d), _stream()), "cogv_adamw_step")
+    # algorithmic bytes per parameter: 16-bit gradient in, master + two moments read and written (3 x 8), 16-bit parameter out
+    with timed_launch("adamw", 0.0, params.numel() * (2 * params.element_size() + 24), "fused unscale + clip + AdamW + 16-bit copy-out"):
+        L.check(L.lib().cogv_adamw_step(C.byref(d), _stream()), "cogv_adamw_step")
 
 
 def cast_flat(src_half, dst_f32):

@@ -578,3 +578,85 @@ def test_decode_chain_launch_sequence_and_absmax_contract(monkeypatch):
     last = calls[-1]
     assert last[0] == "gemv_ln" and last[1] == (V_, H_) and last[2] and last[3]
     assert all(s.out is s.cache for s in slots)
+
+
+def test_weight_gradient_queue_launches_whole_rounds_and_covers_every_tile_row(monkeypatch):
+    """functional._DeferredWeightGrads (round 5): every non-final flush launches a multiple of 256 tiles (at most the rounds the
+    flushed layer group would have paid), cut along tile rows of dW; the final flush takes the rest.  Driven on a recording
+    stub of ops.gemm_grouped that really computes dW (+)= dY^T X on the CPU: every row of every gradient is written exactly
+    once (bit-equal to the one-shot product), a partial last tile row is never launched on its own, layer callbacks fire in
+    backward order once all of the layer's problems are out, and the 4B tile arithmetic gives 234 rounds instead of 249."""
+    import math
+    import types
+    import torch
+    from cogview_amd import functional as F_
+
+    launches = []
+
+    class Ops:
+        @staticmethod
+        def gemm_grouped(problems, trans_a=True, trans_b=True, accumulate=True):
+            assert trans_a and trans_b and 1 <= len(problems) <= 16
+            tiles = 0
+            for dy, x, out, acc in problems:
+                assert dy.shape[1] == out.shape[0] and out.shape[0] >= 256 and dy.stride(1) == 1 and out.stride(1) == 1
+                prod = dy.t().float() @ x.float()
+                out.copy_(out + prod if acc else prod)
+                tiles += ((out.shape[0] + 255) // 256) * ((out.shape[1] + 255) // 256)
+            launches.append(tiles)
+
+    monkeypatch.setattr(F_, "ops", Ops)
+    monkeypatch.setattr(F_, "_WGRADS", F_._DeferredWeightGrads())
+    monkeypatch.setattr(F_, "WGRAD_QUEUE", True)
+    monkeypatch.setattr(F_, "grad_accumulate", lambda *ps: False)        # fresh gradients: every chunk overwrites its rows
+    torch.manual_seed(0)
+    tok = 64
+
+    def prob(o, i):
+        w = torch.nn.Parameter(torch.zeros(o, i))
+        w.grad = torch.full((o, i), float("nan"))                       # any row no chunk writes stays NaN
+        return torch.randn(tok, o), torch.randn(tok, i), w
+
+    # "logits" 2304 + 128 rows (partial last tile row) x 512: 10 x 2 = 20 tiles; per layer 3 problems of 2 x 8 + 8 x 2 + 2 x 2 = 36 tiles
+    fired, all_probs = [], []
+    owners = [types.SimpleNamespace(name=f"layer{i}") for i in range(5)]
+    logits = prob(2304 + 128, 512)
+    all_probs.append(logits)
+    F_._WGRADS.add(*logits)
+    monkeypatch.setattr(F_, "WGRAD_ROUND_TILES", 8)       # a "round" of 8 tile slots, so that the toy sizes exercise the arithmetic
+    flush = lambda final: F_.flush_weight_grads(final=final)
+
+    for li, owner in enumerate(owners):
+        for o, i in ((512, 2048), (2048, 512), (512, 512)):
+            p_ = prob(o, i)
+            all_probs.append(p_)
+            F_._WGRADS.add(*p_, owner=owner)
+        F_._WGRADS.callbacks.append((lambda l: fired.append(l.name), owner))
+        n_before = len(launches)
+        flush(final=(li == len(owners) - 1))
+        if li < len(owners) - 1:
+            assert len(launches) == n_before + 1 and launches[-1] % 8 == 0 and launches[-1] <= 40      # 36 own tiles: <= 5 "rounds"
+    assert not F_._WGRADS.entries and not F_._WGRADS.callbacks
+    assert fired == [o.name for o in owners]
+    assert sum(launches) == 20 + 5 * 36
+    for dy, x, w in all_probs:
+        assert torch.equal(w.grad, dy.t().float() @ x.float())           # every row written once, same product
+
+    # the real constants on the 4B shapes: tied logits (58240 rows, partial last tile row) + 48 layers
+    ent, rounds, sizes = [[0, 228, 10, 58240]], 0, []
+    for layer in range(48):
+        ent = [e for e in ent if e[0] < e[1]]
+        ent = [[0, 10, 40, 2560], [0, 40, 10, 10240], [0, 10, 10, 2560], [0, 30, 10, 7680]] + ent      # a layer's own problems first
+        pending = sum((e[1] - e[0]) * e[2] for e in ent)
+        budget = None if layer == 47 else min(1280, pending // 256 * 256)
+        plan = F_.plan_wgrad_chunks([tuple(e) for e in ent], budget)
+        t = 0
+        for i, t0, t1 in plan:
+            assert t0 == ent[i][0] and min(256 * t1, ent[i][3]) - 256 * t0 >= 256
+            ent[i][0] = t1
+            t += (t1 - t0) * ent[i][2]
+        assert budget is None or (t <= budget and budget - t < 10)
+        sizes.append(t)
+        rounds += math.ceil(t / 256)
+    assert all(e[0] == e[1] for e in ent) and sum(sizes) == 48 * 1200 + 2280
+    assert rounds == 234 and 48 * 5 + 9 == 249

@@ -1015,3 +1015,59 @@ def test_forward_nan_guard_skips_the_step_without_touching_the_loss_scale(golden
     assert sk2 == 0 and skr == 0 and loss2.item() == lossr.item()
     for p, q in zip(model.module.parameters(), ref_model.module.parameters()):
         assert torch.equal(p.detach(), q.detach())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_weight_gradient_queue_is_bit_identical_to_one_launch_per_layer(monkeypatch, dtype):
+    """functional._DeferredWeightGrads (round 5): the weight gradients of the layers and of the tied logits cut into launches
+    of whole rounds of 256 x 256 tiles (tile rows of one problem spread over several grouped launches, the tied-logits
+    gradient riding in the layers' free tile slots, its partial last tile row never alone) against the round-4 form (every
+    flush launches all it has, the logits' gradient is a launch of its own): every parameter gradient bit for bit the same,
+    with and without a gradient already in the arena (accumulate)."""
+    from cogview_amd import functional as F_
+    from cogview_amd import mpu
+    from cogview_amd.fp16 import FP16_Module
+    from cogview_amd.model import GPT2Model
+    L_, V_, H_, NH_, S_, B_ = 5, 2304 + 128, 512, 8, 128, 4            # 512 tokens; per layer 16 + 16 + 4 + 12 = 48 tiles, logits 10 x 2
+    torch.manual_seed(11)
+    m = GPT2Model(L_, V_, H_, NH_, 0.1, 0.1, 0.1, S_, 0, False)
+    model = FP16_Module(m.cuda(), dtype=dtype, keep_half_outputs=True).train()
+    tokens = torch.randint(0, V_, (B_, S_), device="cuda")
+    labels = torch.randint(0, V_, (B_, S_), device="cuda")
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    launches = []
+    real = F_.ops.gemm_grouped
+
+    def spy(problems, **kw):
+        launches.append(sum(((p[2].shape[0] + 255) // 256) * ((p[2].shape[1] + 255) // 256) for p in problems))
+        return real(problems, **kw)
+
+    monkeypatch.setattr(F_.ops, "gemm_grouped", spy)
+    grads = {}
+    for queue in (False, True):
+        monkeypatch.setattr(F_, "WGRAD_QUEUE", queue)
+        monkeypatch.setattr(F_, "WGRAD_ROUND_TILES", 32)             # a "round" of 32 tile slots: 48-tile layers get cut
+        monkeypatch.setattr(F_, "_WGRAD_GROUP_CACHE", {})
+        monkeypatch.setattr(F_, "WGRAD_GROUP_LAYERS", 1)
+        del launches[:]
+        got = []
+        model.module._cogv_arena.zero_grad()
+        for rep in range(2):                                         # second pass accumulates into the first pass's gradients
+            mpu.model_parallel_cuda_manual_seed(77)                  # same dropout streams in both modes
+            logits, = model(tokens, pos, 0, None, None, 0)
+            loss = mpu.vocab_parallel_cross_entropy(logits.contiguous(), labels).mean()
+            (loss * 64.0).backward()
+            torch.cuda.synchronize()
+            assert not F_._WGRADS.entries and not F_._WGRADS.callbacks
+            got.append({n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None})
+        grads[queue] = got
+        if queue:
+            assert sum(launches) == 2 * (L_ * 48 + 20) and max(launches[:L_ - 1]) <= 64, launches
+            assert any(t not in (48, 68) for t in launches), launches        # problems really were cut along their tile rows
+        else:
+            assert launches[:L_] == [48] * (L_ - 1) + [48], launches
+    for rep in range(2):
+        assert set(grads[True][rep]) == set(grads[False][rep])
+        for n in grads[False][rep]:
+            assert torch.equal(grads[True][rep][n], grads[False][rep][n]), (rep, n)
+        assert all(bool(torch.isfinite(t).all()) for t in grads[True][rep].values())

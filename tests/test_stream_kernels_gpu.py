@@ -255,3 +255,29 @@ def test_clip_grad_norm_is_one_pass_per_storage_and_exact():
     assert sorted(calls) == [1, 1, 3], calls            # arena views sharing a table (3 chunks), the odd-offset view, the bf16 tensor
     for p, b0 in zip(params, before):
         assert ((p.grad.float() - 0.5 * b0.float()).abs().max() <= 4e-3 * b0.float().abs().max()).item()
+
+
+def test_grad_stats_and_clip_grad_norm_on_a_side_stream():
+    """The norm / overflow pass under torch.cuda.stream(non-default): its per-stream scratch is keyed on the stream handle (round-4
+    advisor finding: a ctypes handle in a '%x' format raised TypeError on every stream but the default one); same value as on
+    the default stream, and the two streams get separate scratch buffers."""
+    from cogview_amd import mpu, ops
+    g = torch.Generator().manual_seed(5)
+    flat = (torch.randn(3 * 4096 + 100, generator=g)).half().cuda()
+    ref = float((flat.double() ** 2).sum()) ** 0.5
+
+    def run():
+        p = torch.nn.Parameter(torch.zeros_like(flat))
+        p.grad = flat.clone()
+        p.model_parallel = False
+        return mpu.clip_grad_norm([p], 1e9)
+
+    want = run()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    n_ws = len(ops._WS)
+    with torch.cuda.stream(side):
+        got = run()
+    side.synchronize()
+    assert got == want and abs(got - ref) < 1e-6 * ref
+    assert len(ops._WS) == n_ws + 1                        # a scratch buffer of its own for the side stream
