@@ -1,0 +1,313 @@
+"""CPU restatement of the `cogview_amd.ops` entry points a GPT train step calls -- TEST INFRASTRUCTURE ONLY.
+
+`install(monkeypatch_like)` replaces those functions on the `cogview_amd.ops` module with plain torch-CPU code of the same
+signatures and semantics (include/cogview_hip.h is the specification; fp32 arithmetic, results rounded to the storage type
+where the kernels round).  It exists so that the HOST side of the path -- the `mpu` / `model` / `fp16` mirrors, the fused
+layer Function, the gradient arena, the fused optimizer's control flow, and the REFERENCE's own driver functions calling them
+(tests/test_reference_drivers_cpu.py) -- can execute end to end in a container without a GPU.  Nothing in the product
+imports this file; the product path fails loudly without the HIP library (tests/test_abi.py).  Dropout is not emulated
+(every caller here runs with p = 0), nor are the decode / sparse / gathered forms.
+"""
+import math
+
+import torch
+
+_HALF = (torch.float16, torch.bfloat16)
+
+
+def _gelu(x):
+    return 0.5 * x * (1.0 + torch.tanh(0.7978845608028654 * x * (1.0 + 0.044715 * x * x)))
+
+
+def _gelu_grad(x):
+    u = 0.7978845608028654 * x * (1.0 + 0.044715 * x * x)
+    t = torch.tanh(u)
+    return 0.5 * (1.0 + t) + 0.5 * x * (1.0 - t * t) * 0.7978845608028654 * (1.0 + 3.0 * 0.044715 * x * x)
+
+
+def _no_dropout(d):
+    assert d is None or d[0] == 0.0, "tests/cpu_ops.py does not emulate dropout"
+
+
+def new_absmax_slot(device):
+    return torch.zeros(1, dtype=torch.float32)
+
+
+def _publish(slot, t):
+    if slot is not None:
+        slot.copy_(torch.maximum(slot, t.detach().float().abs().max().view(1)))
+
+
+def absmax(x, out=None):
+    if out is None:
+        out = new_absmax_slot(x.device)
+    _publish(out, x)
+    return out
+
+
+def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, gelu_aux=None, dgelu_aux=None, dropout=None,
+         absmax=None, accumulate=False, splitk=None, out_dtype=None, variant=0, colsum_out=None, colsum_accumulate=True,
+         gelu_daux=None, mul_aux=None):
+    _no_dropout(dropout)
+    A = a.float().t() if trans_a else a.float()
+    B = b.float() if trans_b else b.float().t()
+    c = A @ B
+    if bias is not None:
+        c = c + bias.float()
+    if gelu:
+        pre = c
+        if gelu_aux is not None:
+            gelu_aux.copy_(pre)
+        if gelu_daux is not None:
+            gelu_daux.copy_(_gelu_grad(pre))
+        c = _gelu(pre)
+    if dgelu_aux is not None:
+        c = c * _gelu_grad(dgelu_aux.float())
+    if mul_aux is not None:
+        c = c * mul_aux.float()
+    if out is None:
+        assert not accumulate
+        out = torch.empty(c.shape, dtype=out_dtype or a.dtype)
+    if accumulate:
+        c = c + out.float()
+    out.copy_(c)
+    _publish(absmax, out)
+    if colsum_out is not None:
+        colsum(out, out=colsum_out, accumulate=colsum_accumulate)
+    return out
+
+
+def gemm_grouped(problems, trans_a=True, trans_b=True, accumulate=True):
+    assert 1 <= len(problems) <= 16
+    for pr in problems:
+        a, b, out = pr[:3]
+        assert out.shape[0] >= 1 and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+        gemm(a, b, trans_a=trans_a, trans_b=trans_b, out=out, accumulate=pr[3] if len(pr) > 3 else accumulate)
+
+
+def colsum(dy, out=None, accumulate=False):
+    s = dy.float().sum(0)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(dy.shape[1], dtype=dy.dtype)
+    out.copy_(s + out.float() if accumulate else s)
+    return out
+
+
+def sandwich_ln_fwd(x, gamma, beta, eps, absmax_in, residual=None, absmax_out=None, save_stats=True):
+    h = x.shape[-1]
+    xf = x.reshape(-1, h).float()
+    e = float(eps)
+    if absmax_in is not None:
+        c = float(absmax_in) * 0.125
+        e = e * c * c
+    mean = xf.mean(1)
+    var = ((xf - mean[:, None]) ** 2).mean(1)
+    rstd = 1.0 / torch.sqrt(var + e)
+    y = (xf - mean[:, None]) * rstd[:, None] * gamma.float() + beta.float()
+    if residual is not None and residual.dtype == torch.float32:
+        y = residual.reshape(-1, h) + y                              # the fp32 stream: no rounding in between
+    else:
+        y = y.to(gamma.dtype)
+        if residual is not None:
+            y = (y.float() + residual.reshape(-1, h).float()).to(gamma.dtype)
+    _publish(absmax_out, y)
+    return y.view(x.shape), (mean if save_stats else None), (rstd if save_stats else None)
+
+
+def _accum_param_grad(dst, val, accumulate):
+    if dst is not None:
+        dst.copy_(val + dst.float() if accumulate else val)
+
+
+def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=None, dbeta=None, colsum=None, accumulate=False):
+    _no_dropout(dropout)
+    h = x.shape[-1]
+    dyf, xf = dy.reshape(-1, h).float(), x.reshape(-1, h).float()
+    xh = (xf - mean[:, None]) * rstd[:, None]
+    g = dyf * gamma.float()
+    dx = rstd[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+    if add_in is not None:
+        dx = dx + add_in.reshape(-1, h).float()
+    dx = dx.to(x.dtype)                                              # fp32 for the stream forms' fp32 x, else the storage type
+    _accum_param_grad(dgamma, (dyf * xh).sum(0), accumulate)
+    _accum_param_grad(dbeta, dyf.sum(0), accumulate)
+    _accum_param_grad(colsum, dx.float().sum(0), accumulate)
+    return dx.view(x.shape)
+
+
+def _visible(s_q, s_k, sep):
+    i = torch.arange(s_q)[:, None]
+    j = torch.arange(s_k)[None, :]
+    return (j <= i + (s_k - s_q)) | (j < int(sep))
+
+
+def _attn(q, k, v, sep):
+    # q [b, s_q, H, 64] -> scores [b, H, s_q, s_k]; reference order: Q / sqrt(d) first (mpu/sparse_transformer.py:653-659)
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
+    s = (qf / math.sqrt(q.shape[-1])) @ kf.transpose(-1, -2)
+    vis = _visible(q.shape[1], k.shape[1], sep)
+    s = torch.where(vis, s, torch.full_like(s, -10000.0))
+    lse = torch.logsumexp(s, -1)
+    o = torch.softmax(s, -1) @ vf
+    return o.permute(0, 2, 1, 3), lse
+
+
+def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None, keep_bits=False, mask=None):
+    _no_dropout(dropout)
+    assert kv_index is None and sparse is None and mask is None
+    o, lse = _attn(q, k, v, sep)
+    o = o.contiguous().to(q.dtype)
+    return (o, lse, None) if keep_bits else (o, lse)
+
+
+def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, dv=None, colsum_out=None, colsum_accumulate=True,
+                  keep_bits=None, mask=None):
+    _no_dropout(dropout)
+    qg, kg, vg = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    with torch.enable_grad():
+        out, _ = _attn(qg, kg, vg, sep)
+        gq, gk, gv = torch.autograd.grad(out, (qg, kg, vg), dout.float())
+    outs = []
+    for dst, g in ((dq, gq), (dk, gk), (dv, gv)):
+        if dst is None:
+            dst = torch.empty(g.shape, dtype=q.dtype)
+        dst.copy_(g)
+        outs.append(dst)
+    if colsum_out is not None:
+        H = q.shape[2]
+        for i, t in enumerate(outs):
+            colsum(t.reshape(-1, H * 64), out=colsum_out[i * H * 64:(i + 1) * H * 64], accumulate=colsum_accumulate)
+    return tuple(outs)
+
+
+def embedding_fwd(ids, table, vocab_start, pos_ids=None, pos_table=None, dropout=None, absmax_out=None, x_in=None, out_f32=False):
+    _no_dropout(dropout)
+    src = table if table is not None else x_in
+    if ids is not None:
+        local = ids - vocab_start
+        ok = (local >= 0) & (local < table.shape[0])
+        x = table.float()[local.clamp(0, table.shape[0] - 1)] * ok[..., None]
+    else:
+        x = x_in.float()
+    if pos_table is not None:
+        x = x + pos_table.float()[pos_ids.expand(x.shape[:-1])]
+    out = x if out_f32 else x.to(src.dtype)
+    _publish(absmax_out, out)
+    return out.contiguous()
+
+
+def embedding_bwd(dout, ids, dtable, vocab_start, pos_ids=None, dpos=None, dropout=None, dx=None):
+    _no_dropout(dropout)
+    h = dout.shape[-1]
+    d2 = dout.reshape(-1, h).float()
+    if dtable is not None and ids is not None:
+        local = (ids - vocab_start).reshape(-1)
+        ok = (local >= 0) & (local < dtable.shape[0])
+        acc = torch.zeros(dtable.shape, dtype=torch.float32).index_add_(0, local[ok], d2[ok])
+        dtable.copy_(dtable.float() + acc)
+    if dpos is not None:
+        p = pos_ids.expand(dout.shape[:-1]).reshape(-1)
+        acc = torch.zeros(dpos.shape, dtype=torch.float32).index_add_(0, p, d2)
+        dpos.copy_(dpos.float() + acc)
+    if dx is not None:
+        dx.copy_(dout)
+
+
+def ce_fwd(logits2d, target1d, vocab_start, want_loss=True):
+    lf = logits2d.float()
+    rowmax = lf.max(1).values
+    sumexp = torch.exp(lf - rowmax[:, None]).sum(1)
+    local = target1d - vocab_start
+    ok = (local >= 0) & (local < lf.shape[1])
+    pred = lf.gather(1, local.clamp(0, lf.shape[1] - 1)[:, None])[:, 0] * ok
+    loss = torch.log(sumexp) + rowmax - pred if want_loss else None
+    return rowmax, sumexp, pred, loss
+
+
+def ce_bwd(logits2d, target1d, vocab_start, gmax, gsum, grad, out=None):
+    lf = logits2d.float()
+    d = torch.exp(lf - gmax[:, None]) / gsum[:, None]
+    local = target1d - vocab_start
+    ok = (local >= 0) & (local < lf.shape[1])
+    rows = torch.arange(lf.shape[0])[ok]
+    d[rows, local[ok]] -= 1.0
+    d = d * grad[:, None]
+    if out is None:
+        out = torch.empty_like(logits2d)
+    out.copy_(d)
+    return out
+
+
+def grad_stats(flat_grads, chunk_start, chunk_len, chunk_norm, stats):
+    g = flat_grads.double()
+    tot, bad = 0.0, 0.0
+    for s, n, cnt in zip(chunk_start.tolist(), chunk_len.tolist(), chunk_norm.tolist()):
+        piece = g[s:s + n]
+        if not bool(torch.isfinite(piece).all()):
+            bad = 1.0
+        if cnt:
+            tot += float((piece * piece).sum())
+    stats[0] += tot
+    if bad:
+        stats[1] = 1.0
+
+
+def adamw_step(params, grads, master, exp_avg, exp_avg_sq, chunk_start, chunk_len, chunk_group, lrs, wds, beta1, beta2, eps, step,
+               inv_loss_scale=1.0, max_grad_norm=0.0, stats=None, sumsq_override=None, bias_correction=True, adam_w_mode=True):
+    if stats is not None and float(stats[1]) != 0.0:
+        return
+    gscale = float(inv_loss_scale)
+    if max_grad_norm > 0.0 and stats is not None:
+        ss = float(sumsq_override) if sumsq_override is not None else float(stats[0])
+        coef = max_grad_norm / (math.sqrt(ss) * inv_loss_scale + 1.0e-6)
+        if coef < 1.0:
+            gscale *= coef
+    bc1 = 1.0 - beta1 ** step if bias_correction else 1.0
+    bc2 = 1.0 - beta2 ** step if bias_correction else 1.0
+    for s, n, grp in zip(chunk_start.tolist(), chunk_len.tolist(), chunk_group.tolist()):
+        lr, wd = float(lrs[grp & 7]), float(wds[grp & 7])
+        sl = slice(s, s + n)
+        g = grads[sl].float() * gscale
+        w, m, v = master[sl], exp_avg[sl], exp_avg_sq[sl]
+        if not adam_w_mode:
+            g = g + wd * w
+        m.mul_(beta1).add_(g, alpha=1.0 - beta1)
+        v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+        upd = (m / bc1) / (torch.sqrt(v) / math.sqrt(bc2) + eps)
+        if adam_w_mode:
+            upd = upd + wd * w
+        w.sub_(lr * upd)
+        params[sl].copy_(w)
+
+
+def cast_flat(src_half, dst_f32):
+    dst_f32.copy_(src_half)
+
+
+def cast_flat_back(src_f32, dst_half):
+    dst_half.copy_(src_f32)
+
+
+def scale(x, s):
+    return (x.float() * s).to(x.dtype)
+
+
+def add(a, b, absmax_out=None):
+    out = (a.float() + b.float()).to(torch.float32 if a.dtype == torch.float32 else a.dtype)
+    _publish(absmax_out, out)
+    return out
+
+
+NAMES = ("new_absmax_slot", "absmax", "gemm", "gemm_grouped", "colsum", "sandwich_ln_fwd", "sandwich_ln_bwd", "attention_fwd",
+         "attention_bwd", "embedding_fwd", "embedding_bwd", "ce_fwd", "ce_bwd", "grad_stats", "adamw_step", "cast_flat",
+         "cast_flat_back", "scale", "add")
+
+
+def install(setattr_fn=None):
+    """Replace the entry points on the cogview_amd.ops module (setattr_fn: e.g. monkeypatch.setattr; default: plain setattr)."""
+    from cogview_amd import ops
+    g = globals()
+    for n in NAMES:
+        (setattr_fn or setattr)(ops, n, g[n])
+    return ops
