@@ -37,6 +37,18 @@ constexpr int HD = 64;          // head dim
 constexpr int NT = 256;         // threads per block (4 waves)
 constexpr float MASKED = -10000.0f;
 constexpr int TILE = 8192;      // one 64 x 64 16-bit tile
+// Stages of the K|V (forward, dQ) / Q|dO (dK.dV) LDS ring = prefetch distance + 1.  Three stages keep two blocks in flight per
+// workgroup (48-53 KiB: three workgroups per CU); two stages (32-36 KiB, one block in flight: it still has a whole block's
+// compute, ~2 us, to land) let four to five workgroups share a CU -- the kernels are parked 29-35 % of their wave cycles
+// (profiles/r05_attention_pmc.txt: ramp-up, diagonal blocks and tails of 20-us workgroups), which more resident workgroups
+// cover better than a deeper prefetch.  A/B: profiles/r05_attention_stages_ab.log.
+#ifndef COGV_ATTN_STAGES
+#define COGV_ATTN_STAGES 3
+#endif
+constexpr int NSTG = COGV_ATTN_STAGES;
+static_assert(NSTG == 2 || NSTG == 3, "ring of two or three stages");
+constexpr int COLSUM_SMEM = (128 * 68 + 256) * 4;      // tile_colsum's scratch (the ring is free by then)
+constexpr int ring_bytes(int stage, bool colsum) { return (colsum && NSTG * stage < COLSUM_SMEM) ? COLSUM_SMEM : NSTG * stage; }
 
 struct AttnArgs {
   const void* q; const void* k; const void* v; void* o;        // forward
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   // K and V; the table (<= 4096 slots) is staged once behind the ring
   int* lidx = nullptr;
   if (IDX && p.kv_index) {
-    lidx = reinterpret_cast<int*>(smem + 3 * STAGE);
+    lidx = reinterpret_cast<int*>(smem + NSTG * STAGE);
     const int* gi = p.kv_index + (long long)b * p.kv_index_bs + (long long)gblk * p.kv_index_gs;
     for (int i = threadIdx.x; i < p.s_k; i += NT) lidx[i] = gi[i];
     __syncthreads();
@@ -354,12 +366,12 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
   };
   // DROP == 2: this lane's keep word of key block kb goes to kwp[kb * 2 * s_q]
   uint32_t* const kwp = DROP == 2 ? p.keepbits + ((((long long)b * p.H + head) * ((p.s_k + 63) >> 6)) * 2 + fg) * p.s_q + min(myq, p.s_q - 1) : nullptr;
-  if (nkb > 0) { issue(0, 0); issue(nkb > 1 ? 1 : 0, 1); }
+  if (nkb > 0) { issue(0, 0); if (NSTG > 2) issue(nkb > 1 ? 1 : 0, 1); }
   int st = 0;
   for (int kb = 0; kb < nkb; ++kb) {
-    wait_vmcnt<LPT>();
+    wait_vmcnt<(NSTG - 2) * LPT>();
     __builtin_amdgcn_s_barrier();
-    issue(min(kb + 2, nkb - 1), st == 0 ? 2 : st - 1);
+    issue(min(kb + NSTG - 1, nkb - 1), st == 0 ? NSTG - 1 : st - 1);
     if (kb * 64 < kend_w) {
       const char* lk = smem + st * STAGE;
       const uint32_t lv = smem_addr + st * STAGE + TILE;
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(const AttnArgs p) {
         for (int d = 0; d < 2; ++d) oacc[d] = HT<T>::mfma32(tr_pack<T>(vr2[t][d]), pb, oacc[d]);
       }
     }
-    st = (st == 2) ? 0 : st + 1;
+    st = (st == NSTG - 1) ? 0 : st + 1;
   }
   wait_vmcnt<0>();
   if (wave_active && myq < p.s_q) {
@@ -590,7 +602,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 
   int* lidx = nullptr;
   if (IDX && p.kv_index) {
-    lidx = reinterpret_cast<int*>(smem + 3 * STAGE);
+    lidx = reinterpret_cast<int*>(smem + NSTG * STAGE);
     const int* gi = p.kv_index + (long long)b * p.kv_index_bs + (long long)gblk * p.kv_index_gs;
     for (int i = threadIdx.x; i < p.s_k; i += NT) lidx[i] = gi[i];
     __syncthreads();
@@ -604,12 +616,12 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     if (KB) __builtin_amdgcn_global_load_lds((gbl_void_t*)(KWQ + (long long)kb * 2 * p.s_q),
                                              (lds_void_t*)(smem + st * STAGE + 2 * TILE + wave * 256), 4, 0, 0);
   };
-  if (nkb > 0) { issue(0, 0); issue(nkb > 1 ? 1 : 0, 1); }
+  if (nkb > 0) { issue(0, 0); if (NSTG > 2) issue(nkb > 1 ? 1 : 0, 1); }
   int st = 0;
   for (int kb = 0; kb < nkb; ++kb) {
-    wait_vmcnt<LPT>();
+    wait_vmcnt<(NSTG - 2) * LPT>();
     __builtin_amdgcn_s_barrier();
-    issue(min(kb + 2, nkb - 1), st == 0 ? 2 : st - 1);
+    issue(min(kb + NSTG - 1, nkb - 1), st == 0 ? NSTG - 1 : st - 1);
     if (kb * 64 < kend_w) {
       const char* lk = smem + st * STAGE; const char* lv = lk + TILE;
       const uint32_t lkt = smem_addr + st * STAGE;
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
       half(std::integral_constant<int, 0>{});
       half(std::integral_constant<int, 1>{});
     }
-    st = (st == 2) ? 0 : st + 1;
+    st = (st == NSTG - 1) ? 0 : st + 1;
   }
   wait_vmcnt<0>();
   float rq[2][16];
@@ -814,12 +826,12 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   const int kr = mykey & 31;
   const uint32_t kw_seg = (uint32_t)(((wave >> 1) * 2 + ((kr >> 2) & 1)) * 64);               // word offset of the lane's segment
   const uint32_t kw_bit = 31u - (uint32_t)((wave & 1) * 16 + 4 * (kr >> 3) + (kr & 3));
-  if (qb0 < nqb) { issue(qb0, 0); issue(min(qb0 + 1, nqb - 1), 1); }
+  if (qb0 < nqb) { issue(qb0, 0); if (NSTG > 2) issue(min(qb0 + 1, nqb - 1), 1); }
   int st = 0;
   for (int qb = qb0; qb < nqb; ++qb) {
-    wait_vmcnt<LPT>();
+    wait_vmcnt<(NSTG - 2) * LPT>();
     __builtin_amdgcn_s_barrier();
-    issue(min(qb + 2, nqb - 1), st == 0 ? 2 : st - 1);
+    issue(min(qb + NSTG - 1, nqb - 1), st == 0 ? NSTG - 1 : st - 1);
     if (wave_active && qb * 64 + 63 >= qbeg_w) {
       const char* lq = smem + st * STAGE; const char* ldo = lq + TILE;
       const uint32_t lqt = smem_addr + st * STAGE, ldot = lqt + TILE;
@@ -959,7 +971,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
       half(std::integral_constant<int, 0>{});
       half(std::integral_constant<int, 1>{});
     }
-    st = (st == 2) ? 0 : st + 1;
+    st = (st == NSTG - 1) ? 0 : st + 1;
   }
   wait_vmcnt<0>();
   float rk[2][16], rv[2][16];
@@ -1231,7 +1243,7 @@ extern "C" int cogv_attention_fwd(const cogv_attn_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // one-dimensional XCD-aware grid (xcd_block_id): 8 x ceil(units / 8) x blocks, units = H * B
   dim3 grid(8u * (unsigned)((a.H * a.B + 7) / 8) * (unsigned)((a.s_q + 127) / 128));
-  int sh = 3 * 2 * TILE;
+  int sh = NSTG * 2 * TILE;
   if ((rc = index_args(d, a))) return rc;
   if (a.kv_index) sh += ((a.s_k * 4 + 15) / 16) * 16;
   // dense kernels: dropout on / off are separate instantiations (no wave-uniform branches and register copies at their
@@ -1265,10 +1277,6 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   if (d->kv_index && d->sparse_window <= 0) return COGV_ERR_UNSUPPORTED;      // the plain gathered form is inference only
   if ((rc = index_args(d, a))) return rc;
   if (a.sp_w > 0 && d->colsum_partial) return COGV_ERR_UNSUPPORTED;
-  if (a.mask && !d->kv_index) {        // (the IDX dQ instantiation's shared-memory attribute is set on first use below)
-    static bool attr_m = false;
-    if (!attr_m) { set_smem(&attn_bwd_dq_kernel<f16_t, true, -1>, 3 * 2 * TILE); set_smem(&attn_bwd_dq_kernel<bf16_t, true, -1>, 3 * 2 * TILE); attr_m = true; }
-  }
   if (d->colsum_partial) {
     if (d->s_q != d->s_k || ((uintptr_t)d->colsum_partial & 15)) return COGV_ERR_ARG;
     a.colsum_ws = d->colsum_partial;
@@ -1283,7 +1291,7 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   const int planes = a.sp_w > 0 ? a.B * (a.s_q / a.sp_w) : a.B;
   dim3 gq(8u * (unsigned)((a.H * a.B + 7) / 8) * (unsigned)((a.s_q + 127) / 128));
   dim3 gk(8u * (unsigned)((a.H * planes + 7) / 8) * (unsigned)((a.s_k + 127) / 128));
-  const int sh_q = 3 * 2 * TILE + (a.kv_index ? ((a.s_k * 4 + 15) / 16) * 16 : 0), sh_k = 3 * (2 * TILE + 768);
+  const int sh_q = ring_bytes(2 * TILE, true) + (a.kv_index ? ((a.s_k * 4 + 15) / 16) * 16 : 0), sh_k = ring_bytes(2 * TILE + 768, true);
   if (sh_q > 160 * 1024) return COGV_ERR_UNSUPPORTED;
   static int attr_q = 0;
   static bool attr = false;
@@ -1291,13 +1299,15 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
     set_smem(&attn_bwd_dkdv_kernel<f16_t, false, 0>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false, 0>, sh_k);
     set_smem(&attn_bwd_dkdv_kernel<f16_t, false, 1>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false, 1>, sh_k);
     set_smem(&attn_bwd_dkdv_kernel<f16_t, true, -1>, sh_k); set_smem(&attn_bwd_dkdv_kernel<bf16_t, true, -1>, sh_k);
-    set_smem(&attn_bwd_dq_kernel<f16_t, false, 0>, 3 * 2 * TILE); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 0>, 3 * 2 * TILE);
-    set_smem(&attn_bwd_dq_kernel<f16_t, false, 1>, 3 * 2 * TILE); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 1>, 3 * 2 * TILE);
-    set_smem(&attn_bwd_dq_kernel<f16_t, false, 2>, 3 * (2 * TILE + 1024)); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 2>, 3 * (2 * TILE + 1024));
-    set_smem(&attn_bwd_dkdv_kernel<f16_t, false, 2>, 3 * (2 * TILE + 1536)); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false, 2>, 3 * (2 * TILE + 1536));
+    set_smem(&attn_bwd_dq_kernel<f16_t, false, 0>, ring_bytes(2 * TILE, true)); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 0>, ring_bytes(2 * TILE, true));
+    set_smem(&attn_bwd_dq_kernel<f16_t, false, 1>, ring_bytes(2 * TILE, true)); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 1>, ring_bytes(2 * TILE, true));
+    set_smem(&attn_bwd_dq_kernel<f16_t, false, 2>, ring_bytes(2 * TILE + 1024, true)); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 2>, ring_bytes(2 * TILE + 1024, true));
+    set_smem(&attn_bwd_dkdv_kernel<f16_t, false, 2>, ring_bytes(2 * TILE + 1536, true)); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false, 2>, ring_bytes(2 * TILE + 1536, true));
     attr = true;
   }
-  if (a.kv_index && sh_q > attr_q) {
+  // the flexible dQ instantiation (gathered / sparse keys: ring + index table; arbitrary mask tensors: ring only) shares ONE
+  // attribute, which only ever grows (a smaller later request must not lower it under a launch that still needs more)
+  if ((a.kv_index || a.mask) && sh_q > attr_q) {
     set_smem(&attn_bwd_dq_kernel<f16_t, true, -1>, sh_q); set_smem(&attn_bwd_dq_kernel<bf16_t, true, -1>, sh_q);
     attr_q = sh_q;
   }
@@ -1305,7 +1315,7 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   if (d->keep_bits && drop && !a.kv_index) {      // the keep bits the forward call stored (same dropout_p / seed / stream)
     if ((uintptr_t)d->keep_bits & 3) return COGV_ERR_ARG;
     a.keepbits = reinterpret_cast<uint32_t*>(d->keep_bits);
-    const int shq2 = 3 * (2 * TILE + 1024), shk2 = 3 * (2 * TILE + 1536);
+    const int shq2 = ring_bytes(2 * TILE + 1024, true), shk2 = ring_bytes(2 * TILE + 1536, true);
     if (d->dtype == COGV_F16) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, false, 2>), gq, dim3(NT), shq2, st, a);
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t, false, 2>), gk, dim3(NT), shk2, st, a);
