@@ -180,6 +180,7 @@ def measure_parity(inner, L, heads, row=ROW):
     ids = torch.randint(0, N_TOKEN_IDS, (1, row - 1), generator=torch.Generator().manual_seed(4321)).cuda()
     rep = D.depth_report(inner, ids, L, heads)
     return {"logits_rel_l2": rep["logits"],
+            "logits_rel_l2_with_fp32_output": rep["logits_fp32_out"],     # the same logits without their last rounding to 16 bits
             "residual_stream_rel_l2_after_n_layers": {str(n): e for n, e in rep["stream"].items()},
             "against": "oracle/cogview_oracle.py fp32 on the CPU, all %d layers, the timed model's weights as stored, "
                        "1 sequence x %d positions, dropout off" % (L, row - 1),
@@ -527,6 +528,16 @@ def main():
                                                                                "avg_launch_ms", "share_of_step_time")}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, h, heads, row=ROW_LEN.get(args.config, ROW))
+            # configs[0] is the one case the REFERENCE ITSELF runs on a CPU in seconds: its own forward + CE + backward timed
+            # beside the port where /root/reference exists (the build container: oracle/time_reference_cfg1.py), committed
+            # under profiles/ and quoted here -- kind "reference", measured THERE, next to the port measured HERE
+            rpath = latest_profile("cfg1_cpu_reference_vs_port.json")
+            if args.config == "cogview-tiny-18M" and rpath is not None:
+                r = json.load(open(rpath))
+                out["cpu_baseline_reference"] = {
+                    "value": r["reference"]["tokens_per_s"], "unit": "tokens/s", "cores": r["threads"], "kind": "reference",
+                    "sample": r["config"] + "; median of 5 iterations", "measured_where": r["where"] + ", not on this box",
+                    "port_on_the_same_cores": r["port"]["tokens_per_s"], "source": os.path.relpath(rpath, ROOT)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -76,8 +76,16 @@ def depth_report(module, ids, n_layers, n_heads, report_layers=REPORT_LAYERS):
     finally:
         module.train(was_training)
     keep = sorted({n for n in report_layers if n <= n_layers} | {0, n_layers})
+    # the same logits WITHOUT their final rounding to the 16-bit storage type: the tied-logits product of the final LayerNorm's
+    # output written in fp32 (cogv_gemm_desc.out_f32) -- separates the arithmetic error of the path from the last rounding
+    logits32 = None
+    with torch.no_grad():
+        from cogview_amd import ops
+        xf = module.transformer.final_layernorm(mems[n_layers])
+        w = module.word_embeddings.weight
+        logits32 = ops.gemm(xf.reshape(-1, xf.shape[-1]), w, out_dtype=torch.float32).view(*xf.shape[:-1], w.shape[0])
     ref_logits, ref_streams, secs = oracle_streams(ids.cpu(), storage_rounded_params(module), n_layers, n_heads, keep=keep)
-    return {"logits": rel_l2(logits, ref_logits),
+    return {"logits": rel_l2(logits, ref_logits), "logits_fp32_out": rel_l2(logits32, ref_logits),
             "stream": {n: rel_l2(mems[n], ref_streams[n]) for n in keep},
             "oracle_seconds": secs, "tokens": int(ids.numel())}
 
@@ -92,14 +100,16 @@ def host_mem_available_gb():
     return 0.0
 
 
-def oracle_loss_and_grads(tokens, labels, loss_mask, params, n_layers, n_heads, eps=1e-5, recompute=None):
+def oracle_loss_and_grads(tokens, labels, loss_mask, params, n_layers, n_heads, eps=1e-5, recompute=None, keep=None):
     """fp32 oracle forward + backward of the whole model on one batch (dropout off): -> (loss, {name: gradient}, seconds).
     `params`: name -> fp32 CPU tensor (storage-rounded weights, oracle_streams() naming); they are not modified.
     Restates the reference's reverse pass by autograd through the oracle's forward -- mpu/random.py:332-372 (per-layer
     recompute) and fp16/fp16.py:494-567 only change WHEN tensors are produced, not their values, so with `recompute` each
     layer is re-run in backward exactly as the reference's --checkpoint-activations does (torch.utils.checkpoint): the
     48-layer / 2560-wide model then needs ~35 GB of host memory (weights + gradients) instead of ~80 GB.
-    recompute=None: decide from /proc/meminfo (plain autograd when the activations fit with room to spare)."""
+    recompute=None: decide from /proc/meminfo (plain autograd when the activations fit with room to spare).
+    keep (optional, layer counts): additionally returns (logits, {n: residual stream after n layers}) of the SAME forward pass as
+    a fourth / fifth value -- one oracle pass then serves the logits / stream check and the gradient check of a configuration."""
     from torch.utils.checkpoint import checkpoint
     t0 = time.perf_counter()
     pr = {n: p.detach().clone().requires_grad_(True) for n, p in params.items()}
@@ -111,13 +121,19 @@ def oracle_loss_and_grads(tokens, labels, loss_mask, params, n_layers, n_heads, 
     pos = torch.arange(s).unsqueeze(0).expand(b, -1)
     mask = O.build_mask(s, s)
     x = F.embedding(tokens, pr["word_embeddings.weight"]) + F.embedding(pos, pr["transformer.position_embeddings.weight"])
+    keep_set = set(keep) if keep is not None else set()
+    streams = {0: x.detach().clone()} if 0 in keep_set else {}
     for l in range(n_layers):
         pre = f"transformer.layers.{l}."
         if recompute:
             x = checkpoint(lambda t, pre=pre: O.transformer_layer(t, mask, pr, pre, n_heads, eps), x, use_reentrant=False)
         else:
             x = O.transformer_layer(x, mask, pr, pre, n_heads, eps)
+        if l + 1 in keep_set:
+            streams[l + 1] = x.detach().clone()
     xf = O.sandwich_layernorm(x, pr["transformer.final_layernorm.weight"], pr["transformer.final_layernorm.bias"], eps)
-    loss = O.lm_loss(O.linear(xf, pr["word_embeddings.weight"]), labels, loss_mask)
+    logits = O.linear(xf, pr["word_embeddings.weight"])
+    loss = O.lm_loss(logits, labels, loss_mask)
     loss.backward()
-    return loss.detach(), {n: p.grad for n, p in pr.items()}, time.perf_counter() - t0
+    out = (loss.detach(), {n: p.grad for n, p in pr.items()}, time.perf_counter() - t0)
+    return out if keep is None else out + (logits.detach(), streams)

@@ -46,55 +46,85 @@ def _ids():
     return torch.randint(0, N_IDS, (1, S), generator=torch.Generator().manual_seed(1234))
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("cfg", ["cogview-small-336M", "cogview-base-4B"])
-def test_logits_and_residual_stream_at_full_depth(cfg, dtype):
-    model, L, heads = _build(cfg, dtype)
-    rep = D.depth_report(model.module, _ids().cuda(), L, heads)
-    print(f"\n[{cfg} {dtype}] logits rel-L2 {rep['logits']:.3e}; residual stream after n layers: " +
-          " ".join(f"{n}:{e:.2e}" for n, e in rep["stream"].items()) + f" (oracle {rep['oracle_seconds']:.0f}s)")
-    assert rep["logits"] < LOGIT_TOL[dtype], rep
-    assert max(rep["stream"].values()) < STREAM_TOL[dtype], rep
-    assert rep["stream"][0] < 1e-6          # the embedding sum is exact in the fp32 stream
-
-
 def _row(seed=99):
     row = torch.randint(0, N_IDS, (1, S + 1), generator=torch.Generator().manual_seed(seed))
     return row[:, :-1].contiguous(), row[:, 1:].contiguous()
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("cfg", ["cogview-small-336M", "cogview-base-4B"])
-def test_gradients_at_full_depth_vs_oracle(cfg, dtype):
-    """Loss and EVERY parameter gradient of cfg 2 (24 layers) and of cfg 3/4 -- the 48-layer / 2560-wide model the metric
-    is quoted on -- against the oracle's autograd through all layers (fp32, the same storage-rounded weights, one sequence
-    of 1088 positions, dropout off: parity protocol of SURVEY section 8c).  The reference's backward runs through all 48
-    layers (mpu/random.py:332-372, fp16/fp16.py:494-567): a dgrad wrong by a constant in layer 40 fails here."""
+# One oracle pass per (configuration, dtype) serves both tests below (round 5: the GPU suite ran 653 s of the driver's 1200-s
+# limit, more than half of it the CPU oracle at 48 layers).  Where gradients are checked, the oracle's forward + backward of ONE
+# sequence also yields the logits and the residual streams of that sequence; the 48-layer bf16 configuration gets the
+# (forward-only) logits / stream check -- its gradients were measured at 48 layers in round 4 (7.7e-3,
+# profiles/r04_depth_gradient_parity_48L_mp2.log) and are asserted here at 24 layers, fp16's at 24 AND 48.
+WITH_GRADIENTS = {("cogview-small-336M", torch.float16), ("cogview-small-336M", torch.bfloat16), ("cogview-base-4B", torch.float16)}
+_PASS = {}
+
+
+def _oracle_pass(cfg, dtype):
+    key = (cfg, dtype)
+    if key in _PASS:
+        return _PASS[key]
     from cogview_amd import training
     model, L, heads = _build(cfg, dtype)
     model.eval()
     tokens, labels = _row()
-    lmask = torch.ones(1, S)
-    pos = torch.arange(S).unsqueeze(0)
-    batch = (tokens.cuda(), labels.cuda(), lmask.cuda(), 0, pos.cuda())
-    loss, _, _, _ = training.forward_step(batch, model, log=False)
-    # fp16 needs the loss scale the training step runs with (fp16/loss_scaler.py): d(loss)/d(logit) ~ 1e-5 / 1088 is
-    # below fp16's smallest subnormal.  A power of two, so unscaling is exact.
-    scale = 2.0 ** 14 if dtype == torch.float16 else 1.0
-    (loss * scale).backward()
-    l_ref, g_ref, secs = D.oracle_loss_and_grads(tokens, labels, lmask, D.storage_rounded_params(model.module), L, heads)
-    assert abs(loss.item() - l_ref.item()) < 2e-3 * abs(l_ref.item()), (loss.item(), l_ref.item())
-    worst, worst_n, by_layer = 0.0, "", {}
-    for n, p in model.module.named_parameters():
-        e = D.rel_l2(p.grad.float() / scale, g_ref[n])
-        if n.startswith("transformer.layers."):
-            li = int(n.split(".")[2])
-            by_layer[li] = max(by_layer.get(li, 0.0), e)
-        if e > worst:
-            worst, worst_n = e, n
-    print(f"\n[{cfg} {dtype}] loss {loss.item():.5f} (oracle {l_ref.item():.5f}, {secs:.0f}s); worst gradient rel-L2 {worst:.2e} "
-          f"({worst_n}); worst per layer: " + " ".join(f"{li}:{by_layer[li]:.1e}" for li in (0, 1, 3, 7, 15, 23, 31, 39, 47) if li in by_layer))
-    assert worst < GRAD_TOL[dtype], (worst, worst_n)
+    out = {"L": L}
+    keep = sorted({n for n in D.REPORT_LAYERS if n <= L} | {0, L})
+    logits, mems = D.hip_streams(model.module, tokens.cuda())
+    params = D.storage_rounded_params(model.module)
+    if key in WITH_GRADIENTS:
+        lmask = torch.ones(1, S)
+        pos = torch.arange(S).unsqueeze(0)
+        batch = (tokens.cuda(), labels.cuda(), lmask.cuda(), 0, pos.cuda())
+        loss, _, _, _ = training.forward_step(batch, model, log=False)
+        # fp16 needs the loss scale the training step runs with (fp16/loss_scaler.py): d(loss)/d(logit) ~ 1e-5 / 1088 is
+        # below fp16's smallest subnormal.  A power of two, so unscaling is exact.
+        scale = 2.0 ** 14 if dtype == torch.float16 else 1.0
+        (loss * scale).backward()
+        l_ref, g_ref, secs, ref_logits, ref_streams = D.oracle_loss_and_grads(tokens, labels, lmask, params, L, heads, keep=keep)
+        worst, worst_n, by_layer = 0.0, "", {}
+        for n, p in model.module.named_parameters():
+            e = D.rel_l2(p.grad.float() / scale, g_ref[n])
+            if n.startswith("transformer.layers."):
+                li = int(n.split(".")[2])
+                by_layer[li] = max(by_layer.get(li, 0.0), e)
+            if e > worst:
+                worst, worst_n = e, n
+        out.update(loss=loss.item(), loss_ref=l_ref.item(), worst=worst, worst_n=worst_n, by_layer=by_layer)
+        del g_ref
+    else:
+        ref_logits, ref_streams, secs = D.oracle_streams(tokens, params, L, heads, keep=keep)
+    out.update(logits=D.rel_l2(logits, ref_logits), stream={n: D.rel_l2(mems[n], ref_streams[n]) for n in keep}, secs=secs)
+    del model, logits, mems, ref_logits, ref_streams, params
+    torch.cuda.empty_cache()
+    _PASS[key] = out
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cfg", ["cogview-small-336M", "cogview-base-4B"])
+def test_logits_and_residual_stream_at_full_depth(cfg, dtype):
+    rep = _oracle_pass(cfg, dtype)
+    print(f"\n[{cfg} {dtype}] logits rel-L2 {rep['logits']:.3e}; residual stream after n layers: " +
+          " ".join(f"{n}:{e:.2e}" for n, e in rep["stream"].items()) + f" (oracle {rep['secs']:.0f}s)")
+    assert rep["logits"] < LOGIT_TOL[dtype], rep
+    assert max(rep["stream"].values()) < STREAM_TOL[dtype], rep
+    assert rep["stream"][0] < 1e-6          # the embedding sum is exact in the fp32 stream
+
+
+@pytest.mark.parametrize("cfg,dtype", sorted(WITH_GRADIENTS, key=str))
+def test_gradients_at_full_depth_vs_oracle(cfg, dtype):
+    """Loss and EVERY parameter gradient of cfg 2 (24 layers, fp16 and bf16) and of cfg 3/4 -- the 48-layer / 2560-wide model the
+    metric is quoted on, in its headline type fp16 -- against the oracle's autograd through all layers (fp32, the same
+    storage-rounded weights, one sequence of 1088 positions, dropout off: parity protocol of SURVEY section 8c).  The reference's
+    backward runs through all 48 layers (mpu/random.py:332-372, fp16/fp16.py:494-567): a dgrad wrong by a constant in layer 40
+    fails here."""
+    r = _oracle_pass(cfg, dtype)
+    by_layer = r["by_layer"]
+    print(f"\n[{cfg} {dtype}] loss {r['loss']:.5f} (oracle {r['loss_ref']:.5f}, {r['secs']:.0f}s); worst gradient rel-L2 {r['worst']:.2e} "
+          f"({r['worst_n']}); worst per layer: " + " ".join(f"{li}:{by_layer[li]:.1e}" for li in (0, 1, 3, 7, 15, 23, 31, 39, 47) if li in by_layer))
+    assert abs(r["loss"] - r["loss_ref"]) < 2e-3 * abs(r["loss_ref"]), (r["loss"], r["loss_ref"])
+    assert r["worst"] < GRAD_TOL[dtype], (r["worst"], r["worst_n"])
 
 
 # ------------------------------------------------------------------------------------------------ cfg 3: model parallel = 2
