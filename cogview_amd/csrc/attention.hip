@@ -41,9 +41,11 @@ constexpr int TILE = 8192;      // one 64 x 64 16-bit tile
 // workgroup (48-53 KiB: three workgroups per CU); two stages (32-36 KiB, one block in flight: it still has a whole block's
 // compute, ~2 us, to land) let four to five workgroups share a CU -- the kernels are parked 29-35 % of their wave cycles
 // (profiles/r05_attention_pmc.txt: ramp-up, diagonal blocks and tails of 20-us workgroups), which more resident workgroups
-// cover better than a deeper prefetch.  A/B: profiles/r05_attention_stages_ab.log.
+// were expected to cover better than a deeper prefetch.  Measured (profiles/r05_attention_stages_ab.log, same call): forward and
+// backward each 1 % faster in the 4B step (0.387 -> 0.383 ms, 1.079 -> 1.068 ms), 2 % on the 336M shape -- so the parked cycles are
+// NOT an occupancy problem; two stages ship because they are not slower and leave LDS for neighbours.
 #ifndef COGV_ATTN_STAGES
-#define COGV_ATTN_STAGES 3
+#define COGV_ATTN_STAGES 2
 #endif
 constexpr int NSTG = COGV_ATTN_STAGES;
 static_assert(NSTG == 2 || NSTG == 3, "ring of two or three stages");

@@ -36,9 +36,12 @@ struct GemmArgs {
 // a generic pointer would compile to flat_load / flat_store, which also count on the LDS counter
 #define COGV_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ u32x4 gload16(const void* q) { return *(const COGV_GLOBAL u32x4*)q; }
-// streamed-once data (the weight rows of a decode step: every byte is read by ONE workgroup, once per token): the
-// non-temporal policy (global_load_dwordx4 ... nt) keeps the stream from displacing the step's small reused vectors in the
-// caches.  COGV_DECODE_NT=0 builds the default-policy loads (A/B: profiles/r05_decode_nt_ab.log).
+// streamed-once data (the weight rows of a decode step: every byte is read by ONE workgroup, once per token): the non-temporal
+// policy (global_load_dwordx4 ... nt) keeps the stream from displacing the step's small reused vectors in the caches.  Measured
+// in the captured 4B decode step (profiles/r05_decode_nt_ab.log): one row (FormV, a wave streams whole weight rows) 2.78 -> 2.69
+// ms per token; 2 / 4 rows (FormM: the 16 lanes of a 16 x 16 fragment read 16 different rows, 16 bytes each per step) 3.06 ->
+// 3.50 and 3.74 -> 4.23 ms -- so FormV and the decode attention's cache rows take it, FormM keeps the default policy.
+// COGV_DECODE_NT=0 builds default-policy loads everywhere.
 #ifndef COGV_DECODE_NT
 #define COGV_DECODE_NT 1
 #endif

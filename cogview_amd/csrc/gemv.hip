@@ -168,7 +168,7 @@ struct FormM {
     const T* row = reinterpret_cast<const T*>(p.B) + (size_t)n * p.ldb + (lane >> 4) * 8;
 #pragma unroll
     for (int i = S0; i < S1; ++i)
-      if (!GUARD || i < L) r.w[i] = gload16_stream(row + 32 * kstep(kw, i));
+      if (!GUARD || i < L) r.w[i] = gload16(row + 32 * kstep(kw, i));     // (default policy: the non-temporal form measured 12-14 % SLOWER here, profiles/r05_decode_nt_ab.log)
   }
   // lanes 0 .. 15 of a tile's first wave finish: lane t -> row t >> 1, columns (tile) + 8 (t & 1) ..
   static __device__ __forceinline__ u32x4 bias(const GemmArgs& p, int n0, int wave, int lane) {

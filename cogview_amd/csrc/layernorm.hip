@@ -15,6 +15,9 @@
 // rows in flight of the wide STREAM_IN backward (fp32 x, add_in, dx: 20 prefetch registers per row instead of 12).
 // h = 2560, 26112 rows (tools/r3/mb_ln_stream.py): two rows at 162 registers 171.6 us, four rows at 256 registers
 // (+12 B of scratch) 184.7 us.  COGV_LN_BWD_ROWS overrides at run time.
+#ifndef COGV_LN_REVERSE_DEFAULT
+#define COGV_LN_REVERSE_DEFAULT 0
+#endif
 #ifndef COGV_LN_BWD_STREAM_IN_ROWS
 #define COGV_LN_BWD_STREAM_IN_ROWS 2
 #endif
@@ -26,6 +29,7 @@ struct LnFwdArgs {
   void* y; float* mean; float* rstd;
   const float* absmax_in; float* absmax_out;
   int rows, h; float eps;
+  int rev;                 // walk the rows from the last one down (see ln_row_order)
 };
 
 // MODE (cogview_hip.h COGV_LN_*): 0 = every tensor in the storage type T; 1 (STREAM_IN) = x is the fp32 residual
@@ -52,7 +56,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
     }
   }
   uint32_t amax = 0u;                  // running max of |output| bit patterns (absmax_pk / fp32 patterns)
-  for (int row = wave_global; row < p.rows; row += nwaves) {
+  for (int row_i = wave_global; row_i < p.rows; row_i += nwaves) {
+    const int row = p.rev ? p.rows - 1 - row_i : row_i;
     float x[NV][8];
     float s = 0.f;
 #pragma unroll
@@ -117,6 +122,7 @@ struct LnBwdArgs {
   int rows, h;
   int want_colsum;
   uint64_t seed, stream_id; uint32_t thr16; float keep_scale;
+  int rev;                 // walk the rows from the last one down (see ln_row_order)
 };
 
 // Backward.  One workgroup of ceil(h / 512) waves covers a row: every lane owns 8 columns for the whole kernel, so
@@ -146,16 +152,20 @@ void ln_bwd_kernel(const LnBwdArgs p) {
   typename DYR::raw dyn[R];            // the NEXT iteration's rows: loaded before this iteration's barrier and stores
   typename XR::raw xn_[R], adn[R];
   float meann[R], rstdn[R];
+  // logical row -> stored row (reverse order: the rows the producer wrote LAST are read first, while the memory-side cache
+  // still holds them; all per-row data -- dy, x, add_in, statistics, dx -- moves together, sums are order-independent per block)
+  auto phys = [&](int row) { return p.rev ? p.rows - 1 - row : row; };
   auto fetch = [&](int row0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int row = row0 + r;
-      const bool ok = act && row < p.rows;
+      const int lrow = row0 + r;
+      const int row = lrow < p.rows ? phys(lrow) : lrow;
+      const bool ok = act && lrow < p.rows;
       dyn[r] = ok ? DYR::ld(p.dy, (size_t)row * p.h + col) : DYR::zero();
       xn_[r] = ok ? XR::ld(p.x, (size_t)row * p.h + col) : XR::zero();
       if (has_add) adn[r] = ok ? XR::ld(p.add_in, (size_t)row * p.h + col) : XR::zero();
-      meann[r] = row < p.rows ? p.mean[row] : 0.f;
-      rstdn[r] = row < p.rows ? p.rstd[row] : 0.f;
+      meann[r] = lrow < p.rows ? p.mean[row] : 0.f;
+      rstdn[r] = lrow < p.rows ? p.rstd[row] : 0.f;
     }
   };
   fetch(blockIdx.x * R);
@@ -191,11 +201,12 @@ void ln_bwd_kernel(const LnBwdArgs p) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int row = row0 + r;
+      const int lrow = row0 + r;
+      const int row = lrow < p.rows ? phys(lrow) : lrow;
       float m1 = 0.f, m2 = 0.f;
       for (int w = 0; w < nw; ++w) { m1 += red[buf][r][w][0]; m2 += red[buf][r][w][1]; }
       m1 *= inv_h; m2 *= inv_h;
-      if (act && row < p.rows) {
+      if (act && lrow < p.rows) {
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = rstd[r] * (gyk[r][i] - m1 - xhk[r][i] * m2);
@@ -280,6 +291,16 @@ template <typename T, int NV> void launch_fwd(const LnFwdArgs& a, int mode, int 
   else if (mode == COGV_LN_STREAM_OUT) launch_fwd_m<T, NV, 2>(a, blocks, st);
   else launch_fwd_m<T, NV, 0>(a, blocks, st);
 }
+// Row order.  The fp32 residual stream of the 4B step is 267 MB per tensor: more than the 256-MB memory-side cache, so a consumer
+// that walks it in the producer's order finds its first rows already evicted by the producer's last ones -- and evicts the rest
+// as it goes.  Walking it from the END (the rows written last) meets the most recent ~3/4 of the tensor while they are still
+// resident.  COGV_LN_REVERSE: bit 0 forward stream-in (LN1, LN2, final), bit 1 forward stream-out (LN3, LN4), bit 2 backward
+// stream-in, bit 3 backward stream-out.  Forward outputs and dx are bit-identical either way; the backward's column sums (dgamma,
+// dbeta, bias gradient) add the same rows in the opposite order (fp32, deterministic run to run).
+inline int ln_row_order() {
+  const char* e = getenv("COGV_LN_REVERSE");        // read per launch: tests and A/B runs switch it inside one process
+  return e ? atoi(e) : COGV_LN_REVERSE_DEFAULT;
+}
 inline int ln_bwd_stream_in_rows() {
   static const int rows_env = [] { const char* e = getenv("COGV_LN_BWD_ROWS"); return e ? atoi(e) : 0; }();
   return rows_env ? rows_env : COGV_LN_BWD_STREAM_IN_ROWS;
@@ -346,7 +367,8 @@ extern "C" int cogv_sandwich_ln_fwd(int dtype, const void* x, const void* gamma,
   if (stream_mode == COGV_LN_STREAM_IN && residual) return COGV_ERR_ARG;       // the stream is the input, nothing to add to
   if (stream_mode == COGV_LN_STREAM_OUT && !residual) return COGV_ERR_ARG;
   if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)residual) & 15) return COGV_ERR_ARG;
-  LnFwdArgs a{x, gamma, beta, residual, y, mean, rstd, absmax_in, absmax_out, rows, h, eps};
+  LnFwdArgs a{x, gamma, beta, residual, y, mean, rstd, absmax_in, absmax_out, rows, h, eps, 0};
+  a.rev = (stream_mode == COGV_LN_STREAM_IN && (ln_row_order() & 1)) || (stream_mode == COGV_LN_STREAM_OUT && (ln_row_order() & 2));
   const int nv = (h + 511) / 512;
   int blocks = (rows + 3) / 4; if (blocks > 4096) blocks = 4096;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -372,6 +394,7 @@ extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, co
   a.seed = seed; a.stream_id = stream_id;
   a.thr16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
+  a.rev = (stream_mode == COGV_LN_STREAM_IN && (ln_row_order() & 4)) || (stream_mode == COGV_LN_STREAM_OUT && (ln_row_order() & 8));
   // (the two-row STREAM_IN form without dropout replay keeps the one-workgroup-per-CU cap: 256 workgroups 167 us vs 178
   // with 512 at h = 2560, tools/r3/exp1.sh)
   const int blocks = ln_bwd_blocks(rows, h, a.thr16 != 0);

@@ -870,7 +870,7 @@ class _TransformerLayer(torch.autograd.Function):
 _DECODE_FUSE_ENV = _os.environ.get("COGV_DECODE_FUSE_COMBINE")
 
 
-_DECODE_CHAIN_MAX_ROWS = min(8, max(0, int(_os.environ.get("COGV_DECODE_CHAIN_MAX_ROWS", "8"))))
+_DECODE_CHAIN_MAX_ROWS = min(8, max(0, int(_os.environ.get("COGV_DECODE_CHAIN_MAX_ROWS", "4"))))
 
 
 def _decode_fuse_combine():
@@ -883,9 +883,10 @@ def decode_chain_supported(tr, batch):
     """The fused decode chain (decode_chain) covers the dense, single-partition model in a 16-bit type at one token per
     row: what a captured decode step runs."""
     h = tr.layers[0].input_layernorm.weight.shape[0]
-    # COGV_DECODE_CHAIN_MAX_ROWS (default 8): above it the step runs layer by layer (Sandwich-LN launches + plain matrix-vector
-    # products).  At 5 .. 8 rows the fused LayerNorm prologue is what bounds the chain (DESIGN section 8, item 4): the knob lets
-    # the two forms be timed against each other without a code change.
+    # COGV_DECODE_CHAIN_MAX_ROWS (default 4): above it the step runs layer by layer (Sandwich-LN launches + plain matrix-core
+    # products).  At 5 .. 8 rows the fused LayerNorm prologue is what bounds the chain (every workgroup re-derives x_in for all
+    # rows); measured at batch 8, captured 4B step: 6.34 ms per step with the chain, 5.07 layer by layer
+    # (profiles/r05_decode_chain_rows_ab.log).
     return (mp_world_size_or_1() == 1 and batch <= _DECODE_CHAIN_MAX_ROWS and h % 512 == 0 and h <= 4096
             and tr.layers[0].input_layernorm.weight.dtype in (torch.float16, torch.bfloat16))
 
