@@ -15,9 +15,6 @@
 // rows in flight of the wide STREAM_IN backward (fp32 x, add_in, dx: 20 prefetch registers per row instead of 12).
 // h = 2560, 26112 rows (tools/r3/mb_ln_stream.py): two rows at 162 registers 171.6 us, four rows at 256 registers
 // (+12 B of scratch) 184.7 us.  COGV_LN_BWD_ROWS overrides at run time.
-#ifndef COGV_LN_REVERSE_DEFAULT
-#define COGV_LN_REVERSE_DEFAULT 0
-#endif
 #ifndef COGV_LN_BWD_STREAM_IN_ROWS
 #define COGV_LN_BWD_STREAM_IN_ROWS 2
 #endif
@@ -29,7 +26,6 @@ struct LnFwdArgs {
   void* y; float* mean; float* rstd;
   const float* absmax_in; float* absmax_out;
   int rows, h; float eps;
-  int rev;                 // walk the rows from the last one down (see ln_row_order)
 };
 
 // MODE (cogview_hip.h COGV_LN_*): 0 = every tensor in the storage type T; 1 (STREAM_IN) = x is the fp32 residual
@@ -56,8 +52,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
     }
   }
   uint32_t amax = 0u;                  // running max of |output| bit patterns (absmax_pk / fp32 patterns)
-  for (int row_i = wave_global; row_i < p.rows; row_i += nwaves) {
-    const int row = p.rev ? p.rows - 1 - row_i : row_i;
+  for (int row = wave_global; row < p.rows; row += nwaves) {
     float x[NV][8];
     float s = 0.f;
 #pragma unroll
@@ -122,7 +117,6 @@ struct LnBwdArgs {
   int rows, h;
   int want_colsum;
   uint64_t seed, stream_id; uint32_t thr16; float keep_scale;
-  int rev;                 // walk the rows from the last one down (see ln_row_order)
 };
 
 // Backward.  One workgroup of ceil(h / 512) waves covers a row: every lane owns 8 columns for the whole kernel, so
@@ -132,16 +126,22 @@ struct LnBwdArgs {
 // loads per lane); the two row statistics go through a double-buffered LDS exchange, one barrier per R rows.
 // MODE as in ln_fwd_kernel, seen from the backward side: 1 (STREAM_IN: LN1, LN2) = x, add_in and dx are the fp32
 // stream / its gradient, dy is T;  2 (STREAM_OUT: LN3, LN4) = dy is the fp32 stream gradient, x, add_in, dx are T.
-template <typename T, int R, int MODE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R == 2 ? 3 : 2)))
+// LEAN (round 5; the dropout-replay forms LN3' / LN4': MODE 2, no add_in): no add_in registers at all (compile time), and the
+// 16-bit x of the rows in flight is kept RAW (4 registers per row) and re-normalised in the second phase instead of holding
+// x-hat in fp32 (8 per row) across the barrier -- 146 -> <= 128 registers, i.e. four waves per SIMD = three 5-wave workgroups
+// per CU instead of two.  The replay's hash and the column sums put ~170 VALU instructions on every row of this form (the
+// plain forms: ~90), so it needs more waves to keep the memory pipe busy; same arithmetic, bit-identical results.
+template <typename T, int R, int MODE, bool LEAN = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(LEAN ? 4 : (R == 2 ? 3 : 2))))
 void ln_bwd_kernel(const LnBwdArgs p) {
   typedef Row8<T, MODE == 2> DYR;
   typedef Row8<T, MODE == 1> XR;       // x, add_in, dx
+  static_assert(!LEAN || MODE == 2, "the lean form keeps a 16-bit x raw");
   __shared__ float red[2][R][8][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int col = threadIdx.x * 8;
   const bool act = col < p.h;
-  const bool has_add = p.add_in != nullptr;
+  const bool has_add = !LEAN && p.add_in != nullptr;
   const float inv_h = 1.0f / (float)p.h;
 
   float g[8], dg[8], db[8], cs[8];
@@ -152,42 +152,42 @@ void ln_bwd_kernel(const LnBwdArgs p) {
   typename DYR::raw dyn[R];            // the NEXT iteration's rows: loaded before this iteration's barrier and stores
   typename XR::raw xn_[R], adn[R];
   float meann[R], rstdn[R];
-  // logical row -> stored row (reverse order: the rows the producer wrote LAST are read first, while the memory-side cache
-  // still holds them; all per-row data -- dy, x, add_in, statistics, dx -- moves together, sums are order-independent per block)
-  auto phys = [&](int row) { return p.rev ? p.rows - 1 - row : row; };
   auto fetch = [&](int row0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int lrow = row0 + r;
-      const int row = lrow < p.rows ? phys(lrow) : lrow;
-      const bool ok = act && lrow < p.rows;
+      const int row = row0 + r;
+      const bool ok = act && row < p.rows;
       dyn[r] = ok ? DYR::ld(p.dy, (size_t)row * p.h + col) : DYR::zero();
       xn_[r] = ok ? XR::ld(p.x, (size_t)row * p.h + col) : XR::zero();
       if (has_add) adn[r] = ok ? XR::ld(p.add_in, (size_t)row * p.h + col) : XR::zero();
-      meann[r] = lrow < p.rows ? p.mean[row] : 0.f;
-      rstdn[r] = lrow < p.rows ? p.rstd[row] : 0.f;
+      meann[r] = row < p.rows ? p.mean[row] : 0.f;
+      rstdn[r] = row < p.rows ? p.rstd[row] : 0.f;
     }
   };
   fetch(blockIdx.x * R);
   for (int row0 = blockIdx.x * R; row0 < p.rows; row0 += gridDim.x * R) {
-    typename XR::raw adv[R];
-    float rstd[R], s1[R], s2[R];
-    float xhk[R][8], gyk[R][8];        // normalised input and gamma * dy of the rows in flight (kept for phase 2)
+    typename XR::raw adv[R], xraw[LEAN ? R : 1];
+    float rstd[R], s1[R], s2[R], mrk[R];
+    float xhk[LEAN ? 1 : R][8], gyk[R][8];   // normalised input and gamma * dy of the rows in flight (kept for phase 2)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      float dy[8];
-      DYR::to_f(dyn[r], dy); XR::to_f(xn_[r], xhk[r]);
-      adv[r] = adn[r]; rstd[r] = rstdn[r];
+      float dy[8], xh1[8];
+      float (&xh)[8] = LEAN ? xh1 : xhk[LEAN ? 0 : r];
+      DYR::to_f(dyn[r], dy); XR::to_f(xn_[r], xh);
+      if (LEAN) xraw[r] = xn_[r];
+      if (!LEAN) adv[r] = adn[r];
+      rstd[r] = rstdn[r];
       const float mr = meann[r] * rstdn[r];
+      mrk[r] = mr;
       float a1 = 0.f, a2 = 0.f;
       if (act && row0 + r < p.rows) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          xhk[r][i] = fmaf(xhk[r][i], rstd[r], -mr);
+          xh[i] = fmaf(xh[i], rstd[r], -mr);
           gyk[r][i] = dy[i] * g[i];
           a1 += gyk[r][i];
-          a2 = fmaf(gyk[r][i], xhk[r][i], a2);
-          dg[i] = fmaf(dy[i], xhk[r][i], dg[i]);
+          a2 = fmaf(gyk[r][i], xh[i], a2);
+          dg[i] = fmaf(dy[i], xh[i], dg[i]);
           db[i] += dy[i];
         }
       }
@@ -201,15 +201,19 @@ void ln_bwd_kernel(const LnBwdArgs p) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int lrow = row0 + r;
-      const int row = lrow < p.rows ? phys(lrow) : lrow;
+      const int row = row0 + r;
       float m1 = 0.f, m2 = 0.f;
       for (int w = 0; w < nw; ++w) { m1 += red[buf][r][w][0]; m2 += red[buf][r][w][1]; }
       m1 *= inv_h; m2 *= inv_h;
-      if (act && lrow < p.rows) {
-        float o[8];
+      if (act && row < p.rows) {
+        float o[8], xh2[8];
+        if (LEAN) {                         // the same fused multiply-add as in phase 1: bit-identical x-hat
+          XR::to_f(xraw[r], xh2);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = rstd[r] * (gyk[r][i] - m1 - xhk[r][i] * m2);
+          for (int i = 0; i < 8; ++i) xh2[i] = fmaf(xh2[i], rstd[r], -mrk[r]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rstd[r] * (gyk[r][i] - m1 - (LEAN ? xh2[i] : xhk[LEAN ? 0 : r][i]) * m2);
         if (p.thr16) {
           const uint64_t e = (uint64_t)row * (uint64_t)p.h + (uint64_t)col;
           const u32x4 rn = Philox::gen(p.seed, p.stream_id, e >> 3);
@@ -291,25 +295,24 @@ template <typename T, int NV> void launch_fwd(const LnFwdArgs& a, int mode, int 
   else if (mode == COGV_LN_STREAM_OUT) launch_fwd_m<T, NV, 2>(a, blocks, st);
   else launch_fwd_m<T, NV, 0>(a, blocks, st);
 }
-// Row order.  The fp32 residual stream of the 4B step is 267 MB per tensor: more than the 256-MB memory-side cache, so a consumer
-// that walks it in the producer's order finds its first rows already evicted by the producer's last ones -- and evicts the rest
-// as it goes.  Walking it from the END (the rows written last) meets the most recent ~3/4 of the tensor while they are still
-// resident.  COGV_LN_REVERSE: bit 0 forward stream-in (LN1, LN2, final), bit 1 forward stream-out (LN3, LN4), bit 2 backward
-// stream-in, bit 3 backward stream-out.  Forward outputs and dx are bit-identical either way; the backward's column sums (dgamma,
-// dbeta, bias gradient) add the same rows in the opposite order (fp32, deterministic run to run).
-inline int ln_row_order() {
-  const char* e = getenv("COGV_LN_REVERSE");        // read per launch: tests and A/B runs switch it inside one process
-  return e ? atoi(e) : COGV_LN_REVERSE_DEFAULT;
-}
 inline int ln_bwd_stream_in_rows() {
   static const int rows_env = [] { const char* e = getenv("COGV_LN_BWD_ROWS"); return e ? atoi(e) : 0; }();
   return rows_env ? rows_env : COGV_LN_BWD_STREAM_IN_ROWS;
+}
+#ifndef COGV_LN_BWD_LEAN_DEFAULT
+#define COGV_LN_BWD_LEAN_DEFAULT 0
+#endif
+inline bool ln_bwd_lean() {
+  const char* e = getenv("COGV_LN_BWD_LEAN");        // read per launch (A/B runs, tests)
+  return e ? atoi(e) != 0 : COGV_LN_BWD_LEAN_DEFAULT != 0;
 }
 template <typename T, int MODE> void launch_bwd_m(const LnBwdArgs& a, int blocks, hipStream_t st) {
   const int nw = (a.h + 511) / 512;             // waves per row (h <= 4096 -> <= 8)
   // wide rows with the dropout replay: two rows in flight at 128 registers (two workgroups per CU) beat four rows at
   // 206 (one per CU) -- 112 vs 129 us at h = 2560; without the replay four rows and one workgroup per CU win (109 vs 116)
-  if (nw >= 4 && (a.thr16 || (MODE == 1 && ln_bwd_stream_in_rows() == 2)))
+  if (MODE == 2 && nw >= 4 && a.thr16 && !a.add_in && ln_bwd_lean()) {
+    if constexpr (MODE == 2) hipLaunchKernelGGL((ln_bwd_kernel<T, 2, MODE, true>), dim3(blocks), dim3(nw * 64), 0, st, a);
+  } else if (nw >= 4 && (a.thr16 || (MODE == 1 && ln_bwd_stream_in_rows() == 2)))
     hipLaunchKernelGGL((ln_bwd_kernel<T, 2, MODE>), dim3(blocks), dim3(nw * 64), 0, st, a);
   else hipLaunchKernelGGL((ln_bwd_kernel<T, 4, MODE>), dim3(blocks), dim3(nw * 64), 0, st, a);
 }
@@ -367,8 +370,7 @@ extern "C" int cogv_sandwich_ln_fwd(int dtype, const void* x, const void* gamma,
   if (stream_mode == COGV_LN_STREAM_IN && residual) return COGV_ERR_ARG;       // the stream is the input, nothing to add to
   if (stream_mode == COGV_LN_STREAM_OUT && !residual) return COGV_ERR_ARG;
   if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)residual) & 15) return COGV_ERR_ARG;
-  LnFwdArgs a{x, gamma, beta, residual, y, mean, rstd, absmax_in, absmax_out, rows, h, eps, 0};
-  a.rev = (stream_mode == COGV_LN_STREAM_IN && (ln_row_order() & 1)) || (stream_mode == COGV_LN_STREAM_OUT && (ln_row_order() & 2));
+  LnFwdArgs a{x, gamma, beta, residual, y, mean, rstd, absmax_in, absmax_out, rows, h, eps};
   const int nv = (h + 511) / 512;
   int blocks = (rows + 3) / 4; if (blocks > 4096) blocks = 4096;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -394,10 +396,18 @@ extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, co
   a.seed = seed; a.stream_id = stream_id;
   a.thr16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
-  a.rev = (stream_mode == COGV_LN_STREAM_IN && (ln_row_order() & 4)) || (stream_mode == COGV_LN_STREAM_OUT && (ln_row_order() & 8));
   // (the two-row STREAM_IN form without dropout replay keeps the one-workgroup-per-CU cap: 256 workgroups 167 us vs 178
   // with 512 at h = 2560, tools/r3/exp1.sh)
-  const int blocks = ln_bwd_blocks(rows, h, a.thr16 != 0);
+  int blocks = ln_bwd_blocks(rows, h, a.thr16 != 0);
+  if (stream_mode == COGV_LN_STREAM_OUT && a.thr16 && !add_in && (h + 511) / 512 >= 4 && ln_bwd_lean()) {
+    // the lean dropout-replay form: three resident workgroups per CU (COGV_LN_BWD_BLOCKS still overrides)
+    static const int forced = [] { const char* e = getenv("COGV_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
+    if (forced <= 0) {
+      const int want = (rows + 1) / 2, cap = cogv_ln_bwd_num_blocks(rows);      // (the partial-sum workspace is sized by `cap`)
+      blocks = want < 768 ? want : 768;
+      if (blocks > cap) blocks = cap;
+    }
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == COGV_F16) launch_bwd<f16_t>(a, stream_mode, blocks, st); else launch_bwd<bf16_t>(a, stream_mode, blocks, st);
   if (dgamma || dbeta || colsum) {
