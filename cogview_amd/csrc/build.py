@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(os.path.dirname(HERE), "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcogview_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{HERE}"]
-# A/B builds (tools/r3/build_variant.sh): COGV_HIPCC_EXTRA="-DX -DY" adds flags, COGV_VARIANT=name redirects the objects to
+# A/B builds (tools/evidence.sh documents the A/B workflow): COGV_HIPCC_EXTRA="-DX -DY" adds flags, COGV_VARIANT=name redirects the objects to
 # build/obj_<name>/ and the library to build/ab/libcogview_<name>.so (select it at run time with COGVIEW_HIP_LIB)
 FLAGS += os.environ.get("COGV_HIPCC_EXTRA", "").split()
 if os.environ.get("COGV_VARIANT"):

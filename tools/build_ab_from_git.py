@@ -1,7 +1,7 @@
 """A/B baseline: build a library whose gemm.hip (9 objects) comes from a git revision, every other object from the current
-build.  python tools/r4/build_ab_from_git.py <rev> <tag>  ->  build/ab/libcogview_<tag>.so (select with COGVIEW_HIP_LIB)."""
+build.  python tools/build_ab_from_git.py <rev> <tag>  ->  build/ab/libcogview_<tag>.so (select with COGVIEW_HIP_LIB)."""
 import concurrent.futures, os, subprocess, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cogview_amd.csrc import build as B
 

@@ -1,7 +1,7 @@
 """Per-layer error growth of the HIP forward against the fp32 CPU oracle (same storage-rounded weights).
-    python tools/r3/depth_probe.py [336M|4B] [fp16|bf16] ..."""
+    python tools/depth_probe.py [336M|4B] [fp16|bf16] ..."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from oracle import depth_check as D

@@ -1,7 +1,7 @@
 """Which Python lines launch the small torch kernels (copies, fills, casts) inside a 4B training step?  torch profiler with
 stacks around ONE step of a 6-layer model at the 4B width (same per-layer op sequence), grouped by (op, innermost repo frame)."""
 import collections, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist

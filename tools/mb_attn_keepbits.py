@@ -1,7 +1,7 @@
 """Attention with dropout 0.1 at the 4B / 336M bench shapes: the regenerating backward (keep_bits off) against the stored keep
 bits (forward writes them, dQ / dK.dV read them), interleaved in one process.  GPU box."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cogview_amd import ops
 from tools.microbench import timeit

@@ -1,7 +1,7 @@
 """The dense attention kernels exactly as the 4B train step runs them (fp16, b = 24, 40 heads, s = 1088, dropout 0.1, stored keep
 bits, fused QKV-bias column sums): forward and backward times.  COGVIEW_HIP_LIB selects the library (A/B in one call).  GPU box."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cogview_amd import ops
 from tools.microbench import timeit

@@ -1,7 +1,7 @@
 """The 4B / 336M step's GEMM launches with their real epilogues, one library per process (COGVIEW_HIP_LIB); the driver script
-alternates libraries.  GPU box.   python tools/r4/mb_gemm_ab.py <tag>"""
+alternates libraries.  GPU box.   python tools/mb_gemm_ab.py <tag>"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cogview_amd import ops
 from tools.microbench import timeit

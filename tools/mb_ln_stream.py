@@ -2,7 +2,7 @@
 microseconds and GB/s of algorithmic traffic at both hot-path widths.  COGV_LN_BWD_ROWS=2|4 picks the rows in flight of
 the wide STREAM_IN backward."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cogview_amd import ops
 from tools.microbench import timeit

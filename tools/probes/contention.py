@@ -1,7 +1,7 @@
 """Contention experiment (round-3 verdict item 6a): the 4B training step while a side-stream kernel HOLDS n CUs for the whole
 step -- what RCCL's channel kernels do during the data-parallel backward.  Tests the claim that the persistent one-workgroup-
 per-CU GEMM degrades gracefully (per-XCD work queues: a workgroup that starts late or never simply takes fewer items).
-    python tools/r4/contention.py [--steps 4] [--held 0,8,16,32,48,64]
+    python tools/probes/contention.py [--steps 4] [--held 0,8,16,32,48,64]
 Prints tokens/s per setting and the ratio to (256 - n) / 256."""
 import argparse, ctypes, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--config", default="cogview-base-4B")
     ap.add_argument("--dtype", default="fp16")
     a = ap.parse_args()
-    hog = ctypes.CDLL(os.path.join(ROOT, "tools", "r4", "_cu_hog.so"))
+    hog = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "_cu_hog.so"))
     hog.cu_hog_launch.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
     import bench
     from cogview_amd import mpu, training
