@@ -147,7 +147,9 @@ void ln_bwd_kernel(const LnBwdArgs p) {
   float g[8], dg[8], db[8], cs[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { g[i] = 0.f; dg[i] = 0.f; db[i] = 0.f; cs[i] = 0.f; }
-  if (act) unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.gamma) + col), g);
+  u32x4 graw = {0u, 0u, 0u, 0u};       // LEAN: gamma stays in its 16-bit form (4 registers) and is widened where it is used
+  if (act) graw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.gamma) + col);
+  if (!LEAN) unpack8<T>(graw, g);
   int buf = 0;
   typename DYR::raw dyn[R];            // the NEXT iteration's rows: loaded before this iteration's barrier and stores
   typename XR::raw xn_[R], adn[R];
@@ -173,6 +175,7 @@ void ln_bwd_kernel(const LnBwdArgs p) {
     for (int r = 0; r < R; ++r) {
       float dy[8], xh1[8];
       float (&xh)[8] = LEAN ? xh1 : xhk[LEAN ? 0 : r];
+      if (LEAN) unpack8<T>(graw, g);
       DYR::to_f(dyn[r], dy); XR::to_f(xn_[r], xh);
       if (LEAN) xraw[r] = xn_[r];
       if (!LEAN) adv[r] = adn[r];
@@ -185,6 +188,9 @@ void ln_bwd_kernel(const LnBwdArgs p) {
         for (int i = 0; i < 8; ++i) {
           xh[i] = fmaf(xh[i], rstd[r], -mr);
           gyk[r][i] = dy[i] * g[i];
+          // (opaque: the ROUNDED product is what both phases use -- left visible, the compiler may re-derive it in phase 2 and
+          //  fuse it there with the subtraction of the row mean, one rounding fewer in some instantiations than in others)
+          asm volatile("" : "+v"(gyk[r][i]));
           a1 += gyk[r][i];
           a2 = fmaf(gyk[r][i], xh[i], a2);
           dg[i] = fmaf(dy[i], xh[i], dg[i]);
@@ -213,7 +219,8 @@ void ln_bwd_kernel(const LnBwdArgs p) {
           for (int i = 0; i < 8; ++i) xh2[i] = fmaf(xh2[i], rstd[r], -mrk[r]);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = rstd[r] * (gyk[r][i] - m1 - (LEAN ? xh2[i] : xhk[LEAN ? 0 : r][i]) * m2);
+        for (int i = 0; i < 8; ++i)        // (explicit fused multiply-add: the same contraction in every instantiation)
+          o[i] = rstd[r] * fmaf(-(LEAN ? xh2[i] : xhk[LEAN ? 0 : r][i]), m2, gyk[r][i] - m1);
         if (p.thr16) {
           const uint64_t e = (uint64_t)row * (uint64_t)p.h + (uint64_t)col;
           const u32x4 rn = Philox::gen(p.seed, p.stream_id, e >> 3);

@@ -61,6 +61,16 @@ def hip_streams(module, ids):
     return logits, mems
 
 
+@torch.no_grad()
+def hip_logits_fp32_out(module, stream_out):
+    """The tied-logits product of the final LayerNorm's output written in fp32 (cogv_gemm_desc.out_f32) instead of the storage
+    type: the logits without their last rounding.  stream_out: the residual stream after the last layer (hip_streams' last mem)."""
+    from cogview_amd import ops
+    xf = module.transformer.final_layernorm(stream_out)
+    w = module.word_embeddings.weight
+    return ops.gemm(xf.reshape(-1, xf.shape[-1]), w, out_dtype=torch.float32).view(*xf.shape[:-1], w.shape[0])
+
+
 def storage_rounded_params(module):
     """The module's parameters exactly as stored (16-bit), widened to fp32 on the CPU: the oracle then sees the same
     weights as the kernels, which isolates arithmetic error from weight rounding."""
@@ -78,12 +88,7 @@ def depth_report(module, ids, n_layers, n_heads, report_layers=REPORT_LAYERS):
     keep = sorted({n for n in report_layers if n <= n_layers} | {0, n_layers})
     # the same logits WITHOUT their final rounding to the 16-bit storage type: the tied-logits product of the final LayerNorm's
     # output written in fp32 (cogv_gemm_desc.out_f32) -- separates the arithmetic error of the path from the last rounding
-    logits32 = None
-    with torch.no_grad():
-        from cogview_amd import ops
-        xf = module.transformer.final_layernorm(mems[n_layers])
-        w = module.word_embeddings.weight
-        logits32 = ops.gemm(xf.reshape(-1, xf.shape[-1]), w, out_dtype=torch.float32).view(*xf.shape[:-1], w.shape[0])
+    logits32 = hip_logits_fp32_out(module, mems[n_layers])
     ref_logits, ref_streams, secs = oracle_streams(ids.cpu(), storage_rounded_params(module), n_layers, n_heads, keep=keep)
     return {"logits": rel_l2(logits, ref_logits), "logits_fp32_out": rel_l2(logits32, ref_logits),
             "stream": {n: rel_l2(mems[n], ref_streams[n]) for n in keep},

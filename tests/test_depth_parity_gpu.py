@@ -71,6 +71,7 @@ def _oracle_pass(cfg, dtype):
     out = {"L": L}
     keep = sorted({n for n in D.REPORT_LAYERS if n <= L} | {0, L})
     logits, mems = D.hip_streams(model.module, tokens.cuda())
+    logits32 = D.hip_logits_fp32_out(model.module, mems[L])         # the same logits without their last rounding to 16 bits
     params = D.storage_rounded_params(model.module)
     if key in WITH_GRADIENTS:
         lmask = torch.ones(1, S)
@@ -94,8 +95,9 @@ def _oracle_pass(cfg, dtype):
         del g_ref
     else:
         ref_logits, ref_streams, secs = D.oracle_streams(tokens, params, L, heads, keep=keep)
-    out.update(logits=D.rel_l2(logits, ref_logits), stream={n: D.rel_l2(mems[n], ref_streams[n]) for n in keep}, secs=secs)
-    del model, logits, mems, ref_logits, ref_streams, params
+    out.update(logits=D.rel_l2(logits, ref_logits), logits32=D.rel_l2(logits32, ref_logits),
+               stream={n: D.rel_l2(mems[n], ref_streams[n]) for n in keep}, secs=secs)
+    del model, logits, logits32, mems, ref_logits, ref_streams, params
     torch.cuda.empty_cache()
     _PASS[key] = out
     return out
@@ -105,7 +107,7 @@ def _oracle_pass(cfg, dtype):
 @pytest.mark.parametrize("cfg", ["cogview-small-336M", "cogview-base-4B"])
 def test_logits_and_residual_stream_at_full_depth(cfg, dtype):
     rep = _oracle_pass(cfg, dtype)
-    print(f"\n[{cfg} {dtype}] logits rel-L2 {rep['logits']:.3e}; residual stream after n layers: " +
+    print(f"\n[{cfg} {dtype}] logits rel-L2 {rep['logits']:.3e} (written in fp32: {rep['logits32']:.3e}); residual stream after n layers: " +
           " ".join(f"{n}:{e:.2e}" for n, e in rep["stream"].items()) + f" (oracle {rep['secs']:.0f}s)")
     assert rep["logits"] < LOGIT_TOL[dtype], rep
     assert max(rep["stream"].values()) < STREAM_TOL[dtype], rep
