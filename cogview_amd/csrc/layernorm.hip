@@ -307,7 +307,7 @@ inline int ln_bwd_stream_in_rows() {
   return rows_env ? rows_env : COGV_LN_BWD_STREAM_IN_ROWS;
 }
 #ifndef COGV_LN_BWD_LEAN_DEFAULT
-#define COGV_LN_BWD_LEAN_DEFAULT 0
+#define COGV_LN_BWD_LEAN_DEFAULT 1
 #endif
 inline bool ln_bwd_lean() {
   const char* e = getenv("COGV_LN_BWD_LEAN");        // read per launch (A/B runs, tests)

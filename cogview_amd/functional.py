@@ -184,8 +184,9 @@ def mask_to_sep(attention_mask, s_q, s_k):
         return attention_mask
     if attention_mask.numel() == 1:
         return int(attention_mask.item())
+    key = (attention_mask._version, s_q, s_k)             # (the same tensor may be reused with another split of its elements)
     cached = getattr(attention_mask, "_cogv_sep", None)
-    if cached is not None and cached[0] == attention_mask._version:
+    if cached is not None and cached[0] == key:
         return cached[1]
     sep = None
     if attention_mask.numel() == s_q * s_k:
@@ -200,7 +201,7 @@ def mask_to_sep(attention_mask, s_q, s_k):
         if torch.equal(ref, m):
             sep = cand
     try:
-        attention_mask._cogv_sep = (attention_mask._version, sep)
+        attention_mask._cogv_sep = (key, sep)
     except Exception:
         pass
     return sep
@@ -208,9 +209,11 @@ def mask_to_sep(attention_mask, s_q, s_k):
 
 def general_mask(attention_mask, batch, s_q, s_k, dtype):
     """An arbitrary mask tensor in the form the kernels take: [B or 1, s_q, s_k], contiguous, storage type (the reference's
-    masks are [1, 1, s_q, s_k] or [b, 1, s_q, s_k], broadcast over the heads).  Cached per tensor object and dtype."""
+    masks are [1, 1, s_q, s_k] or [b, 1, s_q, s_k], broadcast over the heads).  Cached per tensor object, dtype and geometry.
+    (The general-mask kernels read the mask element by element, uncoalesced: fine off the hot path, which takes the `sep` form.)"""
+    key = (attention_mask._version, dtype, batch, s_q, s_k)
     cached = getattr(attention_mask, "_cogv_gmask", None)
-    if cached is not None and cached[0] == (attention_mask._version, dtype):
+    if cached is not None and cached[0] == key:
         return cached[1]
     n = attention_mask.numel()
     if n == s_q * s_k:
@@ -221,7 +224,7 @@ def general_mask(attention_mask, batch, s_q, s_k, dtype):
         raise ValueError(f"attention mask of shape {tuple(attention_mask.shape)} does not broadcast to [{batch}, 1, {s_q}, {s_k}]")
     m = m.to(dtype).contiguous()
     try:
-        attention_mask._cogv_gmask = ((attention_mask._version, dtype), m)
+        attention_mask._cogv_gmask = (key, m)
     except Exception:
         pass
     return m

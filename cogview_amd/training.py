@@ -112,9 +112,16 @@ def train_step(batch, model, optimizer, lr_scheduler=None, clip_grad=1.0, txt_lo
             if hasattr(model, 'needs_reduction'):
                 model.needs_reduction = False
             return tot.detach(), 1
+    overflow_before = getattr(optimizer, 'overflow', False)
     lm_loss = backward_step(optimizer, model, lm_loss, clip_grad, fp16, world_size=world_size, reduce_loss=log)
     if deferred and optimizer.forward_was_nan():
         print('Skipping backward and optimizer step for nan or inf in forwarding!')
+        # the reference returns before backward: its optimizer never sees these gradients.  Here they were produced and
+        # measured (update_master_grads) before the flag reached the host -- put the optimizer's visible state back: the
+        # overflow flag (saved by state_dict()) as it was, the statistics of the discarded gradients forgotten
+        optimizer.overflow = overflow_before
+        if hasattr(optimizer, '_stats_valid'):
+            optimizer._stats_valid = False
         return tot.detach(), 1
     optimizer.step()
     skipped = 0

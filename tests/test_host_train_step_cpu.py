@@ -89,3 +89,53 @@ def test_train_step_on_cpu_kernels_updates_through_the_flat_arena(cpu_kernels, g
     assert abs(losses[0] - float(g["loss"])) < 1e-3 * float(g["loss"])
     assert losses[2] < losses[1] < losses[0]
     assert torch.equal(opt._master_flat.half(), opt._arena.data)
+
+
+def test_deferred_forward_nan_guard_leaves_the_optimizer_as_the_reference_does(cpu_kernels, golden_dir, monkeypatch):
+    """training.train_step(check_forward_nan=True) on the fused optimizer: the forward's NaN flag reaches the host with the
+    gradient statistics, AFTER backward was enqueued (pretrain_gpt2.py:414-416 returns before backward).  A non-finite forward
+    must leave what the reference's early return leaves: parameters, fp32 masters and Adam moments untouched, loss scale and its
+    counters unchanged, `optimizer.overflow` as it was (round-4 advisor finding: it used to stay True), no scheduler step, the
+    return value (img_loss + txt_loss, 1) -- and the next clean step must run normally."""
+    from cogview_amd import training
+    from cogview_amd.fp16 import FP16_Module, FP16_Optimizer
+    from cogview_amd.model import GPT2Model, gpt2_get_params_for_weight_decay_optimization
+    from cogview_amd.optim import FusedAdam
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
+    z = np.load(os.path.join(golden_dir, "gpt2_small.npz"))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    L_, V_, H_, NH_, P_, S_, B_ = [int(v) for v in g["cfg"]]
+    m = GPT2Model(L_, V_, H_, NH_, 0.0, 0.0, 0.0, P_, 0, False)
+    m.load_state_dict({k[6:]: v for k, v in g.items() if k.startswith("param.")})
+    model = FP16_Module(m, dtype=torch.float16, keep_half_outputs=True)
+    groups = gpt2_get_params_for_weight_decay_optimization(model.module)
+    for grp in groups:
+        for p in grp["params"]:
+            p.model_parallel = getattr(p, "model_parallel", False)
+    opt = FP16_Optimizer(FusedAdam(groups, lr=1e-3, weight_decay=0.01), dynamic_loss_scale=True, dynamic_loss_args={"init_scale": 2 ** 10})
+
+    class Sched:
+        n = 0
+
+        def step(self):
+            Sched.n += 1
+
+    pos = torch.arange(S_).unsqueeze(0).expand(B_, -1)
+    batch = (g["tokens"], g["labels"], g["loss_mask"], 0, pos)
+    loss, skipped = training.train_step(batch, model, opt, lr_scheduler=Sched(), clip_grad=1.0, check_forward_nan=True)
+    assert skipped == 0 and Sched.n == 1 and opt.overflow is False
+    w = model.module.transformer.final_layernorm.weight
+    good = w.data.clone()
+    snap = (opt._arena.data.clone(), opt._master_flat.clone(), opt._m_flat.clone(), opt._v_flat.clone(), opt.loss_scale,
+            opt.loss_scaler.cur_iter, opt.loss_scaler.last_overflow_iter, opt._step_count)
+    w.data[0] = float("nan")                                         # the forward goes non-finite
+    snap_params = opt._arena.data.clone()
+    tot, skipped = training.train_step(batch, model, opt, lr_scheduler=Sched(), clip_grad=1.0, check_forward_nan=True)
+    assert skipped == 1 and not bool(torch.isfinite(tot).all()) and Sched.n == 1
+    assert opt.overflow is False and opt._stats_valid is False
+    assert torch.equal(opt._arena.data.view(torch.int16), snap_params.view(torch.int16))          # bit patterns: NaN != NaN
+    assert torch.equal(opt._master_flat, snap[1]) and torch.equal(opt._m_flat, snap[2]) and torch.equal(opt._v_flat, snap[3])
+    assert (opt.loss_scale, opt.loss_scaler.cur_iter, opt.loss_scaler.last_overflow_iter, opt._step_count) == snap[4:]
+    w.data.copy_(good)                                               # repaired: the next step is an ordinary one
+    loss2, skipped = training.train_step(batch, model, opt, lr_scheduler=Sched(), clip_grad=1.0, check_forward_nan=True)
+    assert skipped == 0 and Sched.n == 2 and bool(torch.isfinite(loss2)) and loss2.item() < loss.item()
