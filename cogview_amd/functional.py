@@ -717,7 +717,7 @@ class _DeferredWeightGrads:
     __slots__ = ("entries", "callbacks", "new_tiles", "hooked")
 
     def __init__(self):
-        self.entries, self.callbacks, self.new_tiles, self.hooked = [], [], 0, False
+        self.entries, self.callbacks, self.new_tiles, self.hooked = [], [], 0, -1      # hooked: graph-task id whose end is hooked
 
     def add(self, dy, x, w, owner=None):
         e = _WgradEntry(dy, x, w, owner)
@@ -810,25 +810,24 @@ def flush_weight_grads(final=True):
     while q.callbacks and id(q.callbacks[0][1]) not in busy:
         cb, layer = q.callbacks.pop(0)
         cb(layer)
-    if final:
-        q.hooked = False
 
 
 def _flush_at_end_of_backward():
-    _WGRADS.hooked = False
     flush_weight_grads(final=True)
 
 
 def defer_weight_grad(dy, x, w, owner=None):
     """Queue dW (+)= dY^T X for the next grouped launches.  Called inside an autograd backward pass: a callback at the end of
     that pass launches whatever no layer flush has taken (nothing in a GPT2Model step: layer index 0 flushes everything)."""
-    _WGRADS.add(dy, x, w, owner)
-    if not _WGRADS.hooked:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end_of_backward)
-            _WGRADS.hooked = True
-        except RuntimeError:                      # not inside a backward pass (a test driving _layer_backward by hand): the
-            pass                                  # caller flushes
+    q = _WGRADS
+    task = torch._C._current_graph_task_id()      # the autograd pass this call belongs to (-1: none)
+    if task >= 0 and q.hooked != task:
+        # the first problem of a new backward pass: hook its end, and drop whatever a pass that died half way (an exception
+        # between two flushes: the engine runs no final callbacks then) left behind -- stale tensors, gradients nobody consumed
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end_of_backward)
+        q.entries, q.callbacks, q.new_tiles = [], [], 0
+        q.hooked = task
+    q.add(dy, x, w, owner)                        # (outside a backward pass -- a test driving _layer_backward by hand -- the caller flushes)
 
 
 class _TransformerLayer(torch.autograd.Function):

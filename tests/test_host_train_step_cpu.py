@@ -139,3 +139,42 @@ def test_deferred_forward_nan_guard_leaves_the_optimizer_as_the_reference_does(c
     w.data.copy_(good)                                               # repaired: the next step is an ordinary one
     loss2, skipped = training.train_step(batch, model, opt, lr_scheduler=Sched(), clip_grad=1.0, check_forward_nan=True)
     assert skipped == 0 and Sched.n == 2 and bool(torch.isfinite(loss2)) and loss2.item() < loss.item()
+
+
+def test_a_backward_pass_that_dies_half_way_leaves_nothing_in_the_weight_gradient_queue(cpu_kernels, golden_dir, monkeypatch):
+    """An exception between two flushes of functional._DeferredWeightGrads (here: the attention backward of the last layer
+    raises) leaves queued problems whose tensors belong to a dead pass.  The next backward pass must start from an empty queue
+    and produce the fixture's gradients."""
+    from cogview_amd import functional as F_
+    from cogview_amd import mpu
+    from cogview_amd.model import GPT2Model
+    z = np.load(os.path.join(golden_dir, "gpt2_small.npz"))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    L_, V_, H_, NH_, P_, S_, B_ = [int(v) for v in g["cfg"]]
+    monkeypatch.setattr(F_, "_WGRADS", F_._DeferredWeightGrads())
+    m = GPT2Model(L_, V_, H_, NH_, 0.0, 0.0, 0.0, P_, 0, False)
+    m.load_state_dict({k[6:]: v for k, v in g.items() if k.startswith("param.")})
+    m = m.half()
+    pos = torch.arange(S_).unsqueeze(0).expand(B_, -1)
+    lm = g["loss_mask"].view(-1)
+
+    def loss_of():
+        logits, = m(g["tokens"], pos, 0, None, None, 0)
+        return (mpu.vocab_parallel_cross_entropy(logits.contiguous().float(), g["labels"]).view(-1) * lm).sum() / lm.sum()
+
+    real = F_.ops.attention_bwd
+
+    def boom(*a, **k):
+        raise RuntimeError("injected")
+
+    monkeypatch.setattr(F_.ops, "attention_bwd", boom)
+    with pytest.raises(RuntimeError, match="injected"):
+        loss_of().backward()
+    assert F_._WGRADS.entries, "the dead pass left its problems behind (that is the situation under test)"
+    monkeypatch.setattr(F_.ops, "attention_bwd", real)
+    for p in m.parameters():
+        p.grad = None
+    loss_of().backward()
+    assert not F_._WGRADS.entries and not F_._WGRADS.callbacks
+    worst = max(rel(p.grad.float(), g["grad." + n]) for n, p in m.named_parameters())
+    assert worst < 5e-3, worst
