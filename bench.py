@@ -260,6 +260,17 @@ def setup_dist(args):
     return world, rank
 
 
+def sampled_step(i, steps):
+    """Which timed steps carry HIP events around their launches (~1500 event pairs per 4B step since round 5 brackets attention,
+    LayerNorm and the optimizer too: ~1 % of such a step; round 4 measured 0.6 % for the 870 GEMM pairs,
+    profiles/r04_bench_event_overhead_ab.log): one step in eight from 16 steps on (the driver's 20: steps 7 and 15), one in four
+    below that, every step of a run shorter than four."""
+    if steps < 4:
+        return True
+    period = 8 if steps >= 16 else 4
+    return i % period == period - 1
+
+
 def timed_steps(step, args, world):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.
     Returns (elapsed seconds, kernel-timing statistics or None, value returned by the last step)."""
@@ -274,8 +285,8 @@ def timed_steps(step, args, world):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if timing is not None:               # HIP events around the dominant kernels of one timed step in four (the last of
-            ops.sample_gemm_timing(i % 4 == 3 or args.steps < 4)      # each group): 0.15 % of the step instead of 0.6 %
+        if timing is not None:               # HIP events around every kernel family's launches of SOME timed steps only
+            ops.sample_gemm_timing(sampled_step(i, args.steps))
         last = step()
     if world > 1:
         dist.barrier()
@@ -377,7 +388,7 @@ def run_gpt(args, dtype_name, world, rank, mp, parity=False):
     out["mfma_roofline_frac_causal_discounted"] = value / world * fpt_c / 1e12 / PEAK_MFMA_TFLOPS
     out["hardware_tflops_per_gpu"] = value / world * fpt_hw / 1e12
     out["mfma_roofline_frac_hardware_flops"] = value / world * fpt_hw / 1e12 / PEAK_MFMA_TFLOPS
-    sampled = args.steps // 4 if args.steps >= 4 else args.steps          # steps whose launches carried HIP events (timed_steps)
+    sampled = sum(1 for i in range(args.steps) if sampled_step(i, args.steps))          # steps whose launches carried HIP events (timed_steps)
     if gemm_stats is not None:
         all_stats, gemm_stats = gemm_stats, dict(gemm_stats["gemm"], by_variant={k: v for k, v in gemm_stats["by_variant"].items() if k in ops_gemm_families()},
                                                   by_shape=gemm_stats["by_shape"])
@@ -453,7 +464,7 @@ def run_vqvae(args, world, rank):
                       "distinct_codes_used": int(ids.unique().numel())},
            "model_tflops_per_gpu": value / world * fl / 1e12,
            "mfma_roofline_frac_end_to_end": value / world * fl / 1e12 / PEAK_FP32_MFMA_TFLOPS}
-    sampled = args.steps // 4 if args.steps >= 4 else args.steps
+    sampled = sum(1 for i in range(args.steps) if sampled_step(i, args.steps))
     if stats is not None:
         conv = stats["by_variant"].get("conv", {"tflops": 0.0, "launches": 0, "avg_ms": 0.0})
         conv_ms = conv["avg_ms"] * conv["launches"]

@@ -38,12 +38,14 @@ constexpr int NT = 256;         // threads per block (4 waves)
 constexpr float MASKED = -10000.0f;
 constexpr int TILE = 8192;      // one 64 x 64 16-bit tile
 // Stages of the K|V (forward, dQ) / Q|dO (dK.dV) LDS ring = prefetch distance + 1.  Three stages keep two blocks in flight per
-// workgroup (48-53 KiB: three workgroups per CU); two stages (32-36 KiB, one block in flight: it still has a whole block's
-// compute, ~2 us, to land) let four to five workgroups share a CU -- the kernels are parked 29-35 % of their wave cycles
-// (profiles/r05_attention_pmc.txt: ramp-up, diagonal blocks and tails of 20-us workgroups), which more resident workgroups
-// were expected to cover better than a deeper prefetch.  Measured (profiles/r05_attention_stages_ab.log, same call): forward and
-// backward each 1 % faster in the 4B step (0.387 -> 0.383 ms, 1.079 -> 1.068 ms), 2 % on the 336M shape -- so the parked cycles are
-// NOT an occupancy problem; two stages ship because they are not slower and leave LDS for neighbours.
+// workgroup (48-53 KiB), two stages one (32-36 KiB: it still has a whole block's compute, ~2 us, to land).  Round 5 built the
+// two-stage form expecting more workgroups per CU -- the kernels are parked 29-35 % of their wave cycles
+// (profiles/r05_attention_pmc.txt) -- but the occupancy of these kernels is set by REGISTERS, not LDS: 143 / 168 / 226 per lane
+// (forward / dQ / dK.dV with stored keep bits) = 3 / 3 / 2 waves per SIMD with either ring depth (tools/probes/attn_occupancy.hip,
+// profiles/r05_attention_occupancy_probe.log; the counters read 2.4 / 2.3 / 1.7 resident waves per SIMD for both).  Asking the
+// compiler for one more wave (__launch_bounds__(256, 4 / 4 / 3)) spills 52 / 120 / 224 bytes per lane inside the block loop,
+// between the asm-issued LDS reads and their waits (refused by build.py's hazard scan).  Two stages still measured 1 % faster per
+// kernel in the 4B step and 2 % on the 336M shape (profiles/r05_attention_stages_ab.log), so they ship.
 #ifndef COGV_ATTN_STAGES
 #define COGV_ATTN_STAGES 2
 #endif
