@@ -510,6 +510,9 @@ def main():
     if args.batch <= 0:
         args.batch = VQ_BATCH if args.config == "vqvae" else DEFAULT_BATCH[args.config]
 
+    # stdout carries the ONE JSON line and nothing else: the mirrors print what the reference prints ("> initializing model
+    # parallel ..."), which goes to stderr for the length of the run
+    json_out, sys.stdout = sys.stdout, sys.stderr
     world, rank = setup_dist(args)
     import torch.distributed as dist
     from cogview_amd import mpu
@@ -550,7 +553,7 @@ def main():
                     "sample": r["config"] + "; median of 5 iterations", "measured_where": r["where"] + ", not on this box",
                     "port_on_the_same_cores": r["port"]["tokens_per_s"], "source": os.path.relpath(rpath, ROOT)}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         dist.barrier()
     dist.destroy_process_group()

@@ -50,6 +50,23 @@ constexpr int TILE = 8192;      // one 64 x 64 16-bit tile
 #define COGV_ATTN_STAGES 2
 #endif
 constexpr int NSTG = COGV_ATTN_STAGES;
+// dK.dV register diet (round 5 experiment, profiles/r05_attention_dkdv_diet_ab.log): the training instantiation needs 226
+// registers = two waves per SIMD.  COGV_DKDV_AHEAD=0 drops the ahead-of-time request of the transposed dO / Q fragments (-32),
+// COGV_DKDV_VLDS=1 keeps the V fragments of the wave's own keys in LDS behind the ring instead of in registers (-16; +16 KiB
+// per workgroup: three still fit a CU with the two-stage ring), COGV_DKDV_WAVES=3 asks the allocator for three waves per SIMD
+// (168 registers, 24 B of spill outside the asm-read windows).  The runtime then grants three workgroups per CU -- and the
+// kernel is NOT faster: backward 1018-1031 us against 1000-1013 with two waves (same call), the 4B step unchanged.  A third
+// wave per SIMD does not cover the parked cycles; the defaults (two waves, fragments requested ahead) stay.
+#ifndef COGV_DKDV_AHEAD
+#define COGV_DKDV_AHEAD 1
+#endif
+#ifndef COGV_DKDV_VLDS
+#define COGV_DKDV_VLDS 0
+#endif
+#ifndef COGV_DKDV_WAVES
+#define COGV_DKDV_WAVES 2
+#endif
+constexpr int DKDV_OWN_V = COGV_DKDV_VLDS ? 4 * 4 * 64 * 16 : 0;      // bytes of the waves' own V fragments behind the ring
 static_assert(NSTG == 2 || NSTG == 3, "ring of two or three stages");
 constexpr int COLSUM_SMEM = (128 * 68 + 256) * 4;      // tile_colsum's scratch (the ring is free by then)
 constexpr int ring_bytes(int stage, bool colsum) { return (colsum && NSTG * stage < COLSUM_SMEM) ? COLSUM_SMEM : NSTG * stage; }
@@ -749,7 +766,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 // DMAs per stage), and a lane (= key) picks ITS bit out of the word of each of its 16 queries: four ds_read_b128 +
 // 16 x (v_bfe_i32, v_and) per 32 x 32 tile where the regenerating form hashes four draws and shares them through DPP.
 template <typename T, bool IDX, int DROP>
-__global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(NT, (!IDX && DROP == 2) ? COGV_DKDV_WAVES : 2) void attn_bwd_dkdv_kernel(const AttnArgs p) {
   const bool drop = DROP < 0 ? (p.thr16 != 0u) : (DROP != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool KB = DROP == 2;
@@ -791,6 +808,14 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
   for (int t = 0; t < 4; ++t) {
     kf[t] = load_frag_global<T>(K + (long long)krow * p.k_rs + 16 * t + 8 * fg, kvalid);
     vf[t] = load_frag_global<T>(V + (long long)krow * p.v_rs + 16 * t + 8 * fg, kvalid);
+  }
+  // (diet) the V fragments parked in LDS behind the ring, one 16-byte slot per (wave, t, lane): lane-private, so the in-order LDS
+  // queue is all the ordering the write and the later reads need
+  constexpr bool VLDS = KB && !IDX && (COGV_DKDV_VLDS != 0);
+  typename HT<T>::v8* const own_v = reinterpret_cast<typename HT<T>::v8*>(smem + ring_bytes(STAGE, true)) + (wave * 4) * 64 + lane;
+  if (VLDS) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) own_v[t * 64] = vf[t];
   }
   const int qbeg_blk = (k0 < p.sep_k) ? qlo : max(qlo, k0 - off);
   const int qbeg_w = (k0w < p.sep_k) ? qlo : max(qlo, k0w - off);
@@ -849,11 +874,11 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
         // requested NOW and land behind the S / dP products and the element-wise chain; the regenerating form (register
         // pressure at the limit) reads them synchronously where they are used -- two exposed LDS round trips per half
         TrRaw dor_a[2][2], qr_a[2][2];
-        if (KB) { tr_frags_issue<T, sb>(ldot, loff, dor_a); tr_frags_issue<T, sb>(lqt, loff, qr_a); }
+        if (KB && COGV_DKDV_AHEAD) { tr_frags_issue<T, sb>(ldot, loff, dor_a); tr_frags_issue<T, sb>(lqt, loff, qr_a); }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           sacc = HT<T>::mfma32(nat_frag<T>(lq, sb * 32 + fr, 2 * t + fg), kf[t], sacc);     // S = Q K^T
-          pacc = HT<T>::mfma32(nat_frag<T>(ldo, sb * 32 + fr, 2 * t + fg), vf[t], pacc);    // dPd = dO V^T
+          pacc = HT<T>::mfma32(nat_frag<T>(ldo, sb * 32 + fr, 2 * t + fg), VLDS ? own_v[t * 64] : vf[t], pacc);    // dPd = dO V^T
         }
         // element e <-> query qfirst + 4fg + (e&3) + 8(e>>2); key fixed per lane
         const int qfirst = qb * 64 + sb * 32;
@@ -942,7 +967,7 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dkdv_kernel(const AttnArgs p) 
         typename HT<T>::v8 pb[2], dsb[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) { pb[t] = cvt8<T>(pd + 8 * t); dsb[t] = cvt8<T>(ds + 8 * t); }
-        if (KB) {
+        if (KB && COGV_DKDV_AHEAD) {
           tr_wait(dor_a[0][0], dor_a[0][1]); tr_wait(dor_a[1][0], dor_a[1][1]);
           tr_wait(qr_a[0][0], qr_a[0][1]); tr_wait(qr_a[1][0], qr_a[1][1]);
 #pragma unroll
@@ -1306,7 +1331,7 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
     set_smem(&attn_bwd_dq_kernel<f16_t, false, 0>, ring_bytes(2 * TILE, true)); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 0>, ring_bytes(2 * TILE, true));
     set_smem(&attn_bwd_dq_kernel<f16_t, false, 1>, ring_bytes(2 * TILE, true)); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 1>, ring_bytes(2 * TILE, true));
     set_smem(&attn_bwd_dq_kernel<f16_t, false, 2>, ring_bytes(2 * TILE + 1024, true)); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 2>, ring_bytes(2 * TILE + 1024, true));
-    set_smem(&attn_bwd_dkdv_kernel<f16_t, false, 2>, ring_bytes(2 * TILE + 1536, true)); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false, 2>, ring_bytes(2 * TILE + 1536, true));
+    set_smem(&attn_bwd_dkdv_kernel<f16_t, false, 2>, ring_bytes(2 * TILE + 1536, true) + DKDV_OWN_V); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false, 2>, ring_bytes(2 * TILE + 1536, true) + DKDV_OWN_V);
     attr = true;
   }
   // the flexible dQ instantiation (gathered / sparse keys: ring + index table; arbitrary mask tensors: ring only) shares ONE
@@ -1319,7 +1344,7 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   if (d->keep_bits && drop && !a.kv_index) {      // the keep bits the forward call stored (same dropout_p / seed / stream)
     if ((uintptr_t)d->keep_bits & 3) return COGV_ERR_ARG;
     a.keepbits = reinterpret_cast<uint32_t*>(d->keep_bits);
-    const int shq2 = ring_bytes(2 * TILE + 1024, true), shk2 = ring_bytes(2 * TILE + 1536, true);
+    const int shq2 = ring_bytes(2 * TILE + 1024, true), shk2 = ring_bytes(2 * TILE + 1536, true) + DKDV_OWN_V;
     if (d->dtype == COGV_F16) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, false, 2>), gq, dim3(NT), shq2, st, a);
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t, false, 2>), gk, dim3(NT), shk2, st, a);

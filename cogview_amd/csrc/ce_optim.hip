@@ -79,6 +79,20 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const LT* logits, const int
 }
 
 // ---------------------------------------------------------------------------------- grad statistics
+// eight consecutive gradients as floats: one 16-byte load of a 16-bit buffer, two of an fp32 buffer (the master gradients of
+// FP16_Optimizer's generic path and of fp32 models, mpu/grads.py:62-84)
+template <typename T> struct GradIO {
+  static __device__ __forceinline__ void load8(const T* p, float* v) { unpack8<T>(*reinterpret_cast<const u32x4*>(p), v); }
+  static __device__ __forceinline__ float load1(const T* p) { return HT<T>::to_f(*p); }
+};
+template <> struct GradIO<float> {
+  static __device__ __forceinline__ void load8(const float* p, float* v) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = a[k]; v[4 + k] = b[k]; }
+  }
+  static __device__ __forceinline__ float load1(const float* p) { return *p; }
+};
 template <typename T>
 __global__ __launch_bounds__(256) void grad_stats_kernel(const T* grads, const int64_t* chunk_start,
                                                         const int32_t* chunk_len, const uint8_t* chunk_norm,
@@ -92,12 +106,12 @@ __global__ __launch_bounds__(256) void grad_stats_kernel(const T* grads, const i
     const int nvec = len >> 3;
     float csq = 0.f;
     for (int i = threadIdx.x; i < nvec; i += 256) {
-      float v[8]; unpack8<T>(*reinterpret_cast<const u32x4*>(g + i * 8), v);
+      float v[8]; GradIO<T>::load8(g + i * 8, v);
 #pragma unroll
       for (int k = 0; k < 8; ++k) { csq += v[k] * v[k]; if (!(fabsf(v[k]) <= 3.0e38f)) bad = true; }
     }
     for (int i = (nvec << 3) + threadIdx.x; i < len; i += 256) {
-      const float v = HT<T>::to_f(g[i]); csq += v * v; if (!(fabsf(v) <= 3.0e38f)) bad = true;
+      const float v = GradIO<T>::load1(g + i); csq += v * v; if (!(fabsf(v) <= 3.0e38f)) bad = true;
     }
     if (counted) sq += csq;
   }
@@ -253,7 +267,7 @@ extern "C" size_t cogv_grad_stats_workspace_bytes(void) { return 2048 * sizeof(d
 extern "C" int cogv_grad_stats(int dtype, const void* grads, const int64_t* chunk_start, const int32_t* chunk_len,
                                const uint8_t* chunk_norm, int nchunks, double* stats, void* workspace,
                                size_t workspace_bytes, void* stream) {
-  if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
+  if (dtype != COGV_F16 && dtype != COGV_BF16 && dtype != COGV_F32) return COGV_ERR_UNSUPPORTED;
   if (!grads || !chunk_start || !chunk_len || !chunk_norm || nchunks <= 0 || !stats) return COGV_ERR_ARG;
   if ((uintptr_t)grads & 15) return COGV_ERR_ARG;
   // per-workgroup partial sums live in the CALLER's workspace (round 3 kept them in a lazily allocated static buffer: a race
@@ -263,7 +277,8 @@ extern "C" int cogv_grad_stats(int dtype, const void* grads, const int64_t* chun
   const int g = nchunks < 2048 ? nchunks : 2048;
   double* partial = reinterpret_cast<double*>(workspace);
   if (dtype == COGV_F16) hipLaunchKernelGGL((grad_stats_kernel<f16_t>), dim3(g), dim3(256), 0, st, (const f16_t*)grads, chunk_start, chunk_len, chunk_norm, nchunks, stats, partial);
-  else hipLaunchKernelGGL((grad_stats_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)grads, chunk_start, chunk_len, chunk_norm, nchunks, stats, partial);
+  else if (dtype == COGV_BF16) hipLaunchKernelGGL((grad_stats_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)grads, chunk_start, chunk_len, chunk_norm, nchunks, stats, partial);
+  else hipLaunchKernelGGL((grad_stats_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)grads, chunk_start, chunk_len, chunk_norm, nchunks, stats, partial);
   hipLaunchKernelGGL(grad_stats_final_kernel, dim3(1), dim3(64), 0, st, partial, g, stats);
   return cogv_check_launch();
 }

@@ -14,6 +14,8 @@ with ONE host read per step (the overflow flag + norm, needed by the loss-scale 
 Any other combination (loose parameters, another inner optimizer) takes the generic path that mirrors the
 reference step by step.
 """
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -83,6 +85,17 @@ class FP16_Optimizer(object):
                  and all(p.dtype in _HALF for g in self.optimizer.param_groups for p in g['params'] if p.requires_grad)
                  and len({id(p) for p in half_params}) == len(arena.params))
         self._arena = arena if fused else None
+        if not fused and half_params:
+            # never silent: the generic path keeps the reference's per-tensor semantics (fp16/fp16.py:322-...), with the norm /
+            # overflow reductions on cogv_grad_stats but per-tensor copies and the inner optimizer's own update
+            why = ("the 16-bit parameters are not views of one flat arena (build the model through FP16_Module / "
+                   "arena.flatten_module)" if arena is None else
+                   "the inner optimizer is %s, not cogview_amd's FusedAdam" % type(self.optimizer).__name__
+                   if not isinstance(self.optimizer, FusedAdam) else
+                   "more than 8 parameter groups" if len(self.optimizer.param_groups) > 8 else
+                   "the optimizer mixes fp32 parameters with the 16-bit ones, or holds only part of the arena")
+            warnings.warn("FP16_Optimizer: per-tensor path instead of the fused flat one (one statistics launch + one AdamW "
+                          "launch per step): " + why, RuntimeWarning, stacklevel=2)
         if fused:
             self._master_flat = torch.empty(arena.total, dtype=torch.float32, device=arena.data.device)
             ops.cast_flat(arena.data, self._master_flat)

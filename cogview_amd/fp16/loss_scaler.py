@@ -8,6 +8,7 @@ import torch
 
 from .. import mpu
 from .. import ops
+from ..mpu.grads import _chunk_tables
 
 
 def to_python_float(t):
@@ -21,15 +22,9 @@ def _device_overflow_flag(params):
         return None
     dev = params[0].grad.device
     stats = torch.zeros(2, dtype=torch.float64, device=dev)
-    for p in params:
-        g = p.grad.data
-        if g.dtype == torch.float32:
-            stats[1] += (~torch.isfinite(g)).any().double()
-        else:
-            gc = g if g.is_contiguous() else g.contiguous()
-            ops.grad_stats(gc.view(-1), torch.zeros(1, dtype=torch.int64, device=dev),
-                           torch.tensor([gc.numel()], dtype=torch.int32, device=dev),
-                           torch.ones(1, dtype=torch.uint8, device=dev), stats)
+    # one cogv_grad_stats launch per underlying storage (ONE for gradients that live in a flat arena), 16-bit and fp32 alike
+    for flat, cs, cl, cn in _chunk_tables([p.grad.data for p in params]):
+        ops.grad_stats(flat, cs, cl, cn, stats)
     return stats
 
 

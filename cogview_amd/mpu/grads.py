@@ -28,7 +28,7 @@ def _chunk_tables(grads):
                 gc = gc.clone()
             out.append((gc, [(0, gc.numel())]))
     for (_, dtype), (st, chunks) in by_storage.items():
-        flat = torch.empty(0, dtype=dtype, device=grads[0].device).set_(st, 0, (st.nbytes() // 2,))      # 16-bit elements
+        flat = torch.empty(0, dtype=dtype, device=grads[0].device).set_(st, 0, (st.nbytes() // dtype.itemsize,))
         out.append((flat, sorted(chunks)))
     dev = grads[0].device
     return [(flat, torch.tensor([c[0] for c in ch], dtype=torch.int64, device=dev),
@@ -49,10 +49,11 @@ def clip_grad_norm(parameters, max_norm, norm_type=2):
         slot = ops.new_absmax_slot(dev)
         for p in parameters:
             g = p.grad.data
-            if g.dtype == torch.float32:
-                torch.maximum(slot, g.abs().max().reshape(1), out=slot)
+            g = g.contiguous()
+            if g.dtype == torch.float32 and (g.numel() % 4 or g.data_ptr() % 16):
+                torch.maximum(slot, g.abs().max().reshape(1), out=slot)      # an odd-sized fp32 tensor: cogv_absmax reads 16 B
             else:
-                ops.absmax(g.contiguous(), slot)
+                ops.absmax(g, slot)
         total = slot.clone()
         if mp > 1:
             torch.distributed.all_reduce(total, op=torch.distributed.ReduceOp.MAX, group=get_model_parallel_group())
@@ -60,13 +61,8 @@ def clip_grad_norm(parameters, max_norm, norm_type=2):
     elif norm_type == 2.0:
         stats = torch.zeros(2, dtype=torch.float64, device=dev)
         counted = [p.grad.data for p in parameters if getattr(p, 'model_parallel', False) or mp_rank_or_0() == 0]
-        for g in counted:
-            if g.dtype == torch.float32:
-                # fp32 master gradients (FP16_Optimizer's non-arena path): torch reduction on a tiny API path
-                stats[0] += g.double().pow(2).sum()
-        half = [g for g in counted if g.dtype != torch.float32]
-        if half:
-            for flat, cs, cl, cn in _chunk_tables(half):
+        if counted:                                   # 16-bit model gradients and fp32 master gradients alike: cogv_grad_stats
+            for flat, cs, cl, cn in _chunk_tables(counted):
                 ops.grad_stats(flat, cs, cl, cn, stats)
         if mp > 1:
             torch.distributed.all_reduce(stats, group=get_model_parallel_group())

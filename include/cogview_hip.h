@@ -292,7 +292,8 @@ int cogv_ce_bwd(int logits_dtype, const void* logits, const int64_t* target, int
  */
 /* stats[0] += sum of squares of grads in counted chunks (double; per-workgroup partials summed in a fixed order: the same
  * bits run after run), stats[1] = 1.0 if any grad is inf/nan.  workspace: cogv_grad_stats_workspace_bytes() bytes of scratch
- * owned by the caller (8-byte aligned, no initialisation; one per stream that may run the pass concurrently). */
+ * owned by the caller (8-byte aligned, no initialisation; one per stream that may run the pass concurrently).  dtype may be
+ * COGV_F32: the fp32 master gradients of FP16_Optimizer's generic path / of an fp32 model (mpu/grads.py:62-84). */
 int cogv_grad_stats(int dtype, const void* grads, const int64_t* chunk_start, const int32_t* chunk_len,
                     const uint8_t* chunk_norm, int nchunks, double* stats, void* workspace, size_t workspace_bytes,
                     void* stream);

@@ -178,3 +178,14 @@ def test_a_backward_pass_that_dies_half_way_leaves_nothing_in_the_weight_gradien
     assert not F_._WGRADS.entries and not F_._WGRADS.callbacks
     worst = max(rel(p.grad.float(), g["grad." + n]) for n, p in m.named_parameters())
     assert worst < 5e-3, worst
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_generic_optimizer_path_warns_and_follows_the_reference_step(cpu_kernels, monkeypatch, dtype):
+    """FP16_Optimizer around loose parameters and torch.optim.SGD (fp16/fp16.py:322-453 step by step): a RuntimeWarning names why
+    the fused flat path was not taken; overflow pass on the 16-bit model gradients and norm on the fp32 masters both through
+    ops.grad_stats; clean step = fp32 arithmetic written out; overflowing step skipped with the scale halved.  The same case
+    runs through the C ABI in tests/test_generic_optimizer_gpu.py."""
+    from tests.optimizer_cases import run_generic_path_case
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
+    run_generic_path_case(dtype, "cpu")

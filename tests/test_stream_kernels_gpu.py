@@ -252,9 +252,51 @@ def test_clip_grad_norm_is_one_pass_per_storage_and_exact():
     finally:
         ops.grad_stats = real
     assert abs(total - ref) < 1e-6 * ref
-    assert sorted(calls) == [1, 1, 3], calls            # arena views sharing a table (3 chunks), the odd-offset view, the bf16 tensor
+    # arena views sharing a table (3 chunks), the odd-offset view, the bf16 tensor, the fp32 tensor (cogv_grad_stats takes fp32 too)
+    assert sorted(calls) == [1, 1, 1, 3], calls
     for p, b0 in zip(params, before):
         assert ((p.grad.float() - 0.5 * b0.float()).abs().max() <= 4e-3 * b0.float().abs().max()).item()
+
+
+def test_fp32_gradients_take_the_same_kernels():
+    """mpu/grads.py:62-84 on fp32 gradients (FP16_Optimizer's master gradients outside the flat path, fp32 models): the 2-norm
+    and the overflow flag are cogv_grad_stats in its fp32 instantiation, the inf-norm cogv_absmax -- no torch reductions; views
+    of one fp32 buffer share one launch; a non-finite value raises the flag; lengths that are not multiples of 8 / 4."""
+    from cogview_amd import mpu, ops
+    from cogview_amd.fp16.loss_scaler import DynamicLossScaler
+    g = torch.Generator().manual_seed(11)
+    buf = torch.randn(40000, generator=g).cuda()
+    grads = [buf[0:12345], buf[12352:12352 + 20000].view(200, 100), torch.randn(1001, generator=g).cuda(),
+             torch.randn(8, 128, generator=g).cuda()]
+    params = []
+    for t in grads:
+        p = torch.nn.Parameter(torch.zeros_like(t))
+        p.grad = t
+        p.model_parallel = False
+        params.append(p)
+    ref2 = sum(float((p.grad.double() ** 2).sum()) for p in params) ** 0.5
+    refinf = max(float(p.grad.abs().max()) for p in params)
+    calls = []
+    real = ops.grad_stats
+    ops.grad_stats = lambda *a, **k: (calls.append((a[0].dtype, a[1].numel())), real(*a, **k))[1]
+    try:
+        total = mpu.clip_grad_norm(params, 1e9)
+        assert not DynamicLossScaler().has_overflow_serial(params)
+        params[1].grad.view(-1)[19999] = float("nan")
+        assert DynamicLossScaler().has_overflow_serial(params)
+        params[1].grad.view(-1)[19999] = 0.25
+        params[2].grad[1000] = float("inf")             # in the scalar tail of a length that is not a multiple of 8
+        assert DynamicLossScaler().has_overflow_serial(params)
+        params[2].grad[1000] = 0.0
+    finally:
+        ops.grad_stats = real
+    assert abs(total - ref2) < 1e-6 * ref2
+    assert all(dt == torch.float32 for dt, _ in calls) and sorted(n for _, n in calls[:3]) == [1, 1, 2], calls
+    assert mpu.clip_grad_norm(params, 1e9, float("inf")) == pytest.approx(refinf, rel=1e-7)
+    before = [p.grad.clone() for p in params]
+    mpu.clip_grad_norm(params, ref2 / 4)
+    for p, b0 in zip(params, before):
+        assert torch.allclose(p.grad, 0.25 * b0, rtol=1e-5, atol=0)
 
 
 def test_grad_stats_and_clip_grad_norm_on_a_side_stream():
