@@ -156,3 +156,45 @@ def filling_sequence(model, seq, args, mems=None, invalid_slices=[], tokenizer=N
                 img_indices_bool = tokens < n_img
                 txt_indices_bool = ~img_indices_bool
     return tokens.view(tokens.shape[0], -1).contiguous()
+
+
+def inverse_prompt_score(model, seq, args, tokenizer=None):
+    """generation/sampling.py:222-239 (post-selection): for rows laid out as [BASE] [BOI1] 1024 image codes [EOI1] [ROI1] text...,
+    the log-likelihood of the text given the image -- one full forward per call, image codes excluded from the softmax,
+    summed over the text positions.  Returns [rows] fp32."""
+    tokenizer = tokenizer if tokenizer is not None else IdSpace()
+    assert seq.dim() == 2
+    first_text = 2 + 1024 + 1                                   # index of [ROI1]: the text it scores starts right after
+    assert int(seq[0, first_text]) == tokenizer['[ROI1]']
+    tokens, attention_mask, position_ids = get_batch(seq, seq.device, args)
+    with torch.no_grad():
+        logits, *_ = model(tokens, position_ids, attention_mask, None, None, args.is_sparse)
+        logits = logits.float()
+        logits[..., :tokenizer.img_tokenizer.num_tokens] = -float('Inf')
+        log_probs = F.log_softmax(logits[:, first_text:-1], dim=-1)
+        return torch.gather(log_probs, 2, tokens[:, first_text + 1:].unsqueeze(-1)).squeeze(-1).sum(dim=-1)
+
+
+# (row block, column block, lines to fill) of the nine overlapping 16 x 16 -> 32 x 32 windows, in generation order
+_MAGNIFY_WINDOWS = ((0, 0, 18), (0, 1, 30), (0, 2, 30), (1, 1, 30), (1, 0, 30), (1, 2, 30), (2, 0, 32), (2, 1, 32), (2, 2, 32))
+
+
+def magnify(model, tokenizer, tokens_list, text_token_list, args, fill=None):
+    """generation/magnify.py:22-43 (super-resolution): a 32 x 32 code map is magnified to 64 x 64 window by window -- each window
+    conditions on the text, a 16 x 16 patch of the small map and the marker run [EOI1] [ROI2] [POS0] [BASE] [BOI2], and fills
+    the not-yet-written lines of the matching 32 x 32 patch of the large map (lines written by an earlier window are given).
+    Returns [1, 4096] codes.  `fill`: the sequence filler (default: filling_sequence of this module; the tokenizer is handed on)."""
+    fill = fill if fill is not None else filling_sequence
+    side = int(round(len(tokens_list) ** 0.5))
+    assert side == 32 and side * side == len(tokens_list)
+    code = tokens_list.view(side, side)
+    midfix = torch.tensor([tokenizer[m] for m in ('[EOI1]', '[ROI2]', '[POS0]', '[BASE]', '[BOI2]')], device=code.device)
+    big = torch.full((2 * side, 2 * side), -1, dtype=torch.long, device=code.device)
+    only_image_codes = [slice(tokenizer.img_tokenizer.num_tokens, None)]
+    for bi, bj, lines in _MAGNIFY_WINDOWS:
+        patch = code[8 * bi: 8 * (bi + 2), 8 * bj: 8 * (bj + 2)].reshape(-1)
+        target = big[16 * bi: 16 * bi + lines, 16 * bj: 16 * (bj + 2)]
+        context = torch.cat([text_token_list, patch, midfix], dim=0)
+        done = fill(model, torch.cat([context, target.reshape(-1)], dim=0), args, invalid_slices=only_image_codes, tokenizer=tokenizer)
+        big[16 * bi: 16 * bi + lines, 16 * bj: 16 * (bj + 2)] = done[0, len(context):].view(lines, 32)
+    return big.view(1, 4 * side * side)

@@ -293,6 +293,21 @@ def scale(x, s):
     return (x.float() * s).to(x.dtype)
 
 
+def gelu_fwd(x):
+    return _gelu(x.float()).to(x.dtype)
+
+
+def gelu_bwd(dy, x):
+    return (dy.float() * _gelu_grad(x.float())).to(x.dtype)
+
+
+def dropout(x, p, seed, stream_id, absmax_out=None):
+    assert float(p) == 0.0, "tests/cpu_ops.py does not emulate dropout"
+    y = x.clone()
+    _publish(absmax_out, y)
+    return y
+
+
 def add(a, b, absmax_out=None):
     out = (a.float() + b.float()).to(torch.float32 if a.dtype == torch.float32 else a.dtype)
     _publish(absmax_out, out)
@@ -301,7 +316,7 @@ def add(a, b, absmax_out=None):
 
 NAMES = ("new_absmax_slot", "absmax", "gemm", "gemm_grouped", "colsum", "sandwich_ln_fwd", "sandwich_ln_bwd", "attention_fwd",
          "attention_bwd", "embedding_fwd", "embedding_bwd", "ce_fwd", "ce_bwd", "grad_stats", "adamw_step", "cast_flat",
-         "cast_flat_back", "scale", "add")
+         "cast_flat_back", "scale", "add", "gelu_fwd", "gelu_bwd", "dropout")
 
 
 def install(setattr_fn=None):
