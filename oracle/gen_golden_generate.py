@@ -27,6 +27,11 @@ from gen_golden import OUT, install_shims, npz
 # the others have a choice at 0.0002 .. 0.007, which 16-bit arithmetic may legitimately flip)
 CFG = dict(layers=4, hidden=256, heads=4, max_pos=1089, max_mem=1089, seed=17, img_tokens=8192, txt_tokens=500, divisible_by=128,
            n_generate=40, beams=2)
+# sparse generation (is_sparse = 2, mpu/sparse_transformer.py:497-520, 590-601, 727-750): a second, smaller-window model so that 64
+# generated codes outgrow the trailing window (2 x 16 positions) and every layer samples pivots (all text positions + a random
+# subset of the image positions left of the window, drawn with `random.sample`: the consumer seeds `random` the same way).
+# seed 27: of 23..31 the most decisive (smallest top-2 gap 0.020 of the logits' std)
+SPARSE = dict(seed=27, query_window=16, key_window_times=2, num_pivot=256, n_generate=64, random_seed=99)
 MARKERS = ["[ROI1]", "[BASE]", "[BOI1]", "[EOI1]", "[ROI2]", "[BOI2]", "[EOI2]", "[POS0]"]
 
 
@@ -68,6 +73,13 @@ def scenario(tok, cfg=CFG):
     head = torch.cat([torch.tensor([tok["[BASE]"], tok["[BOI1]"]]), image, torch.tensor([tok["[EOI1]"], tok["[ROI1]"]])])
     sel = torch.stack([torch.cat([head, txt(8)]), torch.cat([head, txt(8)])])
     return t2i, sel
+
+
+def sparse_sequence(tok, cfg=CFG, sp=SPARSE):
+    g = torch.Generator().manual_seed(sp["seed"] + 1)
+    txt = torch.randint(cfg["img_tokens"], cfg["img_tokens"] + cfg["txt_tokens"], (5,), generator=g)
+    return torch.cat([torch.tensor([tok["[ROI1]"]]), txt, torch.tensor([tok["[BASE]"], tok["[BOI1]"]]),
+                      torch.full((sp["n_generate"],), -1, dtype=torch.long)])
 
 
 def sampling_args(cfg=CFG):
@@ -127,12 +139,44 @@ def main():
     with torch.no_grad():
         scores = inverse_prompt_score(model, sel, args)
     assert out_tokens.shape == (c["beams"], t2i.numel()) and torch.equal(out_tokens[0], out_tokens[1])
+
+    # sparse generation
+    import random
+    sp = SPARSE
+    torch.manual_seed(sp["seed"])
+    smodel = GPT2Model(num_layers=c["layers"], vocab_size=vocab, hidden_size=c["hidden"], num_attention_heads=c["heads"],
+                       embedding_dropout_prob=0.1, attention_dropout_prob=0.1, output_dropout_prob=0.1,
+                       max_sequence_length=c["max_pos"], max_memory_length=c["max_mem"], checkpoint_activations=False,
+                       checkpoint_num_layers=1, parallel_output=True, query_window=sp["query_window"],
+                       key_window_times=sp["key_window_times"], num_pivot=sp["num_pivot"])
+    smodel.eval()
+    sargs = sampling_args()
+    sargs.is_sparse = 2
+    sseq = sparse_sequence(tok)
+    sgaps, real_forward = [], smodel.forward
+
+    def recording_sparse_forward(*a, **k):
+        out = real_forward(*a, **k)
+        last = out[0][0, -1, :c["img_tokens"]].detach().double()
+        top2 = torch.topk(last, 2)[0]
+        sgaps.append(float(top2[0] - top2[1]) / float(last.std()))
+        return out
+
+    smodel.forward = recording_sparse_forward
+    random.seed(sp["random_seed"])
+    with torch.no_grad():
+        sparse_out = filling_sequence(smodel, sseq.clone(), sargs)
+    assert sparse_out.shape == (1, sseq.numel())
+    print("sparse generation", sparse_out[0, -sp["n_generate"]:].tolist())
+    print("smallest gap, sparse generation: %.4f" % min(sgaps))
     print("generated", out_tokens[0, -c["n_generate"]:].tolist())
     print("smallest gap between the two best admissible logits, in units of the logits' std: %.4f" % min(gaps))
     print("scores", scores.tolist())
     npz("generate_samples.npz", cfg=np.array([c[k] for k in ("layers", "hidden", "heads", "max_pos", "max_mem", "seed", "img_tokens",
                                                              "txt_tokens", "divisible_by", "n_generate", "beams")]),
-        vocab=np.int64(vocab), t2i_seq=t2i, t2i_out=out_tokens, t2i_gaps=np.array(gaps), sel_seq=sel, sel_scores=scores.double())
+        vocab=np.int64(vocab), t2i_seq=t2i, t2i_out=out_tokens, t2i_gaps=np.array(gaps), sel_seq=sel, sel_scores=scores.double(),
+        sparse_cfg=np.array([sp[k] for k in ("seed", "query_window", "key_window_times", "num_pivot", "n_generate", "random_seed")]),
+        sparse_seq=sseq, sparse_out=sparse_out, sparse_gaps=np.array(sgaps))
 
 
 if __name__ == "__main__":

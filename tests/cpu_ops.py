@@ -6,7 +6,7 @@ where the kernels round).  It exists so that the HOST side of the path -- the `m
 layer Function, the gradient arena, the fused optimizer's control flow, and the REFERENCE's own driver functions calling them
 (tests/test_reference_drivers_cpu.py) -- can execute end to end in a container without a GPU.  Nothing in the product
 imports this file; the product path fails loudly without the HIP library (tests/test_abi.py).  Dropout is not emulated
-(every caller here runs with p = 0), nor are the decode / sparse / gathered forms.
+(every caller here runs with p = 0), nor are the decode and the sparse-training forms (the gathered form of sparse generation is).
 """
 import math
 
@@ -155,7 +155,14 @@ def _attn(q, k, v, sep):
 
 def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None, keep_bits=False, mask=None):
     _no_dropout(dropout)
-    assert kv_index is None and sparse is None and mask is None
+    assert sparse is None and mask is None
+    if kv_index is not None:
+        # gathered form (sparse_attention_inference): key slot j of row i is position kv_index[i, j]; the last s_q slots are the
+        # queries themselves, left-to-right among them (include/cogview_hip.h, cogv_attention_fwd with kv_index)
+        assert int(sep) == 0
+        idx = kv_index.long()
+        k = torch.stack([k[i, idx[i]] for i in range(k.shape[0])])
+        v = torch.stack([v[i, idx[i]] for i in range(v.shape[0])])
     o, lse = _attn(q, k, v, sep)
     o = o.contiguous().to(q.dtype)
     return (o, lse, None) if keep_bits else (o, lse)

@@ -124,6 +124,22 @@ with tempfile.TemporaryDirectory() as tmp:
     lines = open(os.path.join(tmp, "sel", "scores_rank_0.txt")).read().splitlines()
     out["sel_text"], out["sel_scores"] = lines[0], [float(x) for x in lines[1].split("\t")]
 
+# sparse generation (is_sparse = 2): a model with a 2 x 16-position trailing window; every layer of every pass samples its pivots
+# with `random.sample`, so `random` is seeded as the golden's generator seeded it
+import random
+sp = G.SPARSE
+args.query_window, args.key_window_times, args.num_pivot = sp["query_window"], sp["key_window_times"], sp["num_pivot"]
+args.is_sparse, args.max_inference_batch_size = 2, 1
+torch.manual_seed(sp["seed"])
+smodel = S.setup_model(args)
+tok.decoded.clear()
+with tempfile.TemporaryDirectory() as tmp:
+    random.seed(sp["random_seed"])
+    S.generate_images_once(smodel, args, "five text pieces, sparse", seq=torch.from_numpy(gold["sparse_seq"]).clone(), num=1,
+                           output_path=os.path.join(tmp, "sparse"))
+out["sparse_tokens"] = [list(map(int, ids)) for ids in tok.decoded]
+args.is_sparse = 0
+
 # the mirror's generation functions against the reference's, on the same model / stand-in
 import generation.magnify                                   # (`generation.magnify` the attribute is the function: __init__ re-exports it)
 RM = sys.modules["generation.magnify"]

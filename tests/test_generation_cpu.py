@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from tests import cpu_ops
-from tests.generation_cases import ToyIds, run_generation_golden_case
+from tests.generation_cases import ToyIds, run_generation_golden_case, run_sparse_generation_golden_case
 
 
 @pytest.fixture()
@@ -30,6 +30,11 @@ def test_generation_loop_reproduces_the_reference_tokens_and_scores(cpu_kernels,
     memories (the reference's layer inputs, or this package's key/value caches), two beams expanded from one;
     inverse_prompt_score: one 1037-token forward, image codes excluded."""
     run_generation_golden_case(golden_dir, "cpu", kv_cache=kv_cache)
+
+
+def test_sparse_generation_reproduces_the_reference_tokens(cpu_kernels, golden_dir):
+    """is_sparse = 2: 64 image codes generated past a 32-position trailing window, pivots redrawn by every layer of every pass."""
+    run_sparse_generation_golden_case(golden_dir, "cpu")
 
 
 class _PositionalOracle:

@@ -6,7 +6,7 @@ the constructor under the golden's seed (the reference's bits, SURVEY 8a row G22
 import pytest
 import torch
 
-from tests.generation_cases import run_generation_golden_case
+from tests.generation_cases import run_generation_golden_case, run_sparse_generation_golden_case
 
 pytestmark = pytest.mark.gpu
 
@@ -16,3 +16,11 @@ def test_generation_reproduces_the_reference_tokens_and_scores(golden_dir, kv_ca
     assert torch.cuda.is_available(), "GPU tests need an MI355X; run with -m 'not gpu' elsewhere"
     out, scores = run_generation_golden_case(golden_dir, "cuda", kv_cache)
     print("generated:", out[0, -8:].tolist(), "scores:", [round(float(s), 4) for s in scores])
+
+
+def test_sparse_generation_reproduces_the_reference_tokens(golden_dir):
+    """is_sparse = 2 on the gathered attention kernel (cogv_attention_fwd with kv_index): the 64 image codes the reference's
+    sparse_attention_inference path generated, pivots drawn by `random.sample` under the same seed."""
+    assert torch.cuda.is_available(), "GPU tests need an MI355X; run with -m 'not gpu' elsewhere"
+    out = run_sparse_generation_golden_case(golden_dir, "cuda")
+    print("sparse generation:", out[0, -8:].tolist())

@@ -72,6 +72,10 @@ def test_reference_generation_drivers_run_over_the_mirrors_and_reproduce_the_ref
     assert out["sel_text"] == "two candidates"
     assert np.allclose(out["sel_scores"], gold["sel_scores"], rtol=0, atol=5e-3), (out["sel_scores"], gold["sel_scores"].tolist())
     assert out["sel_scores"][1] > out["sel_scores"][0]                        # the ranking post-selection exists for
+    # sparse generation (is_sparse = 2): 64 codes past the 32-position trailing window, pivots drawn with random.sample per layer
+    sp_want, sp_gaps = gold["sparse_out"], gold["sparse_gaps"]
+    assert len(out["sparse_tokens"]) == 1 and float(sp_gaps.min()) > 0.004
+    assert out["sparse_tokens"][0] == sp_want[0].tolist()
     # cogview_amd.generation's own inverse_prompt_score / magnify against the reference's functions: same model -> same scores;
     # a positional stand-in model -> the same 64 x 64 codes, token for token (window order, given lines, [ROI2] position offset)
     assert out["score_mirror_vs_reference_fn"] < 1e-4
