@@ -9,3 +9,4 @@ __version__ = "0.1.0"
 # mpu first: functional <-> mpu.transformer import each other, and this is the order that resolves (any sub-package can
 # then be the first thing a script imports)
 from . import mpu  # noqa: E402,F401
+from .bind import bind_reference_names  # noqa: E402,F401

@@ -37,15 +37,9 @@ torch.cuda.synchronize = lambda *a, **k: None
 import cpu_ops
 cpu_ops.install()
 
-# ---- INTEGRATION.md section 2, verbatim
-import cogview_amd.mpu, cogview_amd.model, cogview_amd.fp16, cogview_amd.vqvae, cogview_amd.optim
-sys.modules["mpu"] = cogview_amd.mpu
-sys.modules["model"] = cogview_amd.model
-sys.modules["fp16"] = cogview_amd.fp16
-sys.modules["vqvae"] = cogview_amd.vqvae
-apex = types.ModuleType("apex"); apex.optimizers = types.ModuleType("apex.optimizers")
-apex.optimizers.FusedAdam = cogview_amd.optim.FusedAdam
-sys.modules["apex"], sys.modules["apex.optimizers"] = apex, apex.optimizers
+# ---- INTEGRATION.md section 2, verbatim: one call binds mpu / model / fp16 / vqvae / apex.optimizers
+import cogview_amd
+cogview_amd.bind_reference_names()
 
 # ---- stand-ins for what is not installed / not on the path under test
 ds = types.ModuleType("deepspeed")

@@ -80,3 +80,37 @@ def test_reference_generation_drivers_run_over_the_mirrors_and_reproduce_the_ref
     # a positional stand-in model -> the same 64 x 64 codes, token for token (window order, given lines, [ROI2] position offset)
     assert out["score_mirror_vs_reference_fn"] < 1e-4
     assert out["magnify_equal"] and out["magnify_shape"] == [1, 4096]
+
+
+@needs_reference
+def test_checkpoints_cross_the_boundary_both_ways_through_the_reference_utils(tmp_path):
+    """utils.save_checkpoint / load_checkpoint of the reference, unedited (drive_checkpoint_interop.py, three processes):
+    reference-written weights load into the mirrors (--finetune form) and give the reference's logits; a file written over the
+    mirrors (weights + FP16_Optimizer state incl. the pickled loss scaler + AnnealingLR state) resumes the mirrors BIT-identically
+    (step 4 of a run = step 4 after save / fresh model / load) and loads into the reference's own fp32 model, which then gives
+    the mirrors' logits."""
+    import numpy as np
+
+    def run(mode):
+        r = subprocess.run([sys.executable, os.path.join(HERE, "ref_drivers", "drive_checkpoint_interop.py"), mode, str(tmp_path)],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+    def close(a, b, tol):
+        ra, rb = np.array(a["rows"]), np.array(b["rows"])
+        assert abs(a["norm"] - b["norm"]) < tol * b["norm"]
+        assert np.linalg.norm(ra - rb) < tol * np.linalg.norm(rb), np.linalg.norm(ra - rb) / np.linalg.norm(rb)
+
+    ref = run("ref_save")
+    mir = run("mirror")
+    back = run("ref_load")
+    close(mir["logits_after_loading_reference_file"], ref["logits"], 2e-3)          # fp16 mirrors vs the fp32 reference
+    assert mir["losses"][2] < mir["losses"][0] - 0.3                                  # the three steps trained
+    a, b = mir["step4_uninterrupted"], mir["step4_resumed"]
+    assert a == b and mir["weights_after_step4_equal"], (a, b, mir["weights_after_step4_maxdiff"])
+    assert a["adam_steps"] == 4 and a["lr_steps"] == 4
+    close(back["logits"], mir["logits_of_saved_model"], 2e-3)
+    # and the file itself names the reference's classes only: it opens without this package on the path
+    blob = open(os.path.join(str(tmp_path), "mirror", "3", "mp_rank_00_model_states.pt"), "rb").read()
+    assert b"cogview_amd" not in blob and b"loss_scaler" in blob
