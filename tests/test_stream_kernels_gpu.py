@@ -294,7 +294,8 @@ def test_fp32_gradients_take_the_same_kernels():
     assert all(dt == torch.float32 for dt, _ in calls) and sorted(n for _, n in calls[:3]) == [1, 1, 2], calls
     assert mpu.clip_grad_norm(params, 1e9, float("inf")) == pytest.approx(refinf, rel=1e-7)
     before = [p.grad.clone() for p in params]
-    mpu.clip_grad_norm(params, ref2 / 4)
+    now2 = sum(float((b0.double() ** 2).sum()) for b0 in before) ** 0.5          # two elements were edited above
+    assert mpu.clip_grad_norm(params, now2 / 4) == pytest.approx(now2, rel=1e-6)
     for p, b0 in zip(params, before):
         assert torch.allclose(p.grad, 0.25 * b0, rtol=1e-5, atol=0)
 
