@@ -9,6 +9,7 @@ mirrors' `mpu` / `model` / `fp16` cannot live in one interpreter); tests/test_re
              reference printed; three train_steps; utils.save_checkpoint -> <dir>/mirror (weights + FP16_Optimizer state +
              AnnealingLR state); a FRESH model / optimizer, utils.load_checkpoint(<dir>/mirror) -> the next train_step equals the
              uninterrupted run's; prints the trained model's logits for the fixed batch.
+             Also generate_samples.setup_model (:51-68) on the reference-written file, DeepSpeed-layout branch and plain branch.
   ref_load   REFERENCE stack: utils.load_checkpoint(<dir>/mirror) into its own fp32 GPT2Model -> same logits as the mirror
              printed: a file written over the mirrors is a reference checkpoint.
 
@@ -170,6 +171,19 @@ assert it == 3, it
 lm4b, skipped, *_ = P.train_step(batches(), model2, optimizer2, lr2, args, timers, [])
 out["step4_resumed"] = {"loss": float(lm4b.detach()), "lr_steps": lr2.num_iters, "adam_steps": optimizer2._step_count,
                         "scale": float(optimizer2.loss_scale)}
+# 4. generate_samples.setup_model (:51-68), both of its branches, on the reference-written file: the DeepSpeed-layout branch
+#    (:56-61: reads <load>/<iteration>/mp_rank_00_model_states.pt itself, checkpoint["module"]) and the plain one (load_checkpoint)
+tv, tvu = types.ModuleType("torchvision"), types.ModuleType("torchvision.utils")
+tvu.save_image = lambda *a, **k: None
+tv.utils = tvu
+sys.modules["torchvision"], sys.modules["torchvision.utils"] = tv, tvu
+import generate_samples as S
+assert os.path.realpath(S.__file__).startswith(REF + "/")
+for branch, ds_flag in (("deepspeed_layout", True), ("plain", False)):
+    torch.manual_seed(3)
+    m = S.setup_model(base_args(load=os.path.join(DIR, "ref"), deepspeed=ds_flag))
+    out["setup_model_" + branch] = logits_summary(eval_logits(m))
+
 w_a = torch.cat([p.detach().float().view(-1) for p in model.parameters()])
 w_b = torch.cat([p.detach().float().view(-1) for p in model2.parameters()])
 out["weights_after_step4_equal"] = bool(torch.equal(w_a, w_b))

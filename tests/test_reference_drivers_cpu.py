@@ -106,6 +106,8 @@ def test_checkpoints_cross_the_boundary_both_ways_through_the_reference_utils(tm
     mir = run("mirror")
     back = run("ref_load")
     close(mir["logits_after_loading_reference_file"], ref["logits"], 2e-3)          # fp16 mirrors vs the fp32 reference
+    close(mir["setup_model_deepspeed_layout"], ref["logits"], 2e-3)                   # generate_samples.setup_model, both branches
+    close(mir["setup_model_plain"], ref["logits"], 2e-3)
     assert mir["losses"][2] < mir["losses"][0] - 0.3                                  # the three steps trained
     a, b = mir["step4_uninterrupted"], mir["step4_resumed"]
     assert a == b and mir["weights_after_step4_equal"], (a, b, mir["weights_after_step4_maxdiff"])
