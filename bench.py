@@ -542,15 +542,17 @@ def main():
                                                                                "avg_launch_ms", "share_of_step_time")}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, h, heads, row=ROW_LEN.get(args.config, ROW))
-            # configs[0] is the one case the REFERENCE ITSELF runs on a CPU in seconds: its own forward + CE + backward timed
-            # beside the port where /root/reference exists (the build container: oracle/time_reference_cfg1.py), committed
-            # under profiles/ and quoted here -- kind "reference", measured THERE, next to the port measured HERE
-            rpath = latest_profile("cfg1_cpu_reference_vs_port.json")
-            if args.config == "cogview-tiny-18M" and rpath is not None:
+            # the REFERENCE ITSELF timed beside the port where /root/reference exists (the build container): configs[0] whole
+            # (oracle/time_reference_cfg1.py), the 4B headline on the same bounded sample as the port above
+            # (oracle/time_reference_4B_sample.py) -- committed under profiles/ and quoted here: kind "reference", measured
+            # THERE, next to the port measured HERE
+            rname = {"cogview-tiny-18M": "cfg1_cpu_reference_vs_port.json", "cogview-base-4B": "4B_cpu_reference_vs_port.json"}
+            rpath = latest_profile(rname[args.config]) if args.config in rname else None
+            if rpath is not None:
                 r = json.load(open(rpath))
                 out["cpu_baseline_reference"] = {
                     "value": r["reference"]["tokens_per_s"], "unit": "tokens/s", "cores": r["threads"], "kind": "reference",
-                    "sample": r["config"] + "; median of 5 iterations", "measured_where": r["where"] + ", not on this box",
+                    "sample": r["config"], "measured_where": r["where"] + ", not on this box",
                     "port_on_the_same_cores": r["port"]["tokens_per_s"], "source": os.path.relpath(rpath, ROOT)}
     if rank == 0:
         print(json.dumps(out), file=json_out, flush=True)

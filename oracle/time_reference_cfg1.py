@@ -55,7 +55,7 @@ def main():
         loss.backward()
         return loss.item()
 
-    out = {"config": "BASELINE configs[0]: 4L/256h/4 heads, vocab 58240, 4 rows of 256 tokens (s = 255), fp32, forward + CE + backward",
+    out = {"config": "BASELINE configs[0]: 4L/256h/4 heads, vocab 58240, 4 rows of 256 tokens (s = 255), fp32, forward + CE + backward; median of 5 iterations",
            "where": "build container (no GPU)", "threads": torch.get_num_threads(), "tokens_per_iteration": c["rows"] * s}
     for name, fn in (("reference", ref_iter), ("port", port_iter)):
         loss = fn()
