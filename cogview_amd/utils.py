@@ -10,8 +10,10 @@ cogview-base weights -- a DeepSpeed checkpoint, generate_samples.py:56-61 -- loa
 cogview_amd.model.GPT2Model keeps the reference's parameter names and layouts (fused QKV rows [q; k; v] per partition,
 mpu/layers.py:64-71).  Host-side logic only; the DeepSpeed *engine* paths (args.deepspeed) are not reproduced.
 """
+import contextlib
 import os
 import random
+import sys
 
 import numpy as np
 import torch
@@ -135,6 +137,24 @@ def extend_position_embedding(weight, length):
     return weight.expand(length // ori_length, -1, -1).reshape(length, hidden_size)
 
 
+@contextlib.contextmanager
+def reference_class_names():
+    """While a checkpoint is unpickled: `fp16.loss_scaler.{LossScaler, DynamicLossScaler}` -- the path under which the reference
+    (and this package once cogview_amd.bind_reference_names() has run) pickles the scaler object inside FP16_Optimizer's state
+    (fp16/fp16.py:336-360) -- resolves to the mirror's classes even in a process that has not bound the reference's names."""
+    from . import fp16 as _fp16
+    added = []
+    for name, mod in (("fp16", _fp16), ("fp16.loss_scaler", _fp16.loss_scaler)):
+        if name not in sys.modules:
+            sys.modules[name] = mod
+            added.append(name)
+    try:
+        yield
+    finally:
+        for name in added:
+            sys.modules.pop(name, None)
+
+
 def load_checkpoint(model, optimizer, lr_scheduler, args, load_optimizer_states=True):
     """utils.py:290-380 (the non-DeepSpeed branch; it also reads the model-states file a DeepSpeed run wrote).
     Returns the iteration to resume from (0 for --finetune / release checkpoints or when there is none)."""
@@ -144,7 +164,8 @@ def load_checkpoint(model, optimizer, lr_scheduler, args, load_optimizer_states=
     name = get_checkpoint_name(args.load, iteration, release)
     if _dp_rank() == 0:
         print('global rank {} is loading checkpoint {}'.format(_global_rank(), name))
-    sd = torch.load(name, map_location='cpu', weights_only=False)
+    with reference_class_names():
+        sd = torch.load(name, map_location='cpu', weights_only=False)
     model = _unwrap(model)
     if 'module' not in sd:
         raise KeyError('a metadata file exists but {} holds no model ("module")'.format(name))

@@ -660,3 +660,33 @@ def test_weight_gradient_queue_launches_whole_rounds_and_covers_every_tile_row(m
         rounds += math.ceil(t / 256)
     assert all(e[0] == e[1] for e in ent) and sum(sizes) == 48 * 1200 + 2280
     assert rounds == 234 and 48 * 5 + 9 == 249
+
+
+def test_checkpoint_with_a_reference_path_loss_scaler_unpickles_without_binding(tmp_path):
+    """FP16_Optimizer's state carries the loss-scaler OBJECT (fp16/fp16.py:336-360); the reference -- and this package after
+    cogview_amd.bind_reference_names() -- pickles it as `fp16.loss_scaler.DynamicLossScaler`.  utils.load_checkpoint opens such a
+    file in a process that has bound nothing (utils.reference_class_names), and leaves sys.modules as it found it."""
+    import sys
+    from cogview_amd import utils
+    from cogview_amd.fp16 import loss_scaler as LS
+    assert "fp16" not in sys.modules and "fp16.loss_scaler" not in sys.modules
+    scaler = LS.DynamicLossScaler(init_scale=2 ** 14, scale_window=7, delayed_shift=2)
+    scaler.cur_iter, scaler.last_overflow_iter = 11, 9
+    path = str(tmp_path / "state.pt")
+    saved_module = LS.DynamicLossScaler.__module__
+    try:                                                   # what bind_reference_names() arranges, for the length of the save
+        LS.DynamicLossScaler.__module__ = "fp16.loss_scaler"
+        sys.modules["fp16"], sys.modules["fp16.loss_scaler"] = sys.modules["cogview_amd.fp16"], LS
+        torch.save({"optimizer": {"loss_scaler": scaler}}, path)
+    finally:
+        LS.DynamicLossScaler.__module__ = saved_module
+        del sys.modules["fp16"], sys.modules["fp16.loss_scaler"]
+    blob = open(path, "rb").read()
+    assert b"fp16.loss_scaler" in blob and b"cogview_amd" not in blob
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu", weights_only=False)          # an unbound process cannot resolve the name ...
+    with utils.reference_class_names():                                    # ... except under the loader's context
+        sd = torch.load(path, map_location="cpu", weights_only=False)
+    got = sd["optimizer"]["loss_scaler"]
+    assert type(got) is LS.DynamicLossScaler and got.__dict__ == scaler.__dict__
+    assert "fp16" not in sys.modules and "fp16.loss_scaler" not in sys.modules
