@@ -189,3 +189,15 @@ def test_generic_optimizer_path_warns_and_follows_the_reference_step(cpu_kernels
     from tests.optimizer_cases import run_generic_path_case
     monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
     run_generic_path_case(dtype, "cpu")
+
+
+def test_cpu_emulation_keeps_the_signatures_of_the_entry_points_it_replaces():
+    """tests/cpu_ops.py stands in for cogview_amd.ops in every CPU test of the host path: each stand-in must accept exactly the
+    parameters (names, order, defaults) of the entry point it replaces, or those tests would exercise calls the product never makes."""
+    import inspect
+    from cogview_amd import ops
+    for name in cpu_ops.NAMES:
+        real, fake = inspect.signature(getattr(ops, name)), inspect.signature(getattr(cpu_ops, name))
+        want = [(p.name, p.default, p.kind) for p in real.parameters.values()]
+        got = [(p.name, p.default, p.kind) for p in fake.parameters.values()]
+        assert got == want, (name, got, want)
