@@ -1,7 +1,8 @@
-"""CPU, two processes over gloo, the WHOLE train step on the CPU-emulated ops (tests/cpu_ops.py): what the N > 1 legs of
+"""CPU, two (and four) processes over gloo, the WHOLE train step on the CPU-emulated ops (tests/cpu_ops.py): what the N > 1 legs of
 `bench.py` run -- data parallel with the bucketed exchange issued as each layer's backward finishes (the weight-gradient queue
 releases a layer's bucket one launch late), the sharded form (reduce-scatter, owned-slice AdamW, all-gather), and two-way
-tensor parallel (column / row parallel linears, head-sharded attention, vocab-parallel embedding / logits / cross entropy).
+tensor parallel (column / row parallel linears, head-sharded attention, vocab-parallel embedding / logits / cross entropy),
+and model parallel 2 x data parallel 2 on four ranks.
 The GPU versions of the same three checks are tests/test_model_gpu.py::test_two_rank_* / test_two_way_tensor_parallel_on_one_gpu;
 these run where the CPU suite runs.
 
@@ -263,6 +264,72 @@ def w_tp2(rank, world):
     return {"logits": logits.detach().float(), "loss": float(loss.detach()),
             "params": {n: p.detach().float() for n, p in model.module.named_parameters()},
             "grads": {n: p.grad.detach().float() / 256.0 for n, p in model.module.named_parameters()}}
+
+
+def w_mp2_dp2(rank, world):
+    """Four ranks: two model-parallel groups (ranks {0,1}, {2,3}) that are data-parallel replicas of each other (groups {0,2},
+    {1,3}; mpu/initialize.py:49-75).  Each replica takes one of the two rows; the gradients are exchanged over the data-parallel
+    groups during backward."""
+    from cogview_amd import mpu, training
+    from cogview_amd.fp16 import FP16_Module
+    from cogview_amd.model import GPT2Model, PyTorchDistributedDataParallel
+    mpu.initialize_model_parallel(2)
+    assert mpu.get_model_parallel_rank() == rank % 2 and mpu.get_data_parallel_rank() == rank // 2
+    c = _TP
+    torch.manual_seed(4321)
+    mpu.model_parallel_cuda_manual_seed(4321)
+    m = GPT2Model(c["L"], c["V"], c["H"], c["NH"], 0.0, 0.0, 0.0, c["S"] + 1, 0, False)
+    model = FP16_Module(m, dtype=torch.float16, keep_half_outputs=True)
+    ddp = PyTorchDistributedDataParallel(model, process_group=mpu.get_data_parallel_group(), bucket_layers=1)
+    assert ddp.world == 2 and ddp.overlap
+    opt = _optimizer(model)
+    opt.attach_data_parallel(ddp)
+    g = torch.Generator().manual_seed(11)
+    tokens = torch.randint(0, c["V"], (c["B"], c["S"]), generator=g)
+    labels = torch.randint(0, c["V"], (c["B"], c["S"]), generator=g)
+    d = mpu.get_data_parallel_rank()
+    pos = torch.arange(c["S"]).unsqueeze(0)
+    batch = (tokens[d:d + 1], labels[d:d + 1], torch.ones(1, c["S"]), 0, pos)
+    loss, _, _, _ = training.forward_step(batch, ddp, log=False, world_size=2)
+    training.backward_step(opt, ddp, loss, 1.0)
+    grads = {n: p.grad.detach().float() / opt.loss_scale for n, p in model.module.named_parameters()}
+    opt.step()
+    assert not opt.overflow
+    flat = model.module._cogv_arena.data.detach().float()
+    parts = [torch.empty_like(flat) for _ in range(2)]
+    dist.all_gather(parts, flat, group=mpu.get_data_parallel_group())
+    assert torch.equal(parts[0], parts[1]), "data-parallel replicas of a model shard diverged"
+    return {"grads": grads, "mp_rank": mpu.get_model_parallel_rank(), "loss": float(loss.detach())}
+
+
+def test_model_parallel_2_x_data_parallel_2_train_step(monkeypatch):
+    """BASELINE configs[2] x configs[3] in miniature (world 4): every rank's averaged gradients equal the matching slice of the
+    one-rank model's gradients on the whole batch; the data-parallel replicas of each shard end bit-identical."""
+    out = _run("w_mp2_dp2", world=4)
+    from tests import cpu_ops
+    cpu_ops.install(monkeypatch.setattr)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0)
+    from cogview_amd import mpu
+    if not mpu.model_parallel_is_initialized():
+        mpu.initialize_model_parallel(1)
+    model, logits, loss = _tp_build_and_run()                 # one rank, both rows, loss = mean over all tokens
+    full_g = {n: p.grad.detach().float() / 256.0 for n, p in model.module.named_parameters()}
+    assert abs(0.5 * (out[0]["loss"] + out[2]["loss"]) - float(loss.detach())) < 2e-3 * float(loss.detach())
+    worst = 0.0
+    for r in range(4):
+        for n, gfull in full_g.items():
+            gs = _tp_slice(n, gfull, out[r]["mp_rank"], 2)
+            want = gfull if gs is None else gs
+            e = rel(out[r]["grads"][n], want)
+            worst = max(worst, e)
+            assert e < 2e-2, (n, r, e)
+    print(f"mp 2 x dp 2 on the CPU emulation: worst gradient rel-L2 {worst:.2e}")
 
 
 def test_two_way_tensor_parallel_forward_backward(monkeypatch):
