@@ -13,6 +13,7 @@ in one flat arena (cogview_amd/arena.py) `param.grad` is a view of one flat grad
 data-parallel all-reduce, the overflow check, the norm and the Adam step are each ONE kernel / collective over
 that buffer (the reference does each per tensor: 388 tensors for the 24-layer model, 772 for 48 layers).
 """
+import contextlib
 import math
 
 import torch
@@ -705,8 +706,9 @@ class _DeferredWeightGrads:
     cut along tile rows of dW (a column slice of dY, a row slice of dW: plain pointer offsets, every tile is computed by the same
     kernel in the same order -> bit-identical results).  The tied-logits gradient (functional._Logits.backward) joins the queue
     first and fills the 80 free tile slots of the first 29 layer launches (a layer's own problems are taken before it); after that
-    the launches alternate between 5 and 4 full rounds, a layer's last tile rows riding in the next layer's launch.  234 rounds instead of 249 at 4B: -9.5 ms per step.  The flush of layer index 0 (the last one backward visits),
-    the embedding's backward and the end of the autograd pass launch whatever is left.
+    the launches alternate between 5 and 4 full rounds, a layer's last tile rows riding in the next layer's launch.  234 rounds
+    instead of 249 at 4B: -9.5 ms per step.  The flush of layer index 0 (the last one backward visits), the embedding's backward
+    and the end of the autograd pass launch whatever is left.
     The data-parallel callback of a layer runs once all of ITS problems have been launched, in backward order.
     COGV_WGRAD_QUEUE=0: every flush launches everything it has (the round-4 behaviour).
 
@@ -714,10 +716,12 @@ class _DeferredWeightGrads:
     1.3 % tail) ran at 1267 TFLOP/s -- a 13 ms uninterrupted GEMM sits at the sustained power limit, while 3 ms launches
     separated by the lighter LN / attention kernels clock higher.  Hence one layer per flush whenever a layer fills the chip
     (wgrad_group_layers; COGV_WGRAD_GROUP_LAYERS overrides it for experiments)."""
-    __slots__ = ("entries", "callbacks", "new_tiles", "hooked")
+    __slots__ = ("entries", "callbacks", "new_tiles", "root", "hooked")
 
     def __init__(self):
-        self.entries, self.callbacks, self.new_tiles, self.hooked = [], [], 0, -1      # hooked: graph-task id whose end is hooked
+        # root: graph-task id of the (outermost) backward pass the pending problems belong to; hooked: ids of the passes -- that
+        # one and the passes nested in it (mpu.checkpoint's recompute) -- whose end already carries the flush callback
+        self.entries, self.callbacks, self.new_tiles, self.root, self.hooked = [], [], 0, -1, set()
 
     def add(self, dy, x, w, owner=None):
         e = _WgradEntry(dy, x, w, owner)
@@ -816,17 +820,38 @@ def _flush_at_end_of_backward():
     flush_weight_grads(final=True)
 
 
+# graph-task ids of the backward passes that are, right now, running a NESTED backward pass on this thread (mpu.checkpoint's
+# recompute: CheckpointFunction.backward calls torch.autograd.backward inside the outer pass).  The problems a nested pass defers
+# belong to the outermost pass: its queue must survive them.
+_NESTED_OUTER = []
+
+
+@contextlib.contextmanager
+def nested_backward():
+    """Around a torch.autograd.backward() issued from inside a backward pass (mpu/random.py CheckpointFunction.backward)."""
+    _NESTED_OUTER.append(torch._C._current_graph_task_id())
+    try:
+        yield
+    finally:
+        _NESTED_OUTER.pop()
+
+
 def defer_weight_grad(dy, x, w, owner=None):
     """Queue dW (+)= dY^T X for the next grouped launches.  Called inside an autograd backward pass: a callback at the end of
     that pass launches whatever no layer flush has taken (nothing in a GPT2Model step: layer index 0 flushes everything)."""
     q = _WGRADS
     task = torch._C._current_graph_task_id()      # the autograd pass this call belongs to (-1: none)
-    if task >= 0 and q.hooked != task:
-        # the first problem of a new backward pass: hook its end, and drop whatever a pass that died half way (an exception
-        # between two flushes: the engine runs no final callbacks then) left behind -- stale tensors, gradients nobody consumed
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end_of_backward)
+    root = _NESTED_OUTER[0] if _NESTED_OUTER else task
+    if root >= 0 and q.root != root:
+        # the first problem of a new backward pass: drop whatever a pass that died half way (an exception between two flushes:
+        # the engine runs no final callbacks then) left behind -- stale tensors, gradients nobody consumed.  A pass NESTED in the
+        # current one is not a new pass: round 5's first form compared the nested pass' own id and threw the outer pass'
+        # pending problems away (the tied-logits gradient under mpu.checkpoint'ed layers)
         q.entries, q.callbacks, q.new_tiles = [], [], 0
-        q.hooked = task
+        q.root, q.hooked = root, set()
+    if task >= 0 and task not in q.hooked:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end_of_backward)      # at the end of THIS pass
+        q.hooked.add(task)
     q.add(dy, x, w, owner)                        # (outside a backward pass -- a test driving _layer_backward by hand -- the caller flushes)
 
 

@@ -214,7 +214,9 @@ class CheckpointFunction(torch.autograd.Function):
         if isinstance(outputs, torch.Tensor):
             outputs = (outputs,)
         pairs = [(o, g) for o, g in zip(outputs, grads) if isinstance(o, torch.Tensor) and o.requires_grad]
-        torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+        from .. import functional as F_                       # (functional imports mpu: resolved at call time)
+        with F_.nested_backward():                            # deferred weight gradients of the recomputed layers join the outer pass' queue
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
         return (None,) + tuple(inp.grad if isinstance(inp, torch.Tensor) else None for inp in detached)
 
 

@@ -201,3 +201,13 @@ def test_cpu_emulation_keeps_the_signatures_of_the_entry_points_it_replaces():
         want = [(p.name, p.default, p.kind) for p in real.parameters.values()]
         got = [(p.name, p.default, p.kind) for p in fake.parameters.values()]
         assert got == want, (name, got, want)
+
+
+def test_layers_under_mpu_checkpoint_keep_the_outer_pass_weight_gradients(cpu_kernels):
+    """mpu.checkpoint (mpu/random.py:273-372) around stand-alone layers, as the reference's GPT2Transformer uses it: the recompute
+    runs a NESTED backward pass inside the outer one.  The weight gradients the nested pass defers join the outer pass' queue --
+    the first form of the round-5 queue took the nested pass for a new one and dropped what the outer pass had queued (the
+    tied-logits gradient: the word-embedding gradient lost its larger half).  Bit-identical gradients with and without
+    checkpointing (the emulated kernels are deterministic)."""
+    from tests.queue_cases import run_layers_under_checkpoint_case
+    run_layers_under_checkpoint_case("cpu")

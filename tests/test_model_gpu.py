@@ -1071,3 +1071,11 @@ def test_weight_gradient_queue_is_bit_identical_to_one_launch_per_layer(monkeypa
         for n in grads[False][rep]:
             assert torch.equal(grads[True][rep][n], grads[False][rep][n]), (rep, n)
         assert all(bool(torch.isfinite(t).all()) for t in grads[True][rep].values())
+
+
+def test_layers_under_mpu_checkpoint_keep_the_outer_pass_weight_gradients():
+    """mpu.checkpoint around stand-alone layers runs a nested backward pass inside the outer one: the weight gradients it defers
+    join the outer pass' queue (the first round-5 form dropped the outer pass' pending tied-logits gradient).  Bit-identical
+    gradients with and without checkpointing; the CPU twin of this test runs on the emulated ops."""
+    from tests.queue_cases import run_layers_under_checkpoint_case
+    run_layers_under_checkpoint_case("cuda")
