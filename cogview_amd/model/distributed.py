@@ -193,6 +193,9 @@ class DistributedDataParallel(Module):
             if fp32_allreduce:
                 g.copy_(buf)
 
+    # PyTorchDistributedDataParallel: the exchange finishes by itself at the end of the backward pass, as torch's DDP does
+    auto_sync = False
+
     def forward(self, *inputs, **kwargs):
         self.needs_reduction = True
         self._layers_done = 0
@@ -202,8 +205,30 @@ class DistributedDataParallel(Module):
             self.shard.wait_upto(first if self._transformer() is not None else self.arena.total)
             out = self.module(*inputs, **kwargs)
             self.shard.wait_upto(self.arena.total)
-            return out
-        return self.module(*inputs, **kwargs)
+        else:
+            out = self.module(*inputs, **kwargs)
+        if self.auto_sync and torch.is_grad_enabled() and (self.world > 1 or self.force):
+            self._arm_end_of_backward(out)
+        return out
+
+    def _arm_end_of_backward(self, out):
+        """A hook on the first output that carries a gradient: when the backward pass reaches it (its very beginning), the end of
+        that pass is given the callback that finishes the gradient exchange."""
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        first = next((t for t in outs if isinstance(t, torch.Tensor) and t.requires_grad), None)
+        if first is None:
+            return
+
+        def on_backward_start(grad):
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+            return grad
+
+        first.register_hook(on_backward_start)
+
+    def _end_of_backward(self):
+        from .. import functional as F_
+        F_.flush_weight_grads(final=True)            # no weight gradient may still be queued when its region is exchanged
+        self.allreduce_params(reduce_after=False)    # a no-op if the caller has already finished the exchange itself
 
     def state_dict(self, destination=None, prefix='', keep_vars=False):
         if self.shard is not None:
@@ -340,9 +365,13 @@ class ShardPlan:
 
 
 class PyTorchDistributedDataParallel(DistributedDataParallel):
-    """Same engine; with this class the exchange is finished automatically at the end of backward by
-    `finish_gradient_sync()` (called by FP16_Optimizer.update_master_grads / the training step), mirroring
-    torch-DDP's implicit synchronisation in the reference's default (USE_TORCH_DDP) configuration."""
+    """Same engine; with this class the exchange FINISHES BY ITSELF at the end of every backward pass that reaches the module's
+    output (a callback queued on the autograd engine), mirroring torch-DDP's implicit synchronisation in the reference's default
+    configuration: with USE_TORCH_DDP = True pretrain_gpt2.backward_step (:344-391) never calls allreduce_params.  (Until round 5
+    only this package's own training.backward_step / an attached FP16_Optimizer finished it -- the reference's train_step on two
+    ranks left the embeddings' gradients unreduced and the replicas diverged; tests/ref_drivers/drive_pretrain_gpt2_dp2.py.)
+    Callers that do finish it themselves (training.backward_step, FP16_Optimizer.attach_data_parallel) find nothing left to do."""
+    auto_sync = True
 
     def finish_gradient_sync(self):
         self.allreduce_params(reduce_after=False)

@@ -1,0 +1,122 @@
+"""The REFERENCE's train_step (pretrain_gpt2.py:406-448 -> forward_step, backward_step :344-391), unedited, over the mirrors
+with TWO data-parallel ranks (gloo; one process per rank, started by tests/test_reference_drivers_cpu.py with RANK = 0 / 1).
+
+The reference runs with USE_TORCH_DDP = True (pretrain_gpt2.py:19): its backward_step does NOT call model.allreduce_params --
+torch's DistributedDataParallel finishes the gradient exchange by itself at the end of backward.  The mirror's
+PyTorchDistributedDataParallel must therefore do the same: each rank trains on its own rows, and after every step the replicas
+must hold the same bits; the averaged gradient must be the one-rank gradient of all rows.
+
+Scaffolding as in drive_pretrain_gpt2.py, plus inert stand-ins for torch.cuda's stream / event objects (the mirror issues the
+exchange on a side stream on a GPU; on the CPU every collective completes in program order)."""
+import contextlib
+import json
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+RANK, WORLD, PORT = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.append(REF)
+
+import numpy as np
+import torch
+
+
+class _Inert:
+    def __init__(self, *a, **k):
+        pass
+
+    def wait_stream(self, s):
+        pass
+
+    def wait_event(self, e):
+        pass
+
+    def record(self, s=None):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+torch.Tensor.is_cuda = property(lambda self: True)
+torch.nn.Module.cuda = lambda self, device=None: self
+torch.cuda.current_device = lambda: 0
+torch.cuda.synchronize = lambda *a, **k: None
+torch.cuda.Stream = _Inert
+torch.cuda.Event = _Inert
+torch.cuda.current_stream = lambda *a, **k: _Inert()
+torch.cuda.stream = lambda s: contextlib.nullcontext()
+import cpu_ops
+cpu_ops.install()
+
+import cogview_amd
+cogview_amd.bind_reference_names()
+ds = types.ModuleType("deepspeed")
+ds.add_config_arguments = lambda parser: parser
+sys.modules["deepspeed"] = ds
+tbx = types.ModuleType("tensorboardX")
+tbx.SummaryWriter = type("SummaryWriter", (), {"__init__": lambda self, *a, **k: None, "add_scalar": lambda self, *a, **k: None})
+sys.modules["tensorboardX"] = tbx
+du = types.ModuleType("data_utils")
+_tok = types.SimpleNamespace(img_tokenizer=types.SimpleNamespace(num_tokens=8192))
+du.get_tokenizer = lambda args=None: _tok
+du.make_loaders = du.detect_new_datasets = lambda *a, **k: None
+sys.modules["data_utils"] = du
+
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % PORT, world_size=WORLD, rank=RANK)
+import mpu
+mpu.initialize_model_parallel(1)
+import pretrain_gpt2 as P
+from utils import Timers
+assert os.path.realpath(P.__file__).startswith(REF + "/") and P.USE_TORCH_DDP is True
+
+gold = np.load(os.path.join(ROOT, "tests", "golden", "gpt2_cfg1.npz"))
+rows = torch.from_numpy(gold["rows"])                       # 4 rows of 256 tokens: two per rank
+mine = rows[RANK * 2:(RANK + 1) * 2]
+args = types.SimpleNamespace(
+    num_layers=4, vocab_size=58240, hidden_size=256, num_attention_heads=4, hidden_dropout=0.0, attention_dropout=0.0,
+    max_position_embeddings=256, max_position_embeddings_finetune=256, max_memory_length=0, checkpoint_activations=False,
+    checkpoint_num_layers=1, query_window=128, key_window_times=6, num_pivot=768, deepspeed=False, fp16=True,
+    cpu_optimizer=False, cpu_torch_adam=False, lr=1.5e-4, weight_decay=0.01, loss_scale=None, dynamic_loss_scale=True,
+    loss_scale_window=1000, min_scale=1, hysteresis=2, lr_decay_iters=None, train_iters=100, warmup=0.0,
+    lr_decay_style="linear", lr_decay_ratio=0.1, train_data=["synthetic"], finetune=False, is_sparse=0, txt_loss_scale=1.0,
+    world_size=WORLD, clip_grad=1.0, fp32_allreduce=False, iteration=0)
+
+torch.manual_seed(1234)
+mpu.model_parallel_cuda_manual_seed(1234)
+torch.manual_seed(1234)
+model, optimizer, lr_scheduler = P.setup_model_and_optimizer(args)
+assert isinstance(model, P.DDP) and model.world == WORLD
+optimizer.loss_scaler.cur_scale = 2.0 ** 12
+
+
+def batches():
+    while True:
+        yield {"text": mine.clone(), "loss_mask": torch.ones_like(mine)}
+
+
+def all_equal(t):
+    parts = [torch.empty_like(t) for _ in range(WORLD)]
+    dist.all_gather(parts, t.contiguous())
+    return all(torch.equal(parts[0], p) for p in parts[1:])
+
+
+it, timers, out = batches(), Timers(), {"rank": RANK}
+arena = model.module.module._cogv_arena
+lm, skipped, *_ = P.train_step(it, model, optimizer, lr_scheduler, args, timers, [])
+out["step1"] = {"loss_reduced": float(lm.detach()), "skipped": int(skipped),
+                "grads_equal_across_ranks": all_equal(arena.grad.detach().float()),
+                "grad_norm": (optimizer._host_stats[0] ** 0.5) / (2.0 ** 12),
+                "params_equal_across_ranks": all_equal(arena.data.detach().float())}
+lm, skipped, *_ = P.train_step(it, model, optimizer, lr_scheduler, args, timers, [])
+out["step2"] = {"loss_reduced": float(lm.detach()), "skipped": int(skipped),
+                "params_equal_across_ranks": all_equal(arena.data.detach().float())}
+out["golden"] = {"loss": float(gold["loss"]), "grad_norm": float(gold["grad_norm"])}
+print("RESULT " + json.dumps(out), flush=True)
+dist.barrier()
+dist.destroy_process_group()

@@ -116,3 +116,34 @@ def test_checkpoints_cross_the_boundary_both_ways_through_the_reference_utils(tm
     # and the file itself names the reference's classes only: it opens without this package on the path
     blob = open(os.path.join(str(tmp_path), "mirror", "3", "mp_rank_00_model_states.pt"), "rb").read()
     assert b"cogview_amd" not in blob and b"loss_scaler" in blob
+
+
+@needs_reference
+def test_reference_train_step_on_two_data_parallel_ranks_keeps_the_replicas_identical():
+    """pretrain_gpt2.train_step, unedited, on two data-parallel ranks over the mirrors (two processes, gloo; two of the four
+    golden rows each).  The reference runs with USE_TORCH_DDP = True: its backward_step never calls allreduce_params, so the
+    mirror's PyTorchDistributedDataParallel has to finish the exchange by itself at the end of backward.  After the first step
+    the ranks hold the same gradients -- the mean over all four rows: the golden's global gradient norm -- and after every step
+    the same parameters; the loss the script all-reduces is the golden's."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = os.path.join(HERE, "ref_drivers", "drive_pretrain_gpt2_dp2.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, so[-2000:] + "\n" + se[-3000:]
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    gold = outs[0]["golden"]
+    for o in outs:
+        s1, s2 = o["step1"], o["step2"]
+        assert s1["skipped"] == 0 and s2["skipped"] == 0
+        assert s1["grads_equal_across_ranks"] and s1["params_equal_across_ranks"] and s2["params_equal_across_ranks"]
+        assert abs(s1["loss_reduced"] - gold["loss"]) < 2e-3 * gold["loss"]
+        assert abs(s1["grad_norm"] - gold["grad_norm"]) < 5e-3 * gold["grad_norm"]
+        assert s2["loss_reduced"] < s1["loss_reduced"] - 0.05
+    assert outs[0]["step1"] == outs[1]["step1"] and outs[0]["step2"] == outs[1]["step2"]
