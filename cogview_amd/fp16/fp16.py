@@ -158,6 +158,14 @@ class FP16_Optimizer(object):
         self.first_closure_call_this_step = True
         self.clip_grad_norm = clip_grad_norm
         self._clip, self._stats_valid, self._ddp, self._shard = 0.0, False, None, None
+        # A data-parallel wrapper constructed the way the reference constructs torch's DDP (pretrain_gpt2.py:100-103) has
+        # announced itself on the arena: the reference never introduces the optimizer to it (torch's DDP needs no introduction),
+        # so it is attached here -- update_master_grads() then finishes the gradient exchange, in the calling thread, exactly
+        # as after an explicit attach_data_parallel()
+        wrapper = getattr(arena, 'data_parallel_wrapper', None) if fused else None
+        wrapper = wrapper() if wrapper is not None else None
+        if wrapper is not None and wrapper.auto_sync:
+            self.attach_data_parallel(wrapper)
 
     # ---------------------------------------------------------------------------------------------- misc
     def maybe_print(self, msg):
@@ -169,6 +177,7 @@ class FP16_Optimizer(object):
         (DistributedDataParallel(shard_optimizer=True)) the statistics and AdamW passes are restricted to this rank's
         slices of the flat buffers and step() all-gathers the updated parameters."""
         self._ddp = ddp
+        ddp._sync_consumer = True            # this optimizer finishes the exchange: the wrapper need not (model/distributed.py)
         shard = getattr(ddp, 'shard', None)
         if shard is not None:
             assert self._arena is not None and self._arena is ddp.arena, "sharding needs the fused flat optimizer path"

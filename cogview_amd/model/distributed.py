@@ -12,6 +12,8 @@ buckets in the reference's default configuration -- without autograd hooks or bu
         reference: broadcast parameters at construction, explicit .allreduce_params(reduce_after, no_scale,
         fp32_allreduce) and .needs_reduction (model/distributed.py:35-76)
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 from torch.nn.modules import Module
@@ -42,6 +44,14 @@ class DistributedDataParallel(Module):
                 for p in params:
                     dist.broadcast(p.data, src, group=self.data_parallel_group)
         self.needs_reduction = False
+        # torch-DDP's contract -- the exchange finishes by itself at the end of backward -- for a wrapper constructed the way the
+        # reference constructs torch's DDP (pretrain_gpt2.py:100-103: device_ids=[i], output_device=i); see
+        # PyTorchDistributedDataParallel.  A native construction (this package's training step, bench.py, the tests) finishes
+        # the exchange itself, at a point of its choosing, and the end of its backward pass is left alone.
+        self.auto_sync = bool(type(self).auto_sync_when_constructed_like_torch_ddp and device_ids is not None)
+        self._sync_consumer = False          # an FP16_Optimizer that finishes the exchange in update_master_grads() (attach_data_parallel)
+        if self.auto_sync and self.arena is not None:
+            self.arena.data_parallel_wrapper = weakref.ref(self)      # FP16_Optimizer.__init__ attaches itself to it
         # force_collectives: run the full bucketed / overlapped exchange even in a group of one rank (single-GPU
         # test of the RCCL plumbing; a one-rank mean all-reduce is the identity)
         self.force = bool(force_collectives)
@@ -193,8 +203,7 @@ class DistributedDataParallel(Module):
             if fp32_allreduce:
                 g.copy_(buf)
 
-    # PyTorchDistributedDataParallel: the exchange finishes by itself at the end of the backward pass, as torch's DDP does
-    auto_sync = False
+    auto_sync_when_constructed_like_torch_ddp = False       # PyTorchDistributedDataParallel: True
 
     def forward(self, *inputs, **kwargs):
         self.needs_reduction = True
@@ -207,8 +216,8 @@ class DistributedDataParallel(Module):
             self.shard.wait_upto(self.arena.total)
         else:
             out = self.module(*inputs, **kwargs)
-        if self.auto_sync and torch.is_grad_enabled() and (self.world > 1 or self.force):
-            self._arm_end_of_backward(out)
+        if self.auto_sync and not self._sync_consumer and torch.is_grad_enabled() and (self.world > 1 or self.force):
+            self._arm_end_of_backward(out)   # nobody downstream will finish the exchange (fp32 training: plain loss.backward())
         return out
 
     def _arm_end_of_backward(self, out):
@@ -365,13 +374,21 @@ class ShardPlan:
 
 
 class PyTorchDistributedDataParallel(DistributedDataParallel):
-    """Same engine; with this class the exchange FINISHES BY ITSELF at the end of every backward pass that reaches the module's
-    output (a callback queued on the autograd engine), mirroring torch-DDP's implicit synchronisation in the reference's default
-    configuration: with USE_TORCH_DDP = True pretrain_gpt2.backward_step (:344-391) never calls allreduce_params.  (Until round 5
-    only this package's own training.backward_step / an attached FP16_Optimizer finished it -- the reference's train_step on two
-    ranks left the embeddings' gradients unreduced and the replicas diverged; tests/ref_drivers/drive_pretrain_gpt2_dp2.py.)
-    Callers that do finish it themselves (training.backward_step, FP16_Optimizer.attach_data_parallel) find nothing left to do."""
-    auto_sync = True
+    """Same engine.  Constructed the way the reference constructs torch's DistributedDataParallel -- `DDP(model, device_ids=[i],
+    output_device=i, process_group=...)`, pretrain_gpt2.py:100-103 -- the wrapper takes over torch-DDP's contract: the gradient
+    exchange finishes WITHOUT anybody calling allreduce_params (with USE_TORCH_DDP = True pretrain_gpt2.backward_step :344-391
+    never does).  Two mechanisms:
+      * an FP16_Optimizer built afterwards on the same flat arena attaches itself (fp16.py), and its update_master_grads() --
+        which backward_step calls right after backward -- finishes the exchange in the calling thread: the same code path as
+        training.backward_step / attach_data_parallel(), which the two-process GPU tests exercise;
+      * without such an optimizer (fp32 training: plain loss.backward()) a callback queued on the autograd engine finishes it
+        at the end of every backward pass that reaches the module's output.
+    Until round 5 only this package's own training.backward_step or an explicitly attached optimizer finished the exchange: the
+    reference's train_step on two ranks left the embeddings' gradients unreduced and the replicas diverged
+    (tests/ref_drivers/drive_pretrain_gpt2_dp2.py: two gloo ranks on the CPU-emulated ops; the reference-style construction has
+    NOT yet run on GPUs -- the round's GPU budget was spent when this was found).
+    Constructed natively (no device_ids: training.train_step, bench.py, the GPU tests) nothing changes."""
+    auto_sync_when_constructed_like_torch_ddp = True
 
     def finish_gradient_sync(self):
         self.allreduce_params(reduce_after=False)

@@ -92,6 +92,9 @@ mpu.model_parallel_cuda_manual_seed(1234)
 torch.manual_seed(1234)
 model, optimizer, lr_scheduler = P.setup_model_and_optimizer(args)
 assert isinstance(model, P.DDP) and model.world == WORLD
+# the reference never introduces the optimizer to the wrapper (torch's DDP needs no introduction): the mirror's optimizer found the
+# wrapper on the arena and will finish the exchange in update_master_grads(), which backward_step calls right after backward
+assert model.auto_sync and optimizer._ddp is model and model._sync_consumer
 optimizer.loss_scaler.cur_scale = 2.0 ** 12
 
 

@@ -164,6 +164,37 @@ def w_dp2_sharded(rank, world):
     return _dp_step(rank, world, shard=True)
 
 
+def w_dp2_reference_style_no_optimizer(rank, world):
+    """A wrapper constructed the way the reference constructs torch's DDP (device_ids=[i], output_device=i) and NO optimizer that
+    would finish the exchange (plain loss.backward()): the callback queued on the autograd engine finishes it at the end of the
+    pass -- the ranks hold the same, averaged gradients when backward() returns."""
+    from cogview_amd import mpu, training
+    from cogview_amd.model import PyTorchDistributedDataParallel
+    mpu.initialize_model_parallel(1)
+    g = _golden()
+    S_, B_ = int(g["cfg"][5]), int(g["cfg"][6])
+    half = B_ // world
+    sl = slice(rank * half, (rank + 1) * half)
+    model = _build(g)
+    ddp = PyTorchDistributedDataParallel(model, device_ids=[0], output_device=0, process_group=mpu.get_data_parallel_group())
+    assert ddp.auto_sync and not ddp._sync_consumer
+    pos = torch.arange(S_).unsqueeze(0).expand(half, -1)
+    batch = (g["tokens"][sl], g["labels"][sl], torch.ones_like(g["loss_mask"][sl]), 0, pos)
+    loss, _, _, _ = training.forward_step(batch, ddp, log=False, world_size=world)
+    (loss * 1024.0).backward()
+    assert not ddp.needs_reduction and ddp._pending == []
+    grads = model.module._cogv_arena.grad.detach().float() / 1024.0
+    parts = [torch.empty_like(grads) for _ in range(world)]
+    dist.all_gather(parts, grads)
+    assert torch.equal(parts[0], parts[1]), "gradients differ across the ranks after backward()"
+    return {"grads": grads, "params": None, "loss": float(loss.detach())}
+
+
+def test_reference_style_wrapper_finishes_the_exchange_at_the_end_of_backward(one_rank):
+    out = _run("w_dp2_reference_style_no_optimizer")
+    assert rel(out[0]["grads"], one_rank["grads"]) < 2e-3
+
+
 def _one_rank_whole_batch():
     """The same step in ONE process on the whole batch (this process: a one-rank gloo group)."""
     if not dist.is_initialized():
