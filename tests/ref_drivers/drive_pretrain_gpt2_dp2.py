@@ -17,12 +17,15 @@ import types
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
 RANK, WORLD, PORT = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+MP = int(sys.argv[4]) if len(sys.argv) > 4 else 1            # model-parallel size (1: two data-parallel ranks; 2: one model split in two)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.append(REF)
 
 import numpy as np
 import torch
+
+torch.set_num_threads(max(1, (os.cpu_count() or 8) // WORLD))      # one process per rank on the same cores
 
 
 class _Inert:
@@ -70,14 +73,16 @@ sys.modules["data_utils"] = du
 import torch.distributed as dist
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % PORT, world_size=WORLD, rank=RANK)
 import mpu
-mpu.initialize_model_parallel(1)
+mpu.initialize_model_parallel(MP)
 import pretrain_gpt2 as P
 from utils import Timers
 assert os.path.realpath(P.__file__).startswith(REF + "/") and P.USE_TORCH_DDP is True
 
 gold = np.load(os.path.join(ROOT, "tests", "golden", "gpt2_cfg1.npz"))
 rows = torch.from_numpy(gold["rows"])                       # 4 rows of 256 tokens: two per rank
-mine = rows[RANK * 2:(RANK + 1) * 2]
+DP_RANK, DP_WORLD = mpu.get_data_parallel_rank(), mpu.get_data_parallel_world_size()
+per = rows.shape[0] // DP_WORLD
+mine = rows[DP_RANK * per:(DP_RANK + 1) * per]           # the ranks of one model-parallel group see the same rows
 args = types.SimpleNamespace(
     num_layers=4, vocab_size=58240, hidden_size=256, num_attention_heads=4, hidden_dropout=0.0, attention_dropout=0.0,
     max_position_embeddings=256, max_position_embeddings_finetune=256, max_memory_length=0, checkpoint_activations=False,
@@ -85,16 +90,17 @@ args = types.SimpleNamespace(
     cpu_optimizer=False, cpu_torch_adam=False, lr=1.5e-4, weight_decay=0.01, loss_scale=None, dynamic_loss_scale=True,
     loss_scale_window=1000, min_scale=1, hysteresis=2, lr_decay_iters=None, train_iters=100, warmup=0.0,
     lr_decay_style="linear", lr_decay_ratio=0.1, train_data=["synthetic"], finetune=False, is_sparse=0, txt_loss_scale=1.0,
-    world_size=WORLD, clip_grad=1.0, fp32_allreduce=False, iteration=0)
+    world_size=WORLD, model_parallel_size=MP, clip_grad=1.0, fp32_allreduce=False, iteration=0)
 
 torch.manual_seed(1234)
 mpu.model_parallel_cuda_manual_seed(1234)
 torch.manual_seed(1234)
 model, optimizer, lr_scheduler = P.setup_model_and_optimizer(args)
-assert isinstance(model, P.DDP) and model.world == WORLD
+assert isinstance(model, P.DDP) and model.world == DP_WORLD
 # the reference never introduces the optimizer to the wrapper (torch's DDP needs no introduction): the mirror's optimizer found the
 # wrapper on the arena and will finish the exchange in update_master_grads(), which backward_step calls right after backward
 assert model.auto_sync and optimizer._ddp is model and model._sync_consumer
+assert (sum(p.numel() for p in model.parameters()) < 12e6) == (MP == 2)          # 18.1M parameters; a model-parallel rank holds a shard
 optimizer.loss_scaler.cur_scale = 2.0 ** 12
 
 
@@ -104,8 +110,11 @@ def batches():
 
 
 def all_equal(t):
-    parts = [torch.empty_like(t) for _ in range(WORLD)]
-    dist.all_gather(parts, t.contiguous())
+    """Across the data-parallel group (replicas of the same shard)."""
+    if DP_WORLD == 1:
+        return True
+    parts = [torch.empty_like(t) for _ in range(DP_WORLD)]
+    dist.all_gather(parts, t.contiguous(), group=mpu.get_data_parallel_group())
     return all(torch.equal(parts[0], p) for p in parts[1:])
 
 

@@ -48,7 +48,8 @@ class _Inert:
         return True
 
 
-def _cpu_scaffolding():
+def _cpu_scaffolding(world):
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))      # one process per rank on the same cores
     sys.path.insert(0, ROOT)
     from tests import cpu_ops
     cpu_ops.install()
@@ -65,7 +66,7 @@ def _entry(rank, world, port, fn_name, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
     try:
-        _cpu_scaffolding()
+        _cpu_scaffolding(world)
         ret[rank] = ("ok", globals()[fn_name](rank, world))
     except Exception:
         import traceback

@@ -119,23 +119,26 @@ def test_checkpoints_cross_the_boundary_both_ways_through_the_reference_utils(tm
 
 
 @needs_reference
-def test_reference_train_step_on_two_data_parallel_ranks_keeps_the_replicas_identical():
-    """pretrain_gpt2.train_step, unedited, on two data-parallel ranks over the mirrors (two processes, gloo; two of the four
-    golden rows each).  The reference runs with USE_TORCH_DDP = True: its backward_step never calls allreduce_params, so the
-    mirror's PyTorchDistributedDataParallel has to finish the exchange by itself at the end of backward.  After the first step
-    the ranks hold the same gradients -- the mean over all four rows: the golden's global gradient norm -- and after every step
-    the same parameters; the loss the script all-reduces is the golden's."""
+@pytest.mark.parametrize("world,mp", [(2, 1), (2, 2), (4, 2)])
+def test_reference_train_step_on_several_ranks_over_the_mirrors(world, mp):
+    """pretrain_gpt2.train_step, unedited, on two data-parallel ranks / one model split over two model-parallel ranks / both
+    (four ranks) over the mirrors (one process per rank, gloo; the four golden rows shared out over the data-parallel ranks).
+    The reference runs with USE_TORCH_DDP = True: its backward_step never calls allreduce_params, so the mirror's
+    PyTorchDistributedDataParallel has to finish the exchange without being asked.  After the first step the data-parallel
+    replicas hold the same gradients -- the mean over all four rows: the golden's global gradient norm, which the
+    model-parallel ranks assemble from their shards (mpu/grads.py:28-74) -- and after every step the same parameters; the loss
+    the script all-reduces is the golden's."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     script = os.path.join(HERE, "ref_drivers", "drive_pretrain_gpt2_dp2.py")
-    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-             for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), str(mp)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = []
     for p in procs:
-        so, se = p.communicate(timeout=600)
+        so, se = p.communicate(timeout=900)
         assert p.returncode == 0, so[-2000:] + "\n" + se[-3000:]
         outs.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
     gold = outs[0]["golden"]
@@ -146,4 +149,4 @@ def test_reference_train_step_on_two_data_parallel_ranks_keeps_the_replicas_iden
         assert abs(s1["loss_reduced"] - gold["loss"]) < 2e-3 * gold["loss"]
         assert abs(s1["grad_norm"] - gold["grad_norm"]) < 5e-3 * gold["grad_norm"]
         assert s2["loss_reduced"] < s1["loss_reduced"] - 0.05
-    assert outs[0]["step1"] == outs[1]["step1"] and outs[0]["step2"] == outs[1]["step2"]
+    assert all(o["step1"] == outs[0]["step1"] and o["step2"] == outs[0]["step2"] for o in outs)
