@@ -1,4 +1,5 @@
-"""Run the REFERENCE's own driver functions -- pretrain_gpt2.py: setup_model_and_optimizer (get_model :58-107,
+"""Run the REFERENCE's own driver functions -- pretrain_gpt2.py: the main loop train :482-566 (-> report_iteration_metrics,
+utils.save_checkpoint, evaluate_and_print_results -> evaluate :569-607), setup_model_and_optimizer (get_model :58-107,
 get_optimizer_param_groups :110-122, get_optimizer :125-157, get_learning_rate_scheduler :160-179), get_batch :258-288,
 forward_step :292-341, backward_step :344-391, train_step :406-448 -- UNEDITED, imported from /root/reference, over the
 `cogview_amd` mirrors bound exactly as INTEGRATION.md section 2 prescribes (sys.modules aliases for mpu / model / fp16 / vqvae /
@@ -115,4 +116,30 @@ out["step3"] = {"loss": float(lm.detach()), "skipped": int(skipped), "max_param_
                 "adam_steps": optimizer._step_count}
 lm, skipped, *_ = P.train_step(it, model, optimizer, lr_scheduler, args, timers, [])
 out["step4"] = {"loss": float(lm.detach()), "skipped": int(skipped), "lr_steps": lr_scheduler.num_iters}
+
+# the reference's main loop itself -- pretrain_gpt2.train (:482-566): train_step, the logging block (report_iteration_metrics,
+# timers.log), save_checkpoint every second iteration (the reference's utils.py) and evaluate_and_print_results -> evaluate
+# (:569-607: model.eval(), forward_step under no_grad, model.train()) on the same rows.  report_memory reads the CUDA allocator:
+# stubbed.  No rng block in the file (torch.cuda.get_rng_state; see drive_checkpoint_interop.py).
+import io
+import tempfile
+from contextlib import redirect_stdout
+P.report_memory = lambda name: None
+with tempfile.TemporaryDirectory() as tmp:
+    args.iteration, args.train_iters = 4, 8
+    args.log_interval, args.save, args.save_interval, args.eval_interval, args.eval_iters, args.do_valid = 2, tmp, 2, 4, 2, True
+    args.no_save_optim, args.no_save_rng, args.exit_interval = False, True, None
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        P.train(model, optimizer, lr_scheduler, it, batches(), timers, args)
+    log = buf.getvalue()
+    out["train_loop"] = {
+        "iteration": args.iteration, "lr_steps": lr_scheduler.num_iters, "adam_steps": optimizer._step_count,
+        "saved": sorted(d for d in os.listdir(tmp) if d.isdigit()), "tracker": open(os.path.join(tmp, "latest_checkpointed_iteration.txt")).read(),
+        "logged_iterations": [int(l.split("iteration")[1].split("/")[0]) for l in log.splitlines() if l.startswith(" iteration")],
+        "lm_losses": [float(l.split("lm loss")[1].split("|")[0]) for l in log.splitlines() if l.startswith(" iteration")],
+        "validation": [float(l.split("LM loss:")[1].split("|")[0]) for l in log.splitlines() if "validation loss at" in l],
+        "training_mode_restored": bool(model.training)}
+    lm_eval = P.evaluate(batches(), model, args, timers)
+    out["train_loop"]["evaluate_again"] = lm_eval
 print("RESULT " + json.dumps(out), flush=True)

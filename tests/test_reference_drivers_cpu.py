@@ -40,6 +40,15 @@ def test_reference_train_step_runs_over_the_mirrors_and_reproduces_the_reference
     # 3 / 4: the first AdamW update with lr > 0 moves the table by ~lr and the loss drops on the same batch
     assert s3["skipped"] == 0 and 0.5e-4 < s3["max_param_change"] < 4e-4 and s3["adam_steps"] == 2
     assert s4["skipped"] == 0 and s4["loss"] < s3["loss"] - 0.05 and s4["lr_steps"] == 3
+    # the reference's main loop (pretrain_gpt2.train): iterations 5..8 with logging every 2, checkpoints every 2 through the
+    # reference's utils.save_checkpoint, validation (evaluate: eval mode, no_grad, back to train mode) at iteration 8
+    t = out["train_loop"]
+    assert t["iteration"] == 8 and t["lr_steps"] == 7 and t["adam_steps"] == 7
+    assert t["saved"] == ["6", "8"] and t["tracker"] == "8"
+    assert t["logged_iterations"] == [6, 8] and t["lm_losses"][1] < t["lm_losses"][0] < s4["loss"]
+    assert len(t["validation"]) == 1 and t["training_mode_restored"]
+    assert abs(t["validation"][0] - t["evaluate_again"]) < 1e-4 * t["evaluate_again"]      # same rows, no update in between
+    assert t["evaluate_again"] < t["lm_losses"][1]                                          # evaluated after the last update
 
 
 @needs_reference
