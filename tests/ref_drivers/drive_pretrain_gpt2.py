@@ -70,7 +70,8 @@ gold = np.load(os.path.join(ROOT, "tests", "golden", "gpt2_cfg1.npz"))
 rows = torch.from_numpy(gold["rows"])
 args = types.SimpleNamespace(
     num_layers=4, vocab_size=58240, hidden_size=256, num_attention_heads=4, hidden_dropout=0.0, attention_dropout=0.0,
-    max_position_embeddings=256, max_position_embeddings_finetune=256, max_memory_length=0, checkpoint_activations=False,
+    max_position_embeddings=256, max_position_embeddings_finetune=256, max_memory_length=0,
+    checkpoint_activations=os.environ.get("COGV_DRV_CHECKPOINT_ACTIVATIONS") == "1",      # --checkpoint-activations (the reference's scripts set it)
     checkpoint_num_layers=1, query_window=128, key_window_times=6, num_pivot=768, deepspeed=False, fp16=True,
     cpu_optimizer=False, cpu_torch_adam=False, lr=1.5e-4, weight_decay=0.01, loss_scale=None, dynamic_loss_scale=True,
     loss_scale_window=1000, min_scale=1, hysteresis=2, lr_decay_iters=None, train_iters=100, warmup=0.01,

@@ -16,8 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 needs_reference = pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="/root/reference only exists in the build container")
 
 
-def _run(script):
-    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_drivers", script)], capture_output=True, text=True, timeout=600)
+def _run(script, **env):
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_drivers", script)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **env))
     assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     assert line, r.stdout[-2000:]
@@ -25,8 +26,11 @@ def _run(script):
 
 
 @needs_reference
-def test_reference_train_step_runs_over_the_mirrors_and_reproduces_the_reference_loss():
-    out = _run("drive_pretrain_gpt2.py")
+@pytest.mark.parametrize("checkpoint_activations", ["0", "1"])
+def test_reference_train_step_runs_over_the_mirrors_and_reproduces_the_reference_loss(checkpoint_activations):
+    """checkpoint_activations = 1: --checkpoint-activations as the reference's scripts set it (the mirror recomputes each layer inside
+    its fused backward): the same numbers."""
+    out = _run("drive_pretrain_gpt2.py", COGV_DRV_CHECKPOINT_ACTIVATIONS=checkpoint_activations)
     gold = out["golden"]                               # the reference's own fp32 modules on the same rows (gen_golden_cfg1.py)
     s1, s2, s3, s4 = out["step1"], out["step2"], out["step3"], out["step4"]
     # 1: default dynamic scale 2^32 overflows -> skipped, nothing moves, the scheduler does not advance, hysteresis 2 keeps the scale
