@@ -57,6 +57,9 @@ def set_default_state(state):
     _DEFAULT_STATE.seed, _DEFAULT_STATE.offset = state.seed, state.offset
 
 
+_DEFAULT_STATE_KEY = "cogview-amd-default-dropout-state"
+
+
 class CudaRNGStatesTracker:
     """Named dropout RNG states (API of mpu/random.py:85-180)."""
 
@@ -69,10 +72,32 @@ class CudaRNGStatesTracker:
         self.seeds_ = set()
 
     def get_states(self):
-        return {name: st.clone() for name, st in self.states_.items()}
+        """{name: int64 tensor [seed, offset]} -- built-in types only: utils.save_checkpoint (the reference's :219-225 as well
+        as this package's) pickles the result as sd['rng_tracker_states'], and a file that names a class of this package could
+        not be opened by the reference at all (torch.load unpickles the whole dictionary, whatever --no-load-rng says).  The
+        reference stores byte tensors of torch.cuda.get_rng_state() here; the dropout states of the two stacks are not
+        interchangeable (different generators): pass --no-load-rng when a checkpoint crosses over."""
+        out = {name: torch.tensor([st.seed, st.offset], dtype=torch.int64) for name, st in self.states_.items()}
+        # the default (data-parallel) dropout state rides along under a reserved name: the reference's save_checkpoint knows
+        # nothing of it (it saves torch.cuda.get_rng_state(), which no kernel here reads), and a resume through the reference's
+        # utils.py would otherwise restart the hidden-dropout streams
+        out[_DEFAULT_STATE_KEY] = torch.tensor([_DEFAULT_STATE.seed, _DEFAULT_STATE.offset], dtype=torch.int64)
+        return out
 
     def set_states(self, states):
-        self.states_ = {name: st.clone() for name, st in states.items()}
+        """Accepts what get_states() returns, and the _State objects files written before round 5's end carry."""
+        new = {}
+        for name, st in states.items():
+            if name == _DEFAULT_STATE_KEY:
+                seed, offset = (int(v) for v in st.tolist())
+                set_default_state(_State(seed, offset))
+                continue
+            if isinstance(st, _State):
+                new[name] = st.clone()
+            else:
+                seed, offset = (int(v) for v in (st.tolist() if isinstance(st, torch.Tensor) else st))
+                new[name] = _State(seed, offset)
+        self.states_ = new
 
     def add(self, name, seed):
         if seed in self.seeds_:

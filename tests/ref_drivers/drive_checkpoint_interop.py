@@ -13,8 +13,10 @@ mirrors' `mpu` / `model` / `fp16` cannot live in one interpreter); tests/test_re
   ref_load   REFERENCE stack: utils.load_checkpoint(<dir>/mirror) into its own fp32 GPT2Model -> same logits as the mirror
              printed: a file written over the mirrors is a reference checkpoint.
 
-Scaffolding (no GPU): as tests/ref_drivers/drive_pretrain_gpt2.py; --no-save-rng / --no-load-rng because the reference's rng
-block calls torch.cuda.get_rng_state() (the mirrors' dropout counters are covered on the GPU by tests/test_checkpoint_gpu.py);
+Scaffolding (no GPU): as tests/ref_drivers/drive_pretrain_gpt2.py; torch.cuda.get_rng_state / set_rng_state (which the reference's
+rng block calls, utils.py:219-225, 363-368) are stand-ins in the mirror stage -- no kernel of this package reads that state; its
+dropout streams are the (seed, offset) pairs of mpu.get_cuda_rng_tracker().get_states(), which the reference's block does save --
+and the reference stages run with --no-save-rng / --no-load-rng (the two stacks' dropout states are not interchangeable);
 TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD=1 in both stacks: the reference's `torch.load(name, map_location='cpu')` predates torch 2.6's
 weights_only default, which refuses the loss-scaler object (and the numpy rng state) its own checkpoints carry."""
 import json
@@ -91,6 +93,8 @@ torch.Tensor.is_cuda = property(lambda self: True)
 torch.nn.Module.cuda = lambda self, device=None: self
 torch.cuda.current_device = lambda: 0
 torch.cuda.synchronize = lambda *a, **k: None
+torch.cuda.get_rng_state = lambda *a, **k: torch.zeros(16, dtype=torch.uint8)
+torch.cuda.set_rng_state = lambda *a, **k: None
 import cpu_ops
 cpu_ops.install()
 import cogview_amd
@@ -157,7 +161,15 @@ for _ in range(3):
     lm, skipped, *_ = P.train_step(data, model, optimizer, lr_scheduler, args, timers, [])
     assert skipped == 0
     losses.append(float(lm.detach()))
+# ... with the rng block (the default): python / numpy / torch generators and the dropout states -- the model-parallel tracker's and,
+# under a reserved name, the default one -- as plain tensors
+args.no_save_rng = False
+mpu.random.manual_seed(4242)
+for _ in range(5):
+    mpu.random.next_dropout_stream()
+tracker_before = {k: v.tolist() for k, v in mpu.get_cuda_rng_tracker().get_states().items()}
 U.save_checkpoint(3, model, optimizer, lr_scheduler, args)
+mpu.random.manual_seed(1)                                     # (the resumed process starts from other states)
 out["losses"] = losses
 out["logits_of_saved_model"] = logits_summary(eval_logits(model))
 lm4, skipped, *_ = P.train_step(data, model, optimizer, lr_scheduler, args, timers, [])
@@ -166,8 +178,10 @@ out["step4_uninterrupted"] = {"loss": float(lm4.detach()), "lr_steps": lr_schedu
 
 # 3. resume: a fresh model / optimizer / scheduler, the reference's load_checkpoint, the same step 4
 model2, optimizer2, lr2 = fresh(2)
-it = U.load_checkpoint(model2, optimizer2, lr2, base_args(load=os.path.join(DIR, "mirror")))
+it = U.load_checkpoint(model2, optimizer2, lr2, base_args(load=os.path.join(DIR, "mirror"), no_load_rng=False))
 assert it == 3, it
+tracker_after = {k: v.tolist() for k, v in mpu.get_cuda_rng_tracker().get_states().items()}
+out["dropout_states_restored"] = tracker_after == tracker_before and tracker_after["cogview-amd-default-dropout-state"] == [4242, 5]
 lm4b, skipped, *_ = P.train_step(batches(), model2, optimizer2, lr2, args, timers, [])
 out["step4_resumed"] = {"loss": float(lm4b.detach()), "lr_steps": lr2.num_iters, "adam_steps": optimizer2._step_count,
                         "scale": float(optimizer2.loss_scale)}

@@ -125,6 +125,7 @@ def test_checkpoints_cross_the_boundary_both_ways_through_the_reference_utils(tm
     a, b = mir["step4_uninterrupted"], mir["step4_resumed"]
     assert a == b and mir["weights_after_step4_equal"], (a, b, mir["weights_after_step4_maxdiff"])
     assert a["adam_steps"] == 4 and a["lr_steps"] == 4
+    assert mir["dropout_states_restored"]           # the rng block of the reference's save / load carries the mirrors' dropout states
     close(back["logits"], mir["logits_of_saved_model"], 2e-3)
     # and the file itself names the reference's classes only: it opens without this package on the path
     blob = open(os.path.join(str(tmp_path), "mirror", "3", "mp_rank_00_model_states.pt"), "rb").read()
