@@ -201,7 +201,21 @@ def test_checkpoint_files_follow_the_reference_layout(tmp_path):
                            no_load_optim=False, no_load_rng=False, finetune=False)
     m1, sch = build(1), Sched()
     sch.n = 7
+    # dropout states at the time of the save: default (data-parallel) stream 3 draws in, the model-parallel one 1 draw in
+    from cogview_amd.mpu import random as R
+    tr = R.get_cuda_rng_tracker()
+    keep_tracker, keep_default = tr.get_states(), R.get_default_state()
+    tr.reset()
+    tr.add("model-parallel-rng", 31337)
+    R.manual_seed(777)
+    for _ in range(3):
+        R.next_dropout_stream()
+    with tr.fork():
+        R.next_dropout_stream()
     utils.save_checkpoint(1200, m1, None, sch, args)
+    R.manual_seed(5)                                         # the process that resumes starts from other states
+    tr.reset()
+    tr.add("model-parallel-rng", 1)
     name = os.path.join(str(tmp_path), "1200", "mp_rank_00_model_states.pt")
     assert os.path.isfile(name) and open(os.path.join(str(tmp_path), "latest_checkpointed_iteration.txt")).read() == "1200"
     sd = torch.load(name, map_location="cpu", weights_only=False)
@@ -210,6 +224,12 @@ def test_checkpoint_files_follow_the_reference_layout(tmp_path):
     assert list(sd["module"])[0] == "word_embeddings.weight" and "transformer.layers.0.attention.query_key_value.weight" in sd["module"]
     m2, sch2 = build(2), Sched()
     assert utils.load_checkpoint(m2, None, sch2, args) == 1200 and sch2.n == 7
+    assert R.next_dropout_stream() == (777, 4)               # both dropout streams continue where the saved run stood
+    with tr.fork():
+        assert R.next_dropout_stream() == (31337, 2)
+    assert all(isinstance(v, torch.Tensor) and v.dtype == torch.int64 for v in sd["rng_tracker_states"].values())
+    tr.set_states(keep_tracker)
+    R.set_default_state(keep_default)
     for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
     args.finetune = True
