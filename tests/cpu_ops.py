@@ -5,8 +5,10 @@ signatures and semantics (include/cogview_hip.h is the specification; fp32 arith
 where the kernels round).  It exists so that the HOST side of the path -- the `mpu` / `model` / `fp16` mirrors, the fused
 layer Function, the gradient arena, the fused optimizer's control flow, and the REFERENCE's own driver functions calling them
 (tests/test_reference_drivers_cpu.py) -- can execute end to end in a container without a GPU.  Nothing in the product
-imports this file; the product path fails loudly without the HIP library (tests/test_abi.py).  Dropout is not emulated
-(every caller here runs with p = 0), nor are the decode and the sparse-training forms (the gathered form of sparse generation is).
+imports this file; the product path fails loudly without the HIP library (tests/test_abi.py).  Dropout IS emulated, with the
+kernels' own counter-based generator as oracle/cogview_oracle.py restates it (dropout_keep_mask / attention_keep_mask: a mask is a
+pure function of (seed, stream id, element index), so forward, backward and a recompute see the same one); the decode and the
+sparse-training forms are not emulated (the gathered form of sparse generation is).
 """
 import math
 
@@ -26,7 +28,19 @@ def _gelu_grad(x):
 
 
 def _no_dropout(d):
-    assert d is None or d[0] == 0.0, "tests/cpu_ops.py does not emulate dropout"
+    assert d is None or d[0] == 0.0, "tests/cpu_ops.py: no dropout in this form"
+
+
+def _keep(shape, d):
+    """Scaled keep mask (0 or 65536 / (65536 - thr16)) of the element-wise convention, element index = flat index; None for p = 0."""
+    if d is None or float(d[0]) == 0.0:
+        return None
+    import numpy as np
+    from oracle import cogview_oracle as O
+    n = 1
+    for v in shape:
+        n *= int(v)
+    return torch.from_numpy(np.ascontiguousarray(O.dropout_keep_mask(n, float(d[0]), int(d[1]), int(d[2])))).view(tuple(shape))
 
 
 def new_absmax_slot(device):
@@ -48,7 +62,6 @@ def absmax(x, out=None):
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, gelu_aux=None, dgelu_aux=None, dropout=None,
          absmax=None, accumulate=False, splitk=None, out_dtype=None, variant=0, colsum_out=None, colsum_accumulate=True,
          gelu_daux=None, mul_aux=None):
-    _no_dropout(dropout)
     A = a.float().t() if trans_a else a.float()
     B = b.float() if trans_b else b.float().t()
     c = A @ B
@@ -65,6 +78,9 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
         c = c * _gelu_grad(dgelu_aux.float())
     if mul_aux is not None:
         c = c * mul_aux.float()
+    keep = _keep(c.shape, dropout)                                   # epilogue order: ... -> dropout -> +C -> round (cogview_hip.h:49)
+    if keep is not None:
+        c = c * keep
     if out is None:
         assert not accumulate
         out = torch.empty(c.shape, dtype=out_dtype or a.dtype)
@@ -121,12 +137,14 @@ def _accum_param_grad(dst, val, accumulate):
 
 
 def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=None, dbeta=None, colsum=None, accumulate=False):
-    _no_dropout(dropout)
     h = x.shape[-1]
     dyf, xf = dy.reshape(-1, h).float(), x.reshape(-1, h).float()
     xh = (xf - mean[:, None]) * rstd[:, None]
     g = dyf * gamma.float()
     dx = rstd[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+    keep = _keep(dx.shape, dropout)                                  # dx = [add_in +] mask(LN'(dy)): the producing GEMM's dropout, replayed
+    if keep is not None:
+        dx = dx * keep
     if add_in is not None:
         dx = dx + add_in.reshape(-1, h).float()
     dx = dx.to(x.dtype)                                              # fp32 for the stream forms' fp32 x, else the storage type
@@ -142,38 +160,49 @@ def _visible(s_q, s_k, sep):
     return (j <= i + (s_k - s_q)) | (j < int(sep))
 
 
-def _attn(q, k, v, sep):
+def _attn_keep(q, k, d):
+    if d is None or float(d[0]) == 0.0:
+        return None
+    import numpy as np
+    from oracle import cogview_oracle as O
+    b, s_q, H, _ = q.shape
+    return torch.from_numpy(np.ascontiguousarray(O.attention_keep_mask(b, H, s_q, k.shape[1], float(d[0]), int(d[1]), int(d[2]))))
+
+
+def _attn(q, k, v, sep, keep=None):
     # q [b, s_q, H, 64] -> scores [b, H, s_q, s_k]; reference order: Q / sqrt(d) first (mpu/sparse_transformer.py:653-659)
     qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
     s = (qf / math.sqrt(q.shape[-1])) @ kf.transpose(-1, -2)
     vis = _visible(q.shape[1], k.shape[1], sep)
     s = torch.where(vis, s, torch.full_like(s, -10000.0))
     lse = torch.logsumexp(s, -1)
-    o = torch.softmax(s, -1) @ vf
+    p = torch.softmax(s, -1)
+    if keep is not None:                                             # dropout on the probabilities (mpu/sparse_transformer.py:667-669)
+        p = p * keep
+    o = p @ vf
     return o.permute(0, 2, 1, 3), lse
 
 
 def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None, keep_bits=False, mask=None):
-    _no_dropout(dropout)
     assert sparse is None and mask is None
     if kv_index is not None:
+        _no_dropout(dropout)
         # gathered form (sparse_attention_inference): key slot j of row i is position kv_index[i, j]; the last s_q slots are the
         # queries themselves, left-to-right among them (include/cogview_hip.h, cogv_attention_fwd with kv_index)
         assert int(sep) == 0
         idx = kv_index.long()
         k = torch.stack([k[i, idx[i]] for i in range(k.shape[0])])
         v = torch.stack([v[i, idx[i]] for i in range(v.shape[0])])
-    o, lse = _attn(q, k, v, sep)
+    o, lse = _attn(q, k, v, sep, _attn_keep(q, k, dropout))
     o = o.contiguous().to(q.dtype)
-    return (o, lse, None) if keep_bits else (o, lse)
+    return (o, lse, None) if keep_bits else (o, lse)      # (no stored keep bits: the backward regenerates the mask from the same counters)
 
 
 def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, dv=None, colsum_out=None, colsum_accumulate=True,
                   keep_bits=None, mask=None):
-    _no_dropout(dropout)
     qg, kg, vg = (t.detach().float().requires_grad_(True) for t in (q, k, v))
     with torch.enable_grad():
-        out, _ = _attn(qg, kg, vg, sep)
+        out, _ = _attn(qg, kg, vg, sep, _attn_keep(q, k, dropout))
         gq, gk, gv = torch.autograd.grad(out, (qg, kg, vg), dout.float())
     outs = []
     for dst, g in ((dq, gq), (dk, gk), (dv, gv)):
@@ -189,7 +218,6 @@ def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, 
 
 
 def embedding_fwd(ids, table, vocab_start, pos_ids=None, pos_table=None, dropout=None, absmax_out=None, x_in=None, out_f32=False):
-    _no_dropout(dropout)
     src = table if table is not None else x_in
     if ids is not None:
         local = ids - vocab_start
@@ -199,15 +227,20 @@ def embedding_fwd(ids, table, vocab_start, pos_ids=None, pos_table=None, dropout
         x = x_in.float()
     if pos_table is not None:
         x = x + pos_table.float()[pos_ids.expand(x.shape[:-1])]
+    keep = _keep(x.shape, dropout)
+    if keep is not None:
+        x = x * keep
     out = x if out_f32 else x.to(src.dtype)
     _publish(absmax_out, out)
     return out.contiguous()
 
 
 def embedding_bwd(dout, ids, dtable, vocab_start, pos_ids=None, dpos=None, dropout=None, dx=None):
-    _no_dropout(dropout)
     h = dout.shape[-1]
     d2 = dout.reshape(-1, h).float()
+    keep = _keep(d2.shape, dropout)
+    if keep is not None:
+        d2 = d2 * keep
     if dtable is not None and ids is not None:
         local = (ids - vocab_start).reshape(-1)
         ok = (local >= 0) & (local < dtable.shape[0])
@@ -218,7 +251,7 @@ def embedding_bwd(dout, ids, dtable, vocab_start, pos_ids=None, dpos=None, dropo
         acc = torch.zeros(dpos.shape, dtype=torch.float32).index_add_(0, p, d2)
         dpos.copy_(dpos.float() + acc)
     if dx is not None:
-        dx.copy_(dout)
+        dx.copy_(d2.view(dout.shape))
 
 
 def ce_fwd(logits2d, target1d, vocab_start, want_loss=True):
@@ -309,8 +342,8 @@ def gelu_bwd(dy, x):
 
 
 def dropout(x, p, seed, stream_id, absmax_out=None):
-    assert float(p) == 0.0, "tests/cpu_ops.py does not emulate dropout"
-    y = x.clone()
+    keep = _keep(x.shape, (p, seed, stream_id))
+    y = x.clone() if keep is None else (x.float() * keep).to(x.dtype)
     _publish(absmax_out, y)
     return y
 

@@ -69,7 +69,8 @@ assert P.DDP is cogview_amd.model.PyTorchDistributedDataParallel and P.Adam is c
 gold = np.load(os.path.join(ROOT, "tests", "golden", "gpt2_cfg1.npz"))
 rows = torch.from_numpy(gold["rows"])
 args = types.SimpleNamespace(
-    num_layers=4, vocab_size=58240, hidden_size=256, num_attention_heads=4, hidden_dropout=0.0, attention_dropout=0.0,
+    num_layers=4, vocab_size=58240, hidden_size=256, num_attention_heads=4,
+    hidden_dropout=float(os.environ.get("COGV_DRV_DROPOUT", "0")), attention_dropout=float(os.environ.get("COGV_DRV_DROPOUT", "0")),
     max_position_embeddings=256, max_position_embeddings_finetune=256, max_memory_length=0,
     checkpoint_activations=os.environ.get("COGV_DRV_CHECKPOINT_ACTIVATIONS") == "1",      # --checkpoint-activations (the reference's scripts set it)
     checkpoint_num_layers=1, query_window=128, key_window_times=6, num_pivot=768, deepspeed=False, fp16=True,

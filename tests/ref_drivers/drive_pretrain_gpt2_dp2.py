@@ -84,7 +84,8 @@ DP_RANK, DP_WORLD = mpu.get_data_parallel_rank(), mpu.get_data_parallel_world_si
 per = rows.shape[0] // DP_WORLD
 mine = rows[DP_RANK * per:(DP_RANK + 1) * per]           # the ranks of one model-parallel group see the same rows
 args = types.SimpleNamespace(
-    num_layers=4, vocab_size=58240, hidden_size=256, num_attention_heads=4, hidden_dropout=0.0, attention_dropout=0.0,
+    num_layers=4, vocab_size=58240, hidden_size=256, num_attention_heads=4,
+    hidden_dropout=float(os.environ.get("COGV_DRV_DROPOUT", "0")), attention_dropout=float(os.environ.get("COGV_DRV_DROPOUT", "0")),
     max_position_embeddings=256, max_position_embeddings_finetune=256, max_memory_length=0, checkpoint_activations=False,
     checkpoint_num_layers=1, query_window=128, key_window_times=6, num_pivot=768, deepspeed=False, fp16=True,
     cpu_optimizer=False, cpu_torch_adam=False, lr=1.5e-4, weight_decay=0.01, loss_scale=None, dynamic_loss_scale=True,
@@ -118,6 +119,17 @@ def all_equal(t):
     return all(torch.equal(parts[0], p) for p in parts[1:])
 
 
+def replicated_equal_across_model_parallel_ranks():
+    """LayerNorm weights, row-parallel biases, position embeddings: held by every model-parallel rank, updated by each on its own
+    -- from gradients that must therefore be identical (same hidden-dropout masks on the ranks of a model-parallel group)."""
+    if MP == 1:
+        return True
+    flat = torch.cat([p.detach().float().view(-1) for p in model.parameters() if not getattr(p, "model_parallel", False)])
+    parts = [torch.empty_like(flat) for _ in range(MP)]
+    dist.all_gather(parts, flat, group=mpu.get_model_parallel_group())
+    return all(torch.equal(parts[0], p) for p in parts[1:])
+
+
 it, timers, out = batches(), Timers(), {"rank": RANK}
 arena = model.module.module._cogv_arena
 lm, skipped, *_ = P.train_step(it, model, optimizer, lr_scheduler, args, timers, [])
@@ -127,7 +139,8 @@ out["step1"] = {"loss_reduced": float(lm.detach()), "skipped": int(skipped),
                 "params_equal_across_ranks": all_equal(arena.data.detach().float())}
 lm, skipped, *_ = P.train_step(it, model, optimizer, lr_scheduler, args, timers, [])
 out["step2"] = {"loss_reduced": float(lm.detach()), "skipped": int(skipped),
-                "params_equal_across_ranks": all_equal(arena.data.detach().float())}
+                "params_equal_across_ranks": all_equal(arena.data.detach().float()),
+                "replicated_params_equal_across_mp_ranks": replicated_equal_across_model_parallel_ranks()}
 out["golden"] = {"loss": float(gold["loss"]), "grad_norm": float(gold["grad_norm"])}
 print("RESULT " + json.dumps(out), flush=True)
 dist.barrier()

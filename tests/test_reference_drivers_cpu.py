@@ -133,15 +133,33 @@ def test_checkpoints_cross_the_boundary_both_ways_through_the_reference_utils(tm
 
 
 @needs_reference
-@pytest.mark.parametrize("world,mp", [(2, 1), (2, 2), (4, 2)])
-def test_reference_train_step_on_several_ranks_over_the_mirrors(world, mp):
+def test_reference_train_loop_with_dropout_replays_its_masks_under_activation_checkpointing():
+    """The reference's defaults -- hidden / attention dropout 0.1 -- through its train_step and its main loop over the mirrors (the
+    CPU emulation draws the kernels' own counter-based masks, oracle/cogview_oracle.py dropout_keep_mask / attention_keep_mask):
+    with --checkpoint-activations every layer is recomputed in backward and must see the masks of its forward pass, so every loss
+    of the run is the same number with and without it; and dropout does act (other losses than the dropout-free run's)."""
+    runs = [_run("drive_pretrain_gpt2.py", COGV_DRV_DROPOUT="0.1", COGV_DRV_CHECKPOINT_ACTIVATIONS=ck) for ck in ("0", "1")]
+    seq = [[r["step2"]["loss"], r["step2"]["grad_norm"], r["step3"]["loss"], r["step4"]["loss"]] + r["train_loop"]["lm_losses"]
+           + r["train_loop"]["validation"] for r in runs]
+    assert seq[0] == seq[1], seq
+    gold = runs[0]["golden"]
+    assert abs(seq[0][0] - gold["loss"]) > 1e-3 and abs(seq[0][0] - gold["loss"]) < 0.05 * gold["loss"]
+    assert seq[0][2] != seq[0][0]                                      # step 3 draws other masks than step 2 (the weights had not moved)
+    assert runs[0]["step4"]["loss"] < runs[0]["step3"]["loss"] - 0.05
+
+
+@needs_reference
+@pytest.mark.parametrize("world,mp,dropout", [(2, 1, "0"), (2, 2, "0"), (4, 2, "0"), (4, 2, "0.1")])
+def test_reference_train_step_on_several_ranks_over_the_mirrors(world, mp, dropout):
     """pretrain_gpt2.train_step, unedited, on two data-parallel ranks / one model split over two model-parallel ranks / both
     (four ranks) over the mirrors (one process per rank, gloo; the four golden rows shared out over the data-parallel ranks).
     The reference runs with USE_TORCH_DDP = True: its backward_step never calls allreduce_params, so the mirror's
     PyTorchDistributedDataParallel has to finish the exchange without being asked.  After the first step the data-parallel
     replicas hold the same gradients -- the mean over all four rows: the golden's global gradient norm, which the
     model-parallel ranks assemble from their shards (mpu/grads.py:28-74) -- and after every step the same parameters; the loss
-    the script all-reduces is the golden's."""
+    the script all-reduces is the golden's.  With dropout 0.1 (the reference's default; no golden then): the replicas still
+    agree bit for bit, and so do the parameters every model-parallel rank holds a copy of (same hidden-dropout masks on the ranks of
+    a model-parallel group, mpu/random.py:198-233)."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -149,7 +167,7 @@ def test_reference_train_step_on_several_ranks_over_the_mirrors(world, mp):
     s.close()
     script = os.path.join(HERE, "ref_drivers", "drive_pretrain_gpt2_dp2.py")
     procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), str(mp)], stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+                              stderr=subprocess.PIPE, text=True, env=dict(os.environ, COGV_DRV_DROPOUT=dropout)) for r in range(world)]
     outs = []
     for p in procs:
         so, se = p.communicate(timeout=900)
@@ -160,7 +178,10 @@ def test_reference_train_step_on_several_ranks_over_the_mirrors(world, mp):
         s1, s2 = o["step1"], o["step2"]
         assert s1["skipped"] == 0 and s2["skipped"] == 0
         assert s1["grads_equal_across_ranks"] and s1["params_equal_across_ranks"] and s2["params_equal_across_ranks"]
-        assert abs(s1["loss_reduced"] - gold["loss"]) < 2e-3 * gold["loss"]
-        assert abs(s1["grad_norm"] - gold["grad_norm"]) < 5e-3 * gold["grad_norm"]
+        assert s2["replicated_params_equal_across_mp_ranks"]
+        tol = 2e-3 if dropout == "0" else 2e-2
+        assert abs(s1["loss_reduced"] - gold["loss"]) < tol * gold["loss"]
+        if dropout == "0":
+            assert abs(s1["grad_norm"] - gold["grad_norm"]) < 5e-3 * gold["grad_norm"]
         assert s2["loss_reduced"] < s1["loss_reduced"] - 0.05
     assert all(o["step1"] == outs[0]["step1"] and o["step2"] == outs[0]["step2"] for o in outs)
