@@ -157,7 +157,7 @@ def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=
 def _visible(s_q, s_k, sep):
     i = torch.arange(s_q)[:, None]
     j = torch.arange(s_k)[None, :]
-    return (j <= i + (s_k - s_q)) | (j < int(sep))
+    return (j <= i + (s_k - s_q)) | (j < int(sep) + (s_k - s_q))      # include/cogview_hip.h: the memory shifts the visible prefix too
 
 
 def _attn_keep(q, k, d):
@@ -226,7 +226,7 @@ def embedding_fwd(ids, table, vocab_start, pos_ids=None, pos_table=None, dropout
     else:
         x = x_in.float()
     if pos_table is not None:
-        x = x + pos_table.float()[pos_ids.expand(x.shape[:-1])]
+        x = x + pos_table.float()[pos_ids.expand(x.shape[:-1]).clamp(0, pos_table.shape[0] - 1)]      # the kernel clamps position ids
     keep = _keep(x.shape, dropout)
     if keep is not None:
         x = x * keep
@@ -247,7 +247,7 @@ def embedding_bwd(dout, ids, dtable, vocab_start, pos_ids=None, dpos=None, dropo
         acc = torch.zeros(dtable.shape, dtype=torch.float32).index_add_(0, local[ok], d2[ok])
         dtable.copy_(dtable.float() + acc)
     if dpos is not None:
-        p = pos_ids.expand(dout.shape[:-1]).reshape(-1)
+        p = pos_ids.expand(dout.shape[:-1]).reshape(-1).clamp(0, dpos.shape[0] - 1)
         acc = torch.zeros(dpos.shape, dtype=torch.float32).index_add_(0, p, d2)
         dpos.copy_(dpos.float() + acc)
     if dx is not None:
