@@ -77,6 +77,12 @@ mpu.initialize_model_parallel(MP)
 import pretrain_gpt2 as P
 from utils import Timers
 assert os.path.realpath(P.__file__).startswith(REF + "/") and P.USE_TORCH_DDP is True
+if os.environ.get("COGV_DRV_TORCH_DDP") == "0":
+    # the reference's other setting (pretrain_gpt2.py:19 USE_TORCH_DDP = False): its own DistributedDataParallel wrapper, whose
+    # exchange backward_step requests explicitly -- model.allreduce_params(reduce_after=False, fp32_allreduce=...) (:371-375).
+    # The flag is a module constant read at import: set here as an edit of that one line would set it.
+    import model as _model_pkg
+    P.USE_TORCH_DDP, P.DDP = False, _model_pkg.DistributedDataParallel
 
 gold = np.load(os.path.join(ROOT, "tests", "golden", "gpt2_cfg1.npz"))
 rows = torch.from_numpy(gold["rows"])                       # 4 rows of 256 tokens: two per rank
@@ -91,7 +97,7 @@ args = types.SimpleNamespace(
     cpu_optimizer=False, cpu_torch_adam=False, lr=1.5e-4, weight_decay=0.01, loss_scale=None, dynamic_loss_scale=True,
     loss_scale_window=1000, min_scale=1, hysteresis=2, lr_decay_iters=None, train_iters=100, warmup=0.0,
     lr_decay_style="linear", lr_decay_ratio=0.1, train_data=["synthetic"], finetune=False, is_sparse=0, txt_loss_scale=1.0,
-    world_size=WORLD, model_parallel_size=MP, clip_grad=1.0, fp32_allreduce=False, iteration=0)
+    world_size=WORLD, model_parallel_size=MP, clip_grad=1.0, fp32_allreduce=os.environ.get("COGV_DRV_FP32_ALLREDUCE") == "1", iteration=0)
 
 torch.manual_seed(1234)
 mpu.model_parallel_cuda_manual_seed(1234)
@@ -100,7 +106,10 @@ model, optimizer, lr_scheduler = P.setup_model_and_optimizer(args)
 assert isinstance(model, P.DDP) and model.world == DP_WORLD
 # the reference never introduces the optimizer to the wrapper (torch's DDP needs no introduction): the mirror's optimizer found the
 # wrapper on the arena and will finish the exchange in update_master_grads(), which backward_step calls right after backward
-assert model.auto_sync and optimizer._ddp is model and model._sync_consumer
+if P.USE_TORCH_DDP:
+    assert model.auto_sync and optimizer._ddp is model and model._sync_consumer
+else:
+    assert not model.auto_sync and optimizer._ddp is None and type(model).__name__ == "DistributedDataParallel"
 assert (sum(p.numel() for p in model.parameters()) < 12e6) == (MP == 2)          # 18.1M parameters; a model-parallel rank holds a shard
 optimizer.loss_scaler.cur_scale = 2.0 ** 12
 

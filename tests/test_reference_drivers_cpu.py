@@ -132,6 +132,40 @@ def test_checkpoints_cross_the_boundary_both_ways_through_the_reference_utils(tm
     assert b"cogview_amd" not in blob and b"loss_scaler" in blob
 
 
+def _run_ranks(script, world, port, mp, **env):
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), str(mp)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env)) for r in range(world)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, so[-2000:] + "\n" + se[-3000:]
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    return outs
+
+
+@needs_reference
+@pytest.mark.parametrize("fp32_allreduce", ["0", "1"])
+def test_reference_train_step_with_its_own_data_parallel_wrapper(fp32_allreduce):
+    """The reference's other setting, USE_TORCH_DDP = False (pretrain_gpt2.py:19, 38-41, 104-105, 371-375): model/distributed.py's
+    own DistributedDataParallel, whose exchange backward_step requests with allreduce_params(reduce_after=False,
+    fp32_allreduce=args.fp32_allreduce).  Two data-parallel ranks over the mirror of that class: same gradients (the golden's
+    norm), same parameters, with the 16-bit and with the fp32 exchange."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    outs = _run_ranks(os.path.join(HERE, "ref_drivers", "drive_pretrain_gpt2_dp2.py"), 2, port, 1, COGV_DRV_TORCH_DDP="0",
+                      COGV_DRV_FP32_ALLREDUCE=fp32_allreduce)
+    gold = outs[0]["golden"]
+    for o in outs:
+        s1, s2 = o["step1"], o["step2"]
+        assert s1["skipped"] == 0 and s1["grads_equal_across_ranks"] and s1["params_equal_across_ranks"] and s2["params_equal_across_ranks"]
+        assert abs(s1["loss_reduced"] - gold["loss"]) < 2e-3 * gold["loss"]
+        assert abs(s1["grad_norm"] - gold["grad_norm"]) < 5e-3 * gold["grad_norm"]
+    assert outs[0]["step1"] == outs[1]["step1"] and outs[0]["step2"] == outs[1]["step2"]
+
+
 @needs_reference
 def test_reference_train_loop_with_dropout_replays_its_masks_under_activation_checkpointing():
     """The reference's defaults -- hidden / attention dropout 0.1 -- through its train_step and its main loop over the mirrors (the
@@ -166,13 +200,7 @@ def test_reference_train_step_on_several_ranks_over_the_mirrors(world, mp, dropo
     port = s.getsockname()[1]
     s.close()
     script = os.path.join(HERE, "ref_drivers", "drive_pretrain_gpt2_dp2.py")
-    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), str(mp)], stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, text=True, env=dict(os.environ, COGV_DRV_DROPOUT=dropout)) for r in range(world)]
-    outs = []
-    for p in procs:
-        so, se = p.communicate(timeout=900)
-        assert p.returncode == 0, so[-2000:] + "\n" + se[-3000:]
-        outs.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    outs = _run_ranks(script, world, port, mp, COGV_DRV_DROPOUT=dropout)
     gold = outs[0]["golden"]
     for o in outs:
         s1, s2 = o["step1"], o["step2"]
