@@ -202,6 +202,28 @@ def lm_loss(logits, labels, loss_mask, txt_mask=None, txt_loss_scale=1.0):
     return torch.sum(losses.view(-1) * lm) / lm.sum()
 
 
+IMG_TXT_SEP = 8192      # data_utils/unified_tokenizer.py:32-67: image codes are ids [0, 8192)
+
+
+def forward_step_losses(logits, tokens, labels, loss_mask, txt_loss_scale=1.0):
+    """pretrain_gpt2.py:304-331 on one rank: (loss, img_loss, txt_loss).  Image / text positions are told apart by the INPUT
+    token id (:305-306), text positions additionally need a non-zero mask; the logged partial losses are sums of the already
+    WEIGHTED per-token losses over the boolean sets divided by the set sizes (pads inside the image set count in the
+    denominator), the text one divided by the scale again (:330-331)."""
+    img = tokens < IMG_TXT_SEP
+    txt = (~img) & (loss_mask > 0)
+    losses = vocab_parallel_cross_entropy(logits.contiguous().float(), labels)
+    lm = loss_mask.clone().float()
+    lm[txt] *= txt_loss_scale
+    lm = lm.view(-1)
+    losses = losses.view(-1) * lm
+    loss = torch.sum(losses) / lm.sum()
+    img, txt = img.view(-1), txt.view(-1)
+    img_loss = losses[img].detach().sum() / max(int(img.sum()), 1)
+    txt_loss = losses[txt].detach().sum() / max(int(txt.sum()), 1) / txt_loss_scale
+    return loss, img_loss, txt_loss
+
+
 # --------------------------------------------------------------------------------------------- optimizer
 def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
     """apex FusedAdam(adam_w_mode=True, bias_correction=True) as called at pretrain_gpt2.py:139-140

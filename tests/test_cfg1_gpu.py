@@ -79,6 +79,48 @@ def test_cfg1_forward_backward_vs_the_reference_run(golden_dir, dtype):
     assert e_gn < GNORM_TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_forward_step_with_txt_loss_scale_5_vs_the_reference_run(golden_dir, dtype):
+    """SURVEY 8(a) G14 off its default on the HIP path: `--txt-loss-scale 5` (scripts/pretrain_single_node.sh:40) on a mixed
+    text / image / pad batch (ragged rows of 128 tokens -> s = 127) against the REFERENCE's own forward_step
+    (pretrain_gpt2.py:292-341; tests/golden/forward_step_txtscale.npz, oracle/gen_golden_txtscale.py): loss, the two logged
+    partial losses, per-tensor gradient norms, five gradient tensors, the global norm.  Same tolerances as the cfg 1 run."""
+    from cogview_amd import mpu, training
+    z = np.load(os.path.join(golden_dir, "forward_step_txtscale.npz"))
+    ts = float(z["txt_loss_scale"])
+    rows, mask = torch.from_numpy(z["rows"]).cuda(), torch.from_numpy(z["loss_mask"]).cuda()
+    model = _model(dtype)
+    batch = training.get_batch(rows, mask)
+    assert batch[0].shape == (4, 127) and int((batch[2] == 0).sum()) > 0
+    loss, _, img_loss, txt_loss = training.forward_step(batch, model, txt_loss_scale=ts, log=True)
+    plain, _, _, _ = training.forward_step(batch, model, txt_loss_scale=1.0, log=False)
+    scale = 2.0 ** 12 if dtype == torch.float16 else 1.0
+    (loss * scale).backward()
+    names = [str(n) for n in z["grad_names"]]
+    params = dict(model.module.named_parameters())
+    assert names == list(params)
+    worst_n, worst_name = 0.0, ""
+    for n, ref in zip(names, z["grad_norms"]):
+        e = abs(params[n].grad.double().norm().item() / scale - ref) / ref
+        if e > worst_n:
+            worst_n, worst_name = e, n
+    worst_g = max(rel(params[k[5:]].grad.float() / scale, torch.from_numpy(z[k])) for k in z.files if k.startswith("grad."))
+    for p in params.values():
+        if not hasattr(p, "model_parallel"):
+            p.model_parallel = False
+    gnorm = float(mpu.clip_grad_norm(list(params.values()), 1e12)) / scale
+    e_gn = abs(gnorm - float(z["grad_norm"])) / float(z["grad_norm"])
+    print(f"\n[txt_loss_scale 5 {dtype}] loss {loss.item():.5f} / img {img_loss.item():.5f} / txt {txt_loss.item():.5f} "
+          f"(reference {float(z['loss']):.5f} / {float(z['img_loss']):.5f} / {float(z['txt_loss']):.5f}; unweighted {plain.item():.5f}); "
+          f"per-tensor grad norms worst {worst_n:.2e} ({worst_name}); grad tensors {worst_g:.2e}; global norm {e_gn:.1e}")
+    for got, key in ((loss, "loss"), (img_loss, "img_loss"), (txt_loss, "txt_loss")):
+        assert abs(got.item() - float(z[key])) < LOSS_TOL[dtype] * float(z[key]), key
+    assert abs(plain.item() - float(z["loss"])) > 1e-3            # the weighting is visible on this batch
+    assert worst_n < NORM_TOL[dtype], (worst_n, worst_name)
+    assert worst_g < GRAD_TOL[dtype]
+    assert e_gn < GNORM_TOL[dtype]
+
+
 def test_cfg1_train_steps_run_and_loss_falls(golden_dir):
     """Five optimizer steps of the reference's loop on the cfg 1 batch (dropout 0.1 as arguments.py:30,40 default, dynamic
     loss scale, clip 1.0): no step skipped after the scale settles, finite loss, and the loss on the fixed batch falls."""

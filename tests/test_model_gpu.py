@@ -1079,3 +1079,136 @@ def test_layers_under_mpu_checkpoint_keep_the_outer_pass_weight_gradients():
     gradients with and without checkpointing; the CPU twin of this test runs on the emulated ops."""
     from tests.queue_cases import run_layers_under_checkpoint_case
     run_layers_under_checkpoint_case("cuda")
+
+
+# ------------------------------------------------------------------- two ranks, one GPU, the REFERENCE's construction (last in the file)
+def _dp2_reference_style_worker(rank, world, port, golden_dir, ret, with_optimizer):
+    """pretrain_gpt2.py:100-103 + :344-391 with USE_TORCH_DDP = True, spelled out: DDP(model, device_ids=[i], output_device=i,
+    process_group=...), the optimizer built AFTERWARDS and never introduced to the wrapper, no allreduce_params call anywhere."""
+    import sys
+    import traceback
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        if os.environ.get("COGV_EMULATE_GPU") == "1":      # development aid (tools/emulate_gpu_plugin.py): the spawned rank has no pytest plugin
+            import types
+            from tools import emulate_gpu_plugin
+            emulate_gpu_plugin.pytest_configure(types.SimpleNamespace())
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+        torch.cuda.set_device(0)
+        from cogview_amd import mpu, training
+        from cogview_amd.fp16 import FP16_Optimizer
+        from cogview_amd.model import PyTorchDistributedDataParallel as DDP, gpt2_get_params_for_weight_decay_optimization
+        from cogview_amd.optim import FusedAdam
+        mpu.initialize_model_parallel(1)
+        g = _golden(golden_dir)
+        S_, B_ = int(g["cfg"][5]), int(g["cfg"][6])
+        half = B_ // world
+        sl = slice(rank * half, (rank + 1) * half)
+        model = _build(g, torch.float16)
+        if rank == 1:                                   # the constructor's broadcast must bring rank 0's parameters
+            with torch.no_grad():
+                model.module.transformer.final_layernorm.weight.add_(0.5)
+        i = torch.cuda.current_device()
+        model = DDP(model, device_ids=[i], output_device=i, process_group=mpu.get_data_parallel_group())
+        assert model.auto_sync and model.overlap
+        pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(half, -1)
+        ones = torch.ones_like(g["loss_mask"][sl]).cuda()
+        batch = (g["tokens"][sl].cuda(), g["labels"][sl].cuda(), ones, 0, pos)
+        arena = model.module.module._cogv_arena
+
+        def all_equal(t):
+            flat = t.detach().float().cpu()
+            parts = [torch.empty_like(flat) for _ in range(world)]
+            dist.all_gather(parts, flat)
+            return all(torch.equal(parts[0], p) for p in parts[1:])
+
+        grads = None
+        if with_optimizer:
+            groups = gpt2_get_params_for_weight_decay_optimization(model.module.module)
+            for grp in groups:
+                for p in grp["params"]:
+                    if not hasattr(p, "model_parallel"):
+                        p.model_parallel = False
+            opt = FP16_Optimizer(FusedAdam(groups, lr=1e-3, weight_decay=0.01), dynamic_loss_scale=True,
+                                 dynamic_loss_args={"init_scale": 2 ** 10, "scale_window": 100, "min_scale": 1, "delayed_shift": 1})
+            assert opt._ddp is model and model._sync_consumer          # found on the arena, not introduced
+            for step in range(2):
+                loss, _, _, _ = training.forward_step(batch, model, log=False, world_size=world)
+                opt.zero_grad()                                         # pretrain_gpt2.py:354-356
+                opt.backward(loss, update_master_grads=False)
+                opt.update_master_grads()                               # :380
+                opt.clip_master_grads(1.0)                              # :387
+                torch.cuda.synchronize()
+                assert all_equal(arena.grad), f"step {step}: gradients differ across the replicas after update_master_grads"
+                if step == 0:
+                    grads = (arena.grad.detach().float() / opt.loss_scale).cpu()
+                opt.step()                                              # :430
+                assert not opt.overflow
+                torch.cuda.synchronize()
+                assert all_equal(arena.data), f"step {step}: replicas diverged"
+        else:
+            # no FP16_Optimizer (the reference's fp32 branch, :357-358): plain loss.backward(); the exchange is finished by the
+            # callback the wrapper queued on the autograd engine
+            assert not model._sync_consumer
+            for step in range(2):
+                arena.zero_grad()
+                loss, _, _, _ = training.forward_step(batch, model, log=False, world_size=world)
+                (loss * 1024.0).backward()
+                torch.cuda.synchronize()
+                assert not model.needs_reduction, "the end-of-backward callback did not run"
+                assert all_equal(arena.grad), f"pass {step}: gradients differ across the replicas after loss.backward()"
+            grads = (arena.grad.detach().float() / 1024.0).cpu()
+        assert all_equal(arena.data)
+        ret[rank] = ("ok", grads if rank == 0 else None)
+        dist.destroy_process_group()
+    except Exception:
+        ret[rank] = (traceback.format_exc(), None)
+
+
+@pytest.mark.parametrize("with_optimizer", [True, False], ids=["fp16_optimizer_self_attached", "engine_callback"])
+def test_two_rank_reference_style_ddp_finishes_the_exchange_unasked(golden_dir, with_optimizer):
+    """The reference's default data-parallel construction (pretrain_gpt2.py:100-103, model/distributed.py:26-32) on the GPU: two
+    processes share cuda:0 (gloo moves the CUDA slices).  Nobody calls allreduce_params / attach_data_parallel: with an
+    FP16_Optimizer the optimizer finds the wrapper on the arena and finishes the exchange in update_master_grads(); without
+    one the autograd-engine callback does.  Replicas must stay bit-identical over two steps and the averaged gradients must equal
+    those of ONE process on the whole batch (same bar as test_two_rank_data_parallel_step_on_one_gpu)."""
+    import socket
+    import torch.multiprocessing as mp
+    from cogview_amd import mpu, training
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_dp2_reference_style_worker, args=(r, 2, port, golden_dir, ret, with_optimizer))
+                 for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for r in range(2):
+            assert ret.get(r) is not None and ret[r][0] == "ok", f"rank {r}: {ret.get(r)}"
+        dp_grads = ret[0][1]
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29593")
+        dist.init_process_group("nccl", init_method="env://", world_size=1, rank=0)
+    if not mpu.model_parallel_is_initialized():
+        mpu.initialize_model_parallel(1)
+    g = _golden(golden_dir)
+    S_, B_ = int(g["cfg"][5]), int(g["cfg"][6])
+    model = _build(g, torch.float16)
+    pos = torch.arange(S_, device="cuda").unsqueeze(0).expand(B_, -1)
+    batch = (g["tokens"].cuda(), g["labels"].cuda(), torch.ones_like(g["loss_mask"]).cuda(), 0, pos)
+    loss, _, _, _ = training.forward_step(batch, model, log=False)
+    (loss * 1024.0).backward()
+    one = (model.module._cogv_arena.grad.detach().float() / 1024.0).cpu()
+    e = rel(dp_grads, one)
+    print(f"reference-style DDP ({'FP16_Optimizer' if with_optimizer else 'engine callback'}): two-rank averaged gradients vs "
+          f"one-rank whole batch, rel-L2: {e:.2e}")
+    assert e < 1e-2
