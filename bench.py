@@ -353,6 +353,7 @@ def run_gpt(args, dtype_name, world, rank, mp, parity=False):
 
     torch.manual_seed(1234)
     mpu.model_parallel_cuda_manual_seed(1234)
+    torch.cuda.reset_peak_memory_stats()                  # peak_hbm_gb is this leg's own high-water mark
     L, h, heads = CONFIGS[args.config]
     row = ROW_LEN.get(args.config, ROW)
     vocab = padded_vocab(mp)
@@ -415,6 +416,8 @@ def run_gpt(args, dtype_name, world, rank, mp, parity=False):
                    "logits_rel_l2_vs_fp32_reference": {"measured": None, "tolerance_in_tests": LOGITS_TOLERANCE[dtype_name]}},
         "model_tflops_per_gpu": value / world * fpt / 1e12,
         "mfma_roofline_frac_end_to_end": value / world * fpt / 1e12 / PEAK_MFMA_TFLOPS,
+        # HBM high-water mark of this rank over warm-up + timed steps (torch caching allocator; of 288 GB per MI355X)
+        "peak_hbm_gb": {"allocated": torch.cuda.max_memory_allocated() / 1e9, "reserved": torch.cuda.max_memory_reserved() / 1e9},
     }
     # SURVEY.md section 8(d)'s other two FLOP conventions for the same measured tokens/s: attention over the visible half of
     # the scores only, and the FLOPs the kernels execute (visited score blocks; + the recompute forward with --checkpoint-activations)

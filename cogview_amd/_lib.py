@@ -122,6 +122,7 @@ SIGNATURES = {
     "cogv_sandwich_ln_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "cogv_sandwich_ln_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _u64,
                                   _vp, _sz, _i, _vp]),
+    "cogv_sandwich_ln_bwd_marked": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _sz, _i, _vp]),
     "cogv_ln_bwd_workspace_bytes": (_sz, [_i, _i]),
     "cogv_ln_bwd_num_blocks": (_i, [_i]),
     "cogv_attention_fwd": (_i, [C.POINTER(AttnDesc), _vp]),

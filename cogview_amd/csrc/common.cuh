@@ -334,6 +334,29 @@ __device__ __forceinline__ void gelu_and_grad_f(float x, float& g, float& gd) {
   gd = fmaf(x * fmaf(-s, s, s), fmaf(C1, x2, C0), s);
 }
 
+// The same for TWO elements on the packed-fp32 VALU forms (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two IEEE operations per
+// issue slot, bit-identical to the scalar chain above -- only exp2 and rcp stay per element).  The GEMM epilogue that calls this
+// runs with ONE wave per SIMD (gemm_w4_kernel), i.e. it is bound by instruction ISSUE (one slot per ~4 cycles per wave), not by
+// the VALU's width: left to the SLP vectoriser only the tail of the chain was packed (x^2, the polynomial and the argument were
+// 24 scalar issues per 8 elements).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_and_grad_f2(f32x2_t x, f32x2_t& g, f32x2_t& gd) {
+  constexpr float K0 = -2.0f * 1.4426950408889634f * 0.7978845608028654f, K1 = K0 * 0.044715f;
+  constexpr float C0 = 2.0f * 0.7978845608028654f, C1 = C0 * 3.0f * 0.044715f;
+  const f32x2_t x2 = x * x;
+  const f32x2_t arg = x * __builtin_elementwise_fma(f32x2_t{K1, K1}, x2, f32x2_t{K0, K0});
+  const f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])} + f32x2_t{1.0f, 1.0f};
+  const f32x2_t s = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  g = x * s;
+  gd = __builtin_elementwise_fma(x * __builtin_elementwise_fma(-s, s, s), __builtin_elementwise_fma(f32x2_t{C1, C1}, x2, f32x2_t{C0, C0}), s);
+}
+__device__ __forceinline__ f32x2_t gelu_f2(f32x2_t x) {
+  constexpr float K0 = -2.0f * 1.4426950408889634f * 0.7978845608028654f, K1 = K0 * 0.044715f;
+  const f32x2_t arg = x * __builtin_elementwise_fma(f32x2_t{K1, K1}, x * x, f32x2_t{K0, K0});
+  const f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])} + f32x2_t{1.0f, 1.0f};
+  return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+
 static inline int cogv_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? COGV_OK : COGV_ERR_LAUNCH;

@@ -98,6 +98,11 @@ __device__ __forceinline__ void w4_epilogue(const GemmArgs& pg, f32x4 (&acc)[8][
   if (F < 0 || (F & COGV_EPI_DROPOUT)) { pin_s(p.seed); pin_s(p.stream_id); pin_s(p.thr16); pin_s(p.keep_scale); }
   if (F < 0) { pin_s(p.flags); pin_s(p.out_f32); pin_s(p.bias); }
   if (F == -2) pin_s(p.ws);
+  // (Round 6 measured a DIRECT store from the MFMA layout -- each lane packs the 8 values it holds of a row in two neighbouring
+  //  16-column blocks, the four lanes of a row write 64 contiguous bytes, no LDS transposition; it would need the DMA / the
+  //  transposing reads to permute the B rows so that those 8 values are consecutive columns.  16 rows x 64 B per store
+  //  instruction instead of 8 rows x 128 B is 4-24 % SLOWER on every 4B shape and 19-56 % on the 336M ones
+  //  (profiles/r06_gemm_direct_store_probe.log): the strip transposition stays.)
   const bool want_cs = (F == -1) ? ((p.flags & COGV_EPI_COLSUM) != 0 && !p.out_f32) : (F >= 0 && (F & COGV_EPI_COLSUM));
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int sr = lane >> 3, sc = lane & 7;           // read side: strip row, 8-column group

@@ -86,7 +86,11 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
       // 12 conversion instructions per 8 elements less in the most VALU-bound epilogue of the step.
       float gd[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) gelu_and_grad_f(v[i], v[i], gd[i]);
+      for (int i = 0; i < 8; i += 2) {
+        f32x2_t g2, d2;
+        gelu_and_grad_f2(f32x2_t{v[i], v[i + 1]}, g2, d2);
+        v[i] = g2[0]; v[i + 1] = g2[1]; gd[i] = d2[0]; gd[i + 1] = d2[1];
+      }
       if (p.aux) gstore16c<NT>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n, pack8<T>(gd));
     } else {
       // when the pre-activation is STORED, the activation is evaluated on its rounded value -- exactly what the backward
@@ -97,7 +101,10 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
         gstore16c<NT>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldaux + n, rv);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+      for (int i = 0; i < 8; i += 2) {
+        const f32x2_t g2 = gelu_f2(f32x2_t{v[i], v[i + 1]});
+        v[i] = g2[0]; v[i + 1] = g2[1];
+      }
     }
   }
   if (flags & COGV_EPI_DGELU) {
@@ -115,8 +122,18 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
   if ((flags & COGV_EPI_DROPOUT) && p.thr16) {
     const uint64_t e = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;   // n % 8 == 0
     const u32x4 r = Philox::gen(p.seed, p.stream_id, e >> 3);
+    // MARKED ZEROS (round 6): a dropped element is written as -0.0 and a kept element is never -0.0 -- a kept value that the
+    // 16-bit rounding would turn into a zero of either sign is written as +0.0.  Numerically nothing changes (-0 == +0 in
+    // every consumer), but the output now CARRIES its own keep mask: "16-bit pattern == 0x8000" <=> dropped, and the
+    // Sandwich-LN backward that follows (cogv_sandwich_ln_bwd_marked) reads the mask from x instead of re-hashing it.
+    // (DropTiny: |value| at or below it rounds to zero in T; bf16 uses FLT_MIN, i.e. also flushes fp32 denormals -- whatever
+    //  the conversion does with them, no kept element can come out as -0.)
+    constexpr float tiny = std::is_same<T, f16_t>::value ? 2.98023223876953125e-8f /* 2^-25 */ : 1.17549435e-38f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (drop_bits16(r, i) >= p.thr16) ? v[i] * p.keep_scale : 0.f;
+    for (int i = 0; i < 8; ++i) {
+      const float kept = v[i] * p.keep_scale;
+      v[i] = (drop_bits16(r, i) >= p.thr16) ? ((out_f32 || fabsf(kept) > tiny) ? kept : 0.f) : -0.f;
+    }
   }
   if (flags & COGV_EPI_ACCUM) {
     if (out_f32) {

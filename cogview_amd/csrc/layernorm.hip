@@ -117,7 +117,15 @@ struct LnBwdArgs {
   int rows, h;
   int want_colsum;
   uint64_t seed, stream_id; uint32_t thr16; float keep_scale;
+  int marked;              // the dropout mask is read from x: 16-bit pattern 0x8000 (-0.0) <=> dropped (cogv_sandwich_ln_bwd_marked)
 };
+
+// "dropped" test of element i of 8 raw 16-bit values (marked zeros: the GEMM dropout epilogue writes a dropped element as -0.0
+// and no kept element as -0.0, gemm_shared.cuh epilogue8)
+__device__ __forceinline__ bool marked_dropped(const u32x4& raw, int i) {
+  const uint32_t w = raw[i >> 1];
+  return (i & 1) ? ((w >> 16) == 0x8000u) : ((w & 0xffffu) == 0x8000u);
+}
 
 // Backward.  One workgroup of ceil(h / 512) waves covers a row: every lane owns 8 columns for the whole kernel, so
 // the three per-column accumulators (dgamma, dbeta, column sum of the output) are 24 registers per lane and need
@@ -131,12 +139,17 @@ struct LnBwdArgs {
 // x-hat in fp32 (8 per row) across the barrier -- 146 -> <= 128 registers, i.e. four waves per SIMD = three 5-wave workgroups
 // per CU instead of two.  The replay's hash and the column sums put ~170 VALU instructions on every row of this form (the
 // plain forms: ~90), so it needs more waves to keep the memory pipe busy; same arithmetic, bit-identical results.
-template <typename T, int R, int MODE, bool LEAN = false>
+// MARK (round 6; 16-bit x only): the keep mask is read from x's marked zeros instead of being re-hashed -- the hash, the
+// 64-bit element index and the 16-bit field compares leave the row's instruction stream (the raw x of the rows in flight is
+// kept for it, as in the lean form); bit-identical to the replay when x came from the marking GEMM epilogue.
+template <typename T, int R, int MODE, bool LEAN = false, bool MARK = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(LEAN ? 4 : (R == 2 ? 3 : 2))))
 void ln_bwd_kernel(const LnBwdArgs p) {
   typedef Row8<T, MODE == 2> DYR;
   typedef Row8<T, MODE == 1> XR;       // x, add_in, dx
   static_assert(!LEAN || MODE == 2, "the lean form keeps a 16-bit x raw");
+  static_assert(!MARK || MODE != 1, "marked zeros live in a 16-bit x");
+  constexpr bool KEEP_RAW = LEAN || MARK;
   __shared__ float red[2][R][8][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int col = threadIdx.x * 8;
@@ -168,7 +181,7 @@ void ln_bwd_kernel(const LnBwdArgs p) {
   };
   fetch(blockIdx.x * R);
   for (int row0 = blockIdx.x * R; row0 < p.rows; row0 += gridDim.x * R) {
-    typename XR::raw adv[R], xraw[LEAN ? R : 1];
+    typename XR::raw adv[R], xraw[KEEP_RAW ? R : 1];
     float rstd[R], s1[R], s2[R], mrk[R];
     float xhk[LEAN ? 1 : R][8], gyk[R][8];   // normalised input and gamma * dy of the rows in flight (kept for phase 2)
 #pragma unroll
@@ -177,7 +190,7 @@ void ln_bwd_kernel(const LnBwdArgs p) {
       float (&xh)[8] = LEAN ? xh1 : xhk[LEAN ? 0 : r];
       if (LEAN) unpack8<T>(graw, g);
       DYR::to_f(dyn[r], dy); XR::to_f(xn_[r], xh);
-      if (LEAN) xraw[r] = xn_[r];
+      if (KEEP_RAW) xraw[r] = xn_[r];
       if (!LEAN) adv[r] = adn[r];
       rstd[r] = rstdn[r];
       const float mr = meann[r] * rstdn[r];
@@ -221,7 +234,12 @@ void ln_bwd_kernel(const LnBwdArgs p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)        // (explicit fused multiply-add: the same contraction in every instantiation)
           o[i] = rstd[r] * fmaf(-(LEAN ? xh2[i] : xhk[LEAN ? 0 : r][i]), m2, gyk[r][i] - m1);
-        if (p.thr16) {
+        if (MARK) {
+          if constexpr (MARK) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = marked_dropped(xraw[r], i) ? 0.f : o[i] * p.keep_scale;
+          }
+        } else if (p.thr16) {
           const uint64_t e = (uint64_t)row * (uint64_t)p.h + (uint64_t)col;
           const u32x4 rn = Philox::gen(p.seed, p.stream_id, e >> 3);
 #pragma unroll
@@ -313,11 +331,28 @@ inline bool ln_bwd_lean() {
   const char* e = getenv("COGV_LN_BWD_LEAN");        // read per launch (A/B runs, tests)
   return e ? atoi(e) != 0 : COGV_LN_BWD_LEAN_DEFAULT != 0;
 }
+// rows in flight of the marked-zeros form at wide rows: 4 (the no-dropout geometry: one workgroup per CU) or 2 (the replay
+// form's geometry: lean, three workgroups per CU).  COGV_LN_BWD_MARKED_ROWS overrides.
+#ifndef COGV_LN_BWD_MARKED_ROWS_DEFAULT
+#define COGV_LN_BWD_MARKED_ROWS_DEFAULT 2
+#endif
+inline int ln_bwd_marked_rows() {
+  const char* e = getenv("COGV_LN_BWD_MARKED_ROWS");
+  return e ? atoi(e) : COGV_LN_BWD_MARKED_ROWS_DEFAULT;
+}
 template <typename T, int MODE> void launch_bwd_m(const LnBwdArgs& a, int blocks, hipStream_t st) {
   const int nw = (a.h + 511) / 512;             // waves per row (h <= 4096 -> <= 8)
   // wide rows with the dropout replay: two rows in flight at 128 registers (two workgroups per CU) beat four rows at
   // 206 (one per CU) -- 112 vs 129 us at h = 2560; without the replay four rows and one workgroup per CU win (109 vs 116)
-  if (MODE == 2 && nw >= 4 && a.thr16 && !a.add_in && ln_bwd_lean()) {
+  if (a.marked && a.thr16 && MODE != 1) {
+    if constexpr (MODE != 1) {
+      if (nw >= 4 && ln_bwd_marked_rows() == 4) hipLaunchKernelGGL((ln_bwd_kernel<T, 4, MODE, false, true>), dim3(blocks), dim3(nw * 64), 0, st, a);
+      else if (MODE == 2 && nw >= 4 && !a.add_in && ln_bwd_lean()) {
+        if constexpr (MODE == 2) hipLaunchKernelGGL((ln_bwd_kernel<T, 2, MODE, true, true>), dim3(blocks), dim3(nw * 64), 0, st, a);
+      } else if (nw >= 4) hipLaunchKernelGGL((ln_bwd_kernel<T, 2, MODE, false, true>), dim3(blocks), dim3(nw * 64), 0, st, a);
+      else hipLaunchKernelGGL((ln_bwd_kernel<T, 4, MODE, false, true>), dim3(blocks), dim3(nw * 64), 0, st, a);
+    }
+  } else if (MODE == 2 && nw >= 4 && a.thr16 && !a.add_in && ln_bwd_lean()) {
     if constexpr (MODE == 2) hipLaunchKernelGGL((ln_bwd_kernel<T, 2, MODE, true>), dim3(blocks), dim3(nw * 64), 0, st, a);
   } else if (nw >= 4 && (a.thr16 || (MODE == 1 && ln_bwd_stream_in_rows() == 2)))
     hipLaunchKernelGGL((ln_bwd_kernel<T, 2, MODE>), dim3(blocks), dim3(nw * 64), 0, st, a);
@@ -385,11 +420,11 @@ extern "C" int cogv_sandwich_ln_fwd(int dtype, const void* x, const void* gamma,
   return cogv_check_launch();
 }
 
-extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
-                                    const float* rstd, const void* add_in, void* dx, void* dgamma, void* dbeta,
-                                    void* colsum, int accumulate_param_grads, int rows, int h, float dropout_p,
-                                    uint64_t seed, uint64_t stream_id, void* workspace, size_t workspace_bytes,
-                                    int stream_mode, void* stream) {
+static int ln_bwd_impl(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
+                       const float* rstd, const void* add_in, void* dx, void* dgamma, void* dbeta,
+                       void* colsum, int accumulate_param_grads, int rows, int h, float dropout_p,
+                       uint64_t seed, uint64_t stream_id, void* workspace, size_t workspace_bytes,
+                       int stream_mode, void* stream, int marked) {
   if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
   if (stream_mode < 0 || stream_mode > 2) return COGV_ERR_ARG;
   if (rows <= 0 || h <= 0 || (h & 7) || h > 4096) return COGV_ERR_ARG;
@@ -400,13 +435,14 @@ extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, co
   LnBwdArgs a;
   a.dy = dy; a.x = x; a.gamma = gamma; a.mean = mean; a.rstd = rstd; a.add_in = add_in; a.dx = dx;
   a.partial = reinterpret_cast<float*>(workspace); a.rows = rows; a.h = h; a.want_colsum = colsum ? 1 : 0;
-  a.seed = seed; a.stream_id = stream_id;
+  a.seed = seed; a.stream_id = stream_id; a.marked = marked;
   a.thr16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
   // (the two-row STREAM_IN form without dropout replay keeps the one-workgroup-per-CU cap: 256 workgroups 167 us vs 178
   // with 512 at h = 2560, tools/r3/exp1.sh)
   int blocks = ln_bwd_blocks(rows, h, a.thr16 != 0);
-  if (stream_mode == COGV_LN_STREAM_OUT && a.thr16 && !add_in && (h + 511) / 512 >= 4 && ln_bwd_lean()) {
+  if (marked && a.thr16 && (h + 511) / 512 >= 4 && ln_bwd_marked_rows() == 4) blocks = ln_bwd_blocks(rows, h, false);
+  else if (stream_mode == COGV_LN_STREAM_OUT && a.thr16 && !add_in && (h + 511) / 512 >= 4 && ln_bwd_lean()) {
     // the lean dropout-replay form: three resident workgroups per CU (COGV_LN_BWD_BLOCKS still overrides)
     static const int forced = [] { const char* e = getenv("COGV_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
     if (forced <= 0) {
@@ -425,4 +461,22 @@ extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, co
       hipLaunchKernelGGL((ln_bwd_reduce_kernel<bf16_t>), grid, dim3(1024), 0, st, a.partial, blocks, h, dgamma, dbeta, colsum, accumulate_param_grads);
   }
   return cogv_check_launch();
+}
+
+extern "C" int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
+                                    const float* rstd, const void* add_in, void* dx, void* dgamma, void* dbeta,
+                                    void* colsum, int accumulate_param_grads, int rows, int h, float dropout_p,
+                                    uint64_t seed, uint64_t stream_id, void* workspace, size_t workspace_bytes,
+                                    int stream_mode, void* stream) {
+  return ln_bwd_impl(dtype, dy, x, gamma, mean, rstd, add_in, dx, dgamma, dbeta, colsum, accumulate_param_grads, rows, h,
+                     dropout_p, seed, stream_id, workspace, workspace_bytes, stream_mode, stream, 0);
+}
+
+extern "C" int cogv_sandwich_ln_bwd_marked(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
+                                           const float* rstd, const void* add_in, void* dx, void* dgamma, void* dbeta,
+                                           void* colsum, int accumulate_param_grads, int rows, int h, float dropout_p,
+                                           void* workspace, size_t workspace_bytes, int stream_mode, void* stream) {
+  if (stream_mode == COGV_LN_STREAM_IN) return COGV_ERR_ARG;        // the marks live in a 16-bit x
+  return ln_bwd_impl(dtype, dy, x, gamma, mean, rstd, add_in, dx, dgamma, dbeta, colsum, accumulate_param_grads, rows, h,
+                     dropout_p, 0, 0, workspace, workspace_bytes, stream_mode, stream, dropout_p > 0.f ? 1 : 0);
 }

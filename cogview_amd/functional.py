@@ -15,6 +15,7 @@ that buffer (the reference does each per tensor: 388 tensors for the 24-layer mo
 """
 import contextlib
 import math
+import os
 
 import torch
 
@@ -602,7 +603,11 @@ def _layer_backward(layer, kp, dout, sep):
     dout = dout if dout.is_contiguous() else dout.contiguous()
 
     # out = y + LN4(mo):  d_mo = mask(LN4'(dout)); bias grad of 4h->h = column sums of d_mo
-    d_mo = ops.sandwich_ln_bwd(dout, kp.mo, ln4.weight, *kp.st4, dropout=kp.d_mo, dgamma=G(ln4.weight),
+    # (kp.mo / kp.ao came out of the GEMM dropout epilogue: their dropped elements are -0.0, "marked zeros", and the two
+    #  dropout-side LayerNorm backwards read the mask from them instead of re-hashing it.  Under model parallelism the tensors
+    #  went through an all-reduce in between: there the mask is regenerated, as before.  COGV_LN_BWD_MARKED=0: always regenerate)
+    marked = mp_world_size_or_1() == 1 and os.environ.get("COGV_LN_BWD_MARKED", "1") != "0"
+    d_mo = ops.sandwich_ln_bwd(dout, kp.mo, ln4.weight, *kp.st4, dropout=kp.d_mo, dgamma=G(ln4.weight), marked=marked,
                                dbeta=G(ln4.bias), colsum=G(b2), accumulate=grad_accumulate(ln4.weight, ln4.bias, b2)).view(rows, h)
     # The four weight gradients dW = dY^T X are deferred to a grouped launch (flush_weight_grads): together their
     # 256x256 tiles fill whole rounds of the 256 CUs (each alone needs split-K slabs or idles half a round).
@@ -632,7 +637,7 @@ def _layer_backward(layer, kp, dout, sep):
     dy = ops.sandwich_ln_bwd(dc.view(b, s, h), kp.y, ln2.weight, *kp.st2, add_in=dout, dgamma=G(ln2.weight),
                              dbeta=G(ln2.bias), accumulate=grad_accumulate(ln2.weight, ln2.bias))
     # y = x + LN3(ao):  d_ao = mask(LN3'(dy))
-    d_ao = ops.sandwich_ln_bwd(dy, kp.ao, ln3.weight, *kp.st3, dropout=kp.d_ao, dgamma=G(ln3.weight),
+    d_ao = ops.sandwich_ln_bwd(dy, kp.ao, ln3.weight, *kp.st3, dropout=kp.d_ao, dgamma=G(ln3.weight), marked=marked,
                                dbeta=G(ln3.bias), colsum=G(bo), accumulate=grad_accumulate(ln3.weight, ln3.bias, bo)).view(rows, h)
     d_att = ops.gemm(d_ao, Wo, trans_b=True).view(b, s, npp, 64)
     _wg(d_ao, kp.att.view(rows, hp), Wo)

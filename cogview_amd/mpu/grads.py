@@ -26,7 +26,10 @@ def _chunk_tables(grads):
             gc = g.contiguous().view(-1)
             if gc.data_ptr() % 16:                  # a contiguous view at an odd offset: .contiguous() returned the view itself
                 gc = gc.clone()
-            out.append((gc, [(0, gc.numel())]))
+            # one workgroup reduces one chunk with fp32 partial sums: cut a large loose tensor into chunks of <= 1M elements
+            # (multiples of 8) so that the reduction is parallel and its accumulation error stays bounded
+            n, step = gc.numel(), 1 << 20
+            out.append((gc, [(o, min(step, n - o)) for o in range(0, n, step)] or [(0, 0)]))
     for (_, dtype), (st, chunks) in by_storage.items():
         flat = torch.empty(0, dtype=dtype, device=grads[0].device).set_(st, 0, (st.nbytes() // dtype.itemsize,))
         out.append((flat, sorted(chunks)))
@@ -44,6 +47,10 @@ def clip_grad_norm(parameters, max_norm, norm_type=2):
     if not parameters:
         return 0.0
     dev = parameters[0].grad.device
+    # DEVICE-ONLY for the two norms the training scripts use (2 and inf): they are HIP kernels (cogv_grad_stats / cogv_absmax) for
+    # 16-bit and fp32 gradients alike, and gradients on the CPU raise CogviewHipError there -- by design: a silent torch
+    # fallback on the product path would void the parity claims made for it (oracle/cogview_oracle.py clip_grad_norm is the
+    # CPU statement of this function).  Only the general p-norm below, which nothing on the training path asks for, is torch.
     mp = mp_world_size_or_1()
     if norm_type == inf:
         slot = ops.new_absmax_slot(dev)

@@ -95,6 +95,13 @@ class CudaRNGStatesTracker:
             if isinstance(st, _State):
                 new[name] = st.clone()
             else:
+                if isinstance(st, torch.Tensor) and (st.dtype == torch.uint8 or st.numel() != 2):
+                    # a checkpoint written by the REFERENCE: torch.cuda.get_rng_state() ByteTensors (mpu/random.py:163-168), a
+                    # generator state no kernel here can resume.  The reference's own load_checkpoint tells the user the same
+                    # thing when its states do not fit (utils.py:361-366)
+                    raise ValueError("rng tracker state '{}' is a torch CUDA generator state ({} x {}), not this package's "
+                                     "(seed, offset) pair: the checkpoint was written by another implementation -- load it "
+                                     "with --no-load-rng".format(name, st.numel(), st.dtype))
                 seed, offset = (int(v) for v in (st.tolist() if isinstance(st, torch.Tensor) else st))
                 new[name] = _State(seed, offset)
         self.states_ = new

@@ -178,10 +178,12 @@ class timed_launch:
     __slots__ = ("rec",)
 
     def __init__(self, family, flops, nbytes, label):
+        # flops / label may be callables: they are only evaluated while a timed region runs (~1500 launches per 4B step build
+        # their label strings for nothing otherwise)
         self.rec = None
         if _GEMM_TIMING is not None:
-            self.rec = [family, float(flops), float(nbytes), torch.cuda.Event(enable_timing=True),
-                        torch.cuda.Event(enable_timing=True), label]
+            self.rec = [family, float(flops() if callable(flops) else flops), float(nbytes), torch.cuda.Event(enable_timing=True),
+                        torch.cuda.Event(enable_timing=True), label() if callable(label) else label]
 
     def __enter__(self):
         if self.rec is not None:
@@ -428,7 +430,7 @@ def sandwich_ln_fwd(x, gamma, beta, eps, absmax_in, residual=None, absmax_out=No
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     # algorithmic HBM bytes: x + y (+ residual), each in its own width
     nbytes = rows * h * (x2.element_size() + y.element_size() + (r2.element_size() if r2 is not None else 0))
-    with timed_launch("layernorm", 0.0, nbytes, "ln_fwd " + _LN_MODE_NAME[mode] + (" + residual" if r2 is not None and mode == LN_ALL_T else "")):
+    with timed_launch("layernorm", 0.0, nbytes, lambda: "ln_fwd " + _LN_MODE_NAME[mode] + (" + residual" if r2 is not None and mode == LN_ALL_T else "")):
         L.check(L.lib().cogv_sandwich_ln_fwd(dt_code(gamma), _p(x2), _p(gamma), _p(beta), _p(r2), _p(y), _p(mean), _p(rstd),
                                              _p(absmax_in), _p(absmax_out), rows, h, float(eps), mode, _stream()),
                 "cogv_sandwich_ln_fwd")
@@ -436,8 +438,11 @@ def sandwich_ln_fwd(x, gamma, beta, eps, absmax_in, residual=None, absmax_out=No
 
 
 def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=None, dbeta=None, colsum=None,
-                    accumulate=False):
+                    accumulate=False, marked=False):
     """dx = [add_in +] mask(LN'(dy)).  dgamma/dbeta/colsum: preallocated [h] tensors (or None).
+    marked: x is the output of a gemm(..., dropout=...) -- its dropped elements are -0.0 and no kept element is -0.0, so
+    the mask is read from x (cogv_sandwich_ln_bwd_marked) instead of being regenerated from (seed, stream); `dropout`
+    still supplies p.  Bit-identical to the regenerating form on such an x.
     Stream forms by dtype, mirroring sandwich_ln_fwd: fp32 `x` (LN1, LN2: the saved stream) -> dx fp32, add_in fp32;
     fp32 `dy` (LN3, LN4: the stream's gradient) with a 16-bit x -> dx 16-bit."""
     _need_gpu(dy, x)
@@ -466,8 +471,17 @@ def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=
     ws = workspace("ln_bwd", nbytes, x.device)
     p, seed, sid = (0.0, 0, 0) if dropout is None else dropout
     nb = rows * h * (dy2.element_size() + x2.element_size() + dx.element_size() + (a2.element_size() if a2 is not None else 0))
-    label = "ln_bwd " + _LN_MODE_NAME[mode] + (" + dropout replay" if p > 0.0 else "") + (" + add" if a2 is not None else "")
+    marked = bool(marked) and p > 0.0
+    if marked and mode == LN_STREAM_IN:
+        raise L.CogviewHipError("Sandwich-LN backward: marked zeros need a 16-bit x")
+    label = lambda: "ln_bwd " + _LN_MODE_NAME[mode] + ((" + dropout from marked zeros" if marked else " + dropout replay") if p > 0.0 else "") + \
+        (" + add" if a2 is not None else "")
     with timed_launch("layernorm", 0.0, nb, label):
+        if marked:
+            L.check(lib.cogv_sandwich_ln_bwd_marked(dt_code(gamma), _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(a2), _p(dx),
+                                                    _p(dgamma), _p(dbeta), _p(colsum), int(accumulate), rows, h, float(p),
+                                                    _p(ws), ws.numel(), mode, _stream()), "cogv_sandwich_ln_bwd_marked")
+            return dx.view(x.shape)
         L.check(lib.cogv_sandwich_ln_bwd(dt_code(gamma), _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(a2), _p(dx),
                                          _p(dgamma), _p(dbeta), _p(colsum), int(accumulate), rows, h, float(p), int(seed),
                                          int(sid), _p(ws), ws.numel(), mode, _stream()), "cogv_sandwich_ln_bwd")
@@ -555,8 +569,8 @@ def attention_fwd(q, k, v, sep=0, dropout=None, kv_index=None, sparse=None, keep
     if keep_bits and STORE_KEEP_BITS and dropout is not None and dropout[0] > 0.0 and kv_index is None and sparse is None and mask is None:
         bits = torch.empty(L.lib().cogv_attention_keep_bits_bytes(b, H, s_q, k.shape[1]), dtype=torch.uint8, device=q.device)
         d.keep_bits = bits.data_ptr()
-    fl = 0.0 if _GEMM_TIMING is None else attention_executed_flops(b, H, s_q, d.s_k, sep, dense=(kv_index is None and sparse is None and mask is None))
-    with timed_launch("attention", fl, 0.0, f"attn_fwd {b}x{H}x{s_q}x{d.s_k}" + (" dropout" if dropout is not None else "")):
+    with timed_launch("attention", lambda: attention_executed_flops(b, H, s_q, d.s_k, sep, dense=(kv_index is None and sparse is None and mask is None)),
+                      0.0, lambda: f"attn_fwd {b}x{H}x{s_q}x{d.s_k}" + (" dropout" if dropout is not None else "")):
         L.check(L.lib().cogv_attention_fwd(C.byref(d), _stream()), "cogv_attention_fwd")
     return (o, lse, bits) if keep_bits else (o, lse)
 
@@ -693,8 +707,8 @@ def attention_bwd(dout, q, k, v, o, lse, sep=0, dropout=None, dq=None, dk=None, 
         ws = workspace("attn_colsum", rows * 3 * H * 64 * 4, q.device)
         d.colsum_partial = ws.data_ptr()
     # 5 block products against the forward's 2
-    fl = 0.0 if _GEMM_TIMING is None else 2.5 * attention_executed_flops(b, H, s_q, k.shape[1], sep, dense=mask is None)
-    with timed_launch("attention", fl, 0.0, f"attn_bwd {b}x{H}x{s_q}x{k.shape[1]} (D, dQ, dK.dV)" + (" dropout" if dropout is not None else "")):
+    with timed_launch("attention", lambda: 2.5 * attention_executed_flops(b, H, s_q, k.shape[1], sep, dense=mask is None), 0.0,
+                      lambda: f"attn_bwd {b}x{H}x{s_q}x{k.shape[1]} (D, dQ, dK.dV)" + (" dropout" if dropout is not None else "")):
         L.check(L.lib().cogv_attention_bwd(C.byref(d), _stream()), "cogv_attention_bwd")
     if fuse:
         L.check(L.lib().cogv_colsum_finalize(dt_code(q), d.colsum_partial, rows, 3 * H * 64, _p(colsum_out),

@@ -148,6 +148,16 @@ int cogv_sandwich_ln_bwd(int dtype, const void* dy, const void* x, const void* g
                          const float* rstd, const void* add_in, void* dx, void* dgamma, void* dbeta, void* colsum,
                          int accumulate_param_grads, int rows, int h, float dropout_p, uint64_t seed,
                          uint64_t stream_id, void* workspace, size_t workspace_bytes, int stream_mode, void* stream);
+/* The same with the dropout mask READ FROM x (round 6; COGV_LN_ALL_T / COGV_LN_STREAM_OUT: x is 16-bit): cogv_gemm's dropout
+ * epilogue (COGV_EPI_DROPOUT) writes every dropped element as -0.0 and never writes a kept element as -0.0 ("marked zeros";
+ * numerically the reference's dropout(x), mpu/sparse_transformer.py:163-168,231-233), so "16-bit pattern 0x8000" IS the forward
+ * mask and the backward of the Sandwich-LN that follows that GEMM (mpu/sparse_transformer.py:326-329,337-340) needs neither
+ * the generator nor stored bits.  dropout_p only supplies the scale 1 / (1 - p) (same 16-bit threshold arithmetic as the
+ * replaying form; 0 = no dropout).  Bit-identical to cogv_sandwich_ln_bwd with the producing GEMM's (p, seed, stream). */
+int cogv_sandwich_ln_bwd_marked(int dtype, const void* dy, const void* x, const void* gamma, const float* mean,
+                                const float* rstd, const void* add_in, void* dx, void* dgamma, void* dbeta, void* colsum,
+                                int accumulate_param_grads, int rows, int h, float dropout_p, void* workspace,
+                                size_t workspace_bytes, int stream_mode, void* stream);
 size_t cogv_ln_bwd_workspace_bytes(int rows, int h);
 int cogv_ln_bwd_num_blocks(int rows);   /* upper bound of the backward kernel's workgroup count (workspace sizing) */
 

@@ -87,6 +87,9 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
     if accumulate:
         c = c + out.float()
     out.copy_(c)
+    if keep is not None and not accumulate and out.dtype != torch.float32:
+        # marked zeros (gemm_shared.cuh epilogue8): dropped -> -0.0, a kept value that rounds to a zero -> +0.0
+        out.copy_(torch.where(keep == 0, torch.full_like(out, -0.0), torch.where(out == 0, torch.zeros_like(out), out)))
     _publish(absmax, out)
     if colsum_out is not None:
         colsum(out, out=colsum_out, accumulate=colsum_accumulate)
@@ -136,13 +139,19 @@ def _accum_param_grad(dst, val, accumulate):
         dst.copy_(val + dst.float() if accumulate else val)
 
 
-def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=None, dbeta=None, colsum=None, accumulate=False):
+def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=None, dbeta=None, colsum=None, accumulate=False,
+                    marked=False):
     h = x.shape[-1]
     dyf, xf = dy.reshape(-1, h).float(), x.reshape(-1, h).float()
     xh = (xf - mean[:, None]) * rstd[:, None]
     g = dyf * gamma.float()
     dx = rstd[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
     keep = _keep(dx.shape, dropout)                                  # dx = [add_in +] mask(LN'(dy)): the producing GEMM's dropout, replayed
+    if marked and keep is not None:                                  # ... or read from x's marked zeros (-0.0 <=> dropped)
+        dropped = (x.reshape(-1, h) == 0) & torch.signbit(x.reshape(-1, h))
+        p_ = int(float(dropout[0]) * 65536.0 + 0.5)
+        from_x = torch.where(dropped, torch.zeros((), dtype=torch.float32), torch.tensor(65536.0 / (65536.0 - p_), dtype=torch.float32))
+        assert torch.equal(from_x, keep.float().view(from_x.shape)), "marked zeros of x disagree with the regenerated mask"
     if keep is not None:
         dx = dx * keep
     if add_in is not None:

@@ -710,3 +710,18 @@ def test_checkpoint_with_a_reference_path_loss_scaler_unpickles_without_binding(
     got = sd["optimizer"]["loss_scaler"]
     assert type(got) is LS.DynamicLossScaler and got.__dict__ == scaler.__dict__
     assert "fp16" not in sys.modules and "fp16.loss_scaler" not in sys.modules
+
+
+def test_rng_tracker_refuses_a_reference_written_state_with_a_usable_message():
+    """A checkpoint written by the REFERENCE carries torch.cuda.get_rng_state() ByteTensors under 'rng_tracker_states'
+    (mpu/random.py:163-168); resuming from it must fail with an error that names --no-load-rng (utils.py:361-366 tells the
+    reference's users the same), not with an unpacking ValueError."""
+    from cogview_amd.mpu.random import CudaRNGStatesTracker
+    tr = CudaRNGStatesTracker()
+    tr.add("model-parallel-rng", 4242)
+    good = tr.get_states()
+    tr2 = CudaRNGStatesTracker()
+    tr2.set_states(good)                                                 # this package's own (seed, offset) pairs round-trip
+    assert {k: v.tolist() for k, v in tr2.get_states().items()} == {k: v.tolist() for k, v in good.items()}
+    with pytest.raises(ValueError, match="--no-load-rng"):
+        tr2.set_states({"model-parallel-rng": torch.zeros(816, dtype=torch.uint8)})

@@ -351,3 +351,70 @@ def test_layernorm_backward_lean_dropout_replay_form_equals_the_regular_one(dtyp
     assert abs(float((res["1"][0] == 0).float().mean()) - 0.1) < (0.02 if rows > 100 else 0.1)
     for a, b in zip(res["0"][1:], res["1"][1:]):
         assert ((a.float() - b.float()).norm() / (a.float().norm() + 1e-30)).item() < 2e-3
+
+
+def _bits16(t):
+    return t.contiguous().view(torch.int16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(300, 2560, 128), (1100, 1024, 64), (70, 256, 64), (256, 2560, 2560)])
+def test_gemm_dropout_epilogue_marks_dropped_elements_with_minus_zero(ops, dtype, M, N, K):
+    """Marked zeros (round 6, gemm_shared.cuh epilogue8): the GEMM dropout epilogue writes a dropped element as -0.0 (16-bit
+    pattern 0x8000) and NO kept element as -0.0 -- so the output carries the oracle's keep mask bit for bit -- in every GEMM
+    generation the shapes select (256-tile persistent kernel, the smaller tiles, K not a multiple of 256).  Column 0 of the weight
+    is built so that kept outputs of column 0 underflow to a NEGATIVE value below the storage type's smallest subnormal
+    (fp16; an fp32 denormal for bf16): rounding alone would produce -0.0 there; they must come out as +0.0."""
+    g = torch.Generator().manual_seed(M + N)
+    a, w = rnd((M, K), dtype, g), rnd((N, K), dtype, g, 0.05)
+    bias = rnd((N,), dtype, g, 0.1)
+    tiny = 1e-9 if dtype == torch.float16 else 1e-30
+    w[0].zero_(); w[0, 0] = -(tiny ** 0.5) if dtype == torch.float16 else -1e-20
+    a[:, 0] = (tiny ** 0.5) if dtype == torch.float16 else 1e-20        # bf16: 1e-20 * -1e-20 = -1e-40, an fp32 denormal
+    bias[0] = 0.0
+    mask = torch.from_numpy(O.dropout_keep_mask(M * N, 0.1, 11, 6)).view(M, N)
+    slot = ops.new_absmax_slot(torch.device("cuda"))
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), dropout=(0.1, 11, 6), absmax=slot)
+    marked = (_bits16(out).cpu() == -32768)                               # 0x8000
+    assert torch.equal(marked, mask == 0)
+    col0 = out[:, 0].cpu()
+    assert bool((col0 == 0).all()) and torch.equal(torch.signbit(col0), mask[:, 0] == 0)
+    ref = (a.float() @ w.float().t() + bias.float()) * mask
+    assert rel(out, ref) < TOL[dtype]
+    assert abs(slot.item() - out.float().abs().max().item()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,h,stream_out", [(7, 2560, True), (1000, 2560, True), (26112, 2560, True), (300, 1024, True),
+                                               (70, 256, True), (130, 2560, False), (300, 1024, False)])
+def test_layernorm_backward_reads_the_mask_from_marked_zeros_bit_identically(ops, dtype, rows, h, stream_out):
+    """cogv_sandwich_ln_bwd_marked (round 6): LN3' / LN4' take the hidden-dropout mask from their input's marked zeros instead of
+    re-hashing it.  x is a real output of the marking GEMM epilogue; dx must be bit-identical to the regenerating form with the
+    GEMM's (p, seed, stream), and so must dgamma / dbeta / column sums (same kernel structure, same summation order).  Both
+    stream forms (fp32 gradient in, and all-16-bit), lean / two-row / four-row kernels (h = 2560 / 1024 / 256)."""
+    g = torch.Generator().manual_seed(rows + h)
+    K = 64
+    a, w = rnd((rows, K), dtype, g), rnd((h, K), dtype, g, 0.2)
+    drop = (0.1, 21, 8)
+    slot = ops.new_absmax_slot(torch.device("cuda"))
+    x = ops.gemm(a.cuda(), w.cuda(), dropout=drop, absmax=slot)
+    gam = (torch.rand(h, generator=g) + 0.5).to(dtype).cuda()
+    bet = torch.zeros(h, dtype=dtype, device="cuda")
+    if stream_out:
+        stream = torch.randn(rows, h, generator=g).cuda()
+        dy = torch.randn(rows, h, generator=g).cuda()
+        _, mean, rstd = ops.sandwich_ln_fwd(x, gam, bet, 1e-5, slot, residual=stream)
+        add = None
+    else:
+        dy = rnd((rows, h), dtype, g).cuda()
+        _, mean, rstd = ops.sandwich_ln_fwd(x, gam, bet, 1e-5, slot)
+        add = rnd((rows, h), dtype, g).cuda() if rows == 130 else None
+    res = []
+    for marked in (False, True):
+        dg, db, cs = (torch.zeros(h, dtype=dtype, device="cuda") for _ in range(3))
+        dx = ops.sandwich_ln_bwd(dy, x, gam, mean, rstd, add_in=add, dropout=drop, dgamma=dg, dbeta=db, colsum=cs, marked=marked)
+        res.append((dx, dg, db, cs))
+    for u, v in zip(res[0], res[1]):
+        assert torch.equal(_bits16(u), _bits16(v))
+    if add is None:
+        assert abs(float((res[1][0] == 0).float().mean()) - 0.1) < (0.02 if rows > 100 else 0.1)

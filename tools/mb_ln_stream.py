@@ -31,6 +31,9 @@ for h, b in ((1024, 30), (2560, 24)):
     rec("fwd_all16_res", lambda: ops.sandwich_ln_fwd(x16, g_, b_, 1e-5, am16, residual=dy16, absmax_out=slot), B * 6)
     rec("bwd_LN1_stream_in_add", lambda: ops.sandwich_ln_bwd(dy16, x32, g_, mean, rstd, add_in=r32, dgamma=dg, dbeta=db, accumulate=True), B * 14)
     rec("bwd_LN4_stream_out_drop_colsum", lambda: ops.sandwich_ln_bwd(dy32, x16, g_, mean, rstd, dropout=(0.1, 1, 2), dgamma=dg, dbeta=db, colsum=cs, accumulate=True), B * 8)
+    x16m = torch.where(torch.rand(M, h, device="cuda") < 0.1, torch.full_like(x16, -0.0), x16)      # marked zeros: 10 % dropped
+    rec("bwd_LN4_stream_out_marked_colsum", lambda: ops.sandwich_ln_bwd(dy32, x16m, g_, mean, rstd, dropout=(0.1, 1, 2), dgamma=dg, dbeta=db, colsum=cs, accumulate=True, marked=True), B * 8)
+    rec("bwd_LN4_stream_out_nodrop_colsum", lambda: ops.sandwich_ln_bwd(dy32, x16, g_, mean, rstd, dgamma=dg, dbeta=db, colsum=cs, accumulate=True), B * 8)
     rec("bwd_all16_add", lambda: ops.sandwich_ln_bwd(dy16, x16, g_, mean, rstd, add_in=dy16, dgamma=dg, dbeta=db, accumulate=True), B * 8)
     rec("bwd_all16_drop_colsum", lambda: ops.sandwich_ln_bwd(dy16, x16, g_, mean, rstd, dropout=(0.1, 1, 2), dgamma=dg, dbeta=db, colsum=cs, accumulate=True), B * 6)
     print(json.dumps(row), flush=True)

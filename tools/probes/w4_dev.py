@@ -76,7 +76,9 @@ if __name__ == "__main__":
     elif sys.argv[1] == "run":
         for tag in sys.argv[2:]:
             env = dict(os.environ)
-            if tag != "prod":
+            if os.path.exists(tag):                       # a library path (e.g. build/ab/libcogview_<x>.so)
+                env["COGVIEW_HIP_LIB"] = os.path.abspath(tag)
+            elif tag != "prod":
                 env["COGVIEW_HIP_LIB"] = os.path.join(OUT, f"lib{tag}.so")
             subprocess.run([sys.executable, os.path.abspath(__file__), "one", tag], env=env)
     else:
