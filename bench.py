@@ -41,9 +41,11 @@ CONFIGS = {
 }
 ROW_LEN = {"cogview-tiny-18M": 256}            # tokens per data row (default ROW = 1089)
 # per-GPU micro-batch (sequences): b x 1088 rows must fill whole rounds of 256-row GEMM tiles on 256 CUs.
-#   336M: 30 x 1088 = 127.5 -> 128 row tiles;  4B: 24 x 1088 = 102 row tiles exactly, and 102 x {10, 30, 40}
-#   column tiles of 256 are 3.98 / 11.95 / 15.94 rounds (activations 129 GB + 64 GB of model state < 288 GB)
-DEFAULT_BATCH = {"cogview-small-336M": 30, "cogview-base-4B": 24, "cogview-tiny-18M": 4}
+#   30 x 1088 = 127.5 -> 128 row tiles, and 128 x {10, 30, 40} column tiles of 256 are exactly 5 / 15 / 20 rounds.  4B since
+#   round 6 (24 before: 102 row tiles, 3.98 / 11.95 / 15.94 rounds): the fixed 19 ms of the optimizer pass are spread over 25 %
+#   more tokens -- +0.8 % tokens/s in alternating runs (profiles/r06_batch_24_vs_30.log); HBM high-water mark 239 GB allocated /
+#   255 GB reserved of 288 (204 / 219 at 24), reported by every run as peak_hbm_gb.
+DEFAULT_BATCH = {"cogview-small-336M": 30, "cogview-base-4B": 30, "cogview-tiny-18M": 4}
 METRIC = {"cogview-base-4B": "train tokens/sec/node (seq1089, 4B GPT) at 1/2/4/8 MI355X; % MFMA roofline",
           "cogview-small-336M": "train tokens/sec/node (seq1089, 336M GPT) at 1/2/4/8 MI355X; % MFMA roofline",
           "cogview-tiny-18M": "train tokens/sec/node (seq256, 18M GPT, BASELINE configs[0]) at 1/2/4/8 MI355X; % MFMA roofline"}

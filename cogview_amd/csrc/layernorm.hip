@@ -332,9 +332,11 @@ inline bool ln_bwd_lean() {
   return e ? atoi(e) != 0 : COGV_LN_BWD_LEAN_DEFAULT != 0;
 }
 // rows in flight of the marked-zeros form at wide rows: 4 (the no-dropout geometry: one workgroup per CU) or 2 (the replay
-// form's geometry: lean, three workgroups per CU).  COGV_LN_BWD_MARKED_ROWS overrides.
+// form's geometry: lean, three workgroups per CU).  COGV_LN_BWD_MARKED_ROWS overrides.  h = 2560, 26112 rows, LN4' with column
+// sums (profiles/r06_ln_marked_zeros_rows_ab.log): replaying form 116.6 us (4.59 TB/s), marked two rows 125.0, marked four rows
+// 110.2 (4.85 TB/s), no dropout at all 107.5 -- the hash was never the bound, the rows in flight are.
 #ifndef COGV_LN_BWD_MARKED_ROWS_DEFAULT
-#define COGV_LN_BWD_MARKED_ROWS_DEFAULT 2
+#define COGV_LN_BWD_MARKED_ROWS_DEFAULT 4
 #endif
 inline int ln_bwd_marked_rows() {
   const char* e = getenv("COGV_LN_BWD_MARKED_ROWS");

@@ -49,8 +49,8 @@ def clip_grad_norm(parameters, max_norm, norm_type=2):
     dev = parameters[0].grad.device
     # DEVICE-ONLY for the two norms the training scripts use (2 and inf): they are HIP kernels (cogv_grad_stats / cogv_absmax) for
     # 16-bit and fp32 gradients alike, and gradients on the CPU raise CogviewHipError there -- by design: a silent torch
-    # fallback on the product path would void the parity claims made for it (oracle/cogview_oracle.py clip_grad_norm is the
-    # CPU statement of this function).  Only the general p-norm below, which nothing on the training path asks for, is torch.
+    # fallback on the product path would void the parity claims made for it (the CPU statement of this function lives with the
+    # test infrastructure, not here).  Only the general p-norm below, which nothing on the training path asks for, is torch.
     mp = mp_world_size_or_1()
     if norm_type == inf:
         slot = ops.new_absmax_slot(dev)

@@ -10,6 +10,8 @@
 #                             -> profiles/rNN_bench_4B_b24_fp16_kernel_stats.csv
 #   traffic [bench args]      HBM-side traffic of the GEMM family: FETCH_SIZE / WRITE_SIZE in separate --pmc passes, gfx950 x2
 #                             read correction (tools/collect_traffic.sh) -> profiles/rNN_gemm_hbm_traffic_pmc_4B_b24.json
+#   mall                      Infinity-Cache hits vs HBM reads of the GEMM family from the L2's memory-side read latency
+#                             (tools/mall_probe.py) -> profiles/rNN_gemm_mall_vs_hbm.txt
 #   pmc-gemm                  counters of gemm_w4_kernel on the step's launches with their real epilogues (MFMA busy, clock,
 #                             wave-cycle split) -> profiles/rNN_gemm_w4_pmc_mfma_busy_clock.txt
 #   pmc-attn                  counters of the three dense attention kernels at the bench shape (stored keep bits): MFMA / VALU
@@ -51,6 +53,11 @@ kernel-stats)
   cp $(ls $OUT/kstats/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv; head -14 $OUT/kernel_stats.csv | cut -c1-170 ;;
 traffic)
   bash tools/collect_traffic.sh "$@" | tail -5; cp gpurun_out/gemm_traffic.json $OUT/gemm_hbm_traffic_pmc.json ;;
+mall)
+  # Infinity-Cache (MALL) hits vs HBM reads of the GEMM family, from the L2's memory-side read latency (tools/mall_probe.py)
+  rm -rf $OUT/mall
+  prof rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum --kernel-trace --output-format csv -d $OUT/mall -- python $R/tools/mall_probe.py run > $OUT/mall.log 2>&1
+  python tools/mall_probe.py report $OUT/mall | tee $OUT/gemm_mall_vs_hbm.txt ;;
 pmc-gemm)
   rm -rf $OUT/pmc_gemm_a $OUT/pmc_gemm_b
   prof rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_gemm_a -- python $R/tools/mb_gemm_ab.py pmc > $OUT/pmc_gemm_a.log 2>&1
