@@ -223,7 +223,8 @@ __device__ __forceinline__ void mask_frag(f32x16& a, int lim, int lim_sep, int b
 // Attention dropout bits.  One 64-bit draw per (attention row arow = (b*H+head)*s_q + q, group g = key >> 2 of 4
 // consecutive keys); element i = key & 3 takes bits 16 (i & 1) .. +15 of word i >> 1:
 //     rk   = pcg32((lo32(arow) ^ key) + hi32(arow) * 0x85EBCA6B)            per row, once per kernel
-//     w    = rk + g * 0x9E3779B9;  (x, y) = attn_bits_w(w): one xorshift-multiply-xorshift round per word, see below
+//     x    = rk + g * 0x9E3779B9;  x ^= x >> 15;  x *= 0x2C1B3C6D;  x ^= x >> 12          word 0
+//     y    = (x ^ 0x68E31DA4) * 0x297A2D39;  y ^= y >> 15                                   word 1
 // The row hash carries the quality (PCG); the per-draw part is a Weyl step (an ADD per draw when g advances by a
 // constant, as it does along a lane's keys in the forward and dQ kernels) and one multiply-xorshift round per word --
 // 16 instruction slots per draw where the former generator (PCG + xorshift32 on a 64-bit counter with carry) took 28,
@@ -233,21 +234,17 @@ struct RowKey { uint32_t rk; };
 __device__ __forceinline__ RowKey row_key(uint32_t key, unsigned long long arow) {
   return RowKey{pcg32(((uint32_t)arow ^ key) + (uint32_t)(arow >> 32) * 0x85EBCA6Bu)};
 }
-// Round 6: the two multiplies are 24-BIT multiplies (v_mul_u32_u24, full rate; v_mul_lo_u32 is a quarter-rate instruction: the
-// two of them were 8 of the draw's ~16 issue slots in a forward kernel that is bound by VALU issue, profiles/r05_attention_pmc.txt):
-//     a = w ^ (w >> 15);  x = lo32(a[23:0] * 0xD35A2D);  x ^= x >> 13                            word 0
-//     y = lo32((x ^ 0x68E31DA4)[23:0] * 0xB5297A);  y ^= y >> 14                                  word 1
-// The xor-shift in front of each multiply folds the operand's top bits into the 24 that enter it.  A draw now has 24 bits of
-// state (4.5 M draws hit 3.9 M distinct values where the 32-bit form hit all of them); keep rate, neighbour correlations along
-// keys / rows / inside a draw and byte histograms measure at the noise level next to the former generator
-// (profiles/r06_attention_dropout_generator_statistics.txt).  oracle/cogview_oracle.py::attention_keep_mask restates it.
+// (Round 6 measured the same round on 24-BIT multiplies -- v_mul_u32_u24, on the theory that the two v_mul_lo_u32 are quarter-rate
+//  and half of the draw's issue slots: forward 349.6 vs 349.6 and 348.4 vs 346.1 us in alternating processes at the bench shape,
+//  profiles/r06_attention_mul24_generator_ab.log.  The multiplies are not what bounds the forward kernel; the 32-bit round, whose
+//  draws keep 32 bits of state, stays.)
 __device__ __forceinline__ u32x2 attn_bits_w(uint32_t w) {          // w = rk + g * 0x9E3779B9
   u32x2 o;
-  const uint32_t a = w ^ (w >> 15);
-  uint32_t x = __umul24(a, 0xD35A2Du);
-  x ^= x >> 13;
-  uint32_t y = __umul24(x ^ 0x68E31DA4u, 0xB5297Au);
-  y ^= y >> 14;
+  uint32_t x = w ^ (w >> 15);
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  uint32_t y = (x ^ 0x68E31DA4u) * 0x297A2D39u;
+  y ^= y >> 15;
   o[0] = x; o[1] = y;
   return o;
 }

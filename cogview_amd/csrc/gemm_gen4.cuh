@@ -91,7 +91,7 @@ template <typename T, int F>
 __device__ __forceinline__ void w4_epilogue(const GemmArgs& pg, f32x4 (&acc)[8][4], char* strip, int m_base, int n_base,
                                             int ksplit, int lane, uint32_t& amax_pk, int colsum_row, bool land_dma_first) {
   const int l15 = lane & 15, kb = lane >> 4;
-  if ((COGV_EXP & 2048) && lane == 65) return;                    // probe: no epilogue at all
+  if ((COGV_EXP & 2048) && acc[0][0][0] != 12345.f) return;      // probe: no epilogue at all (a run-time condition the compiler cannot fold)
   GemmArgs p = pg;
   pin_s(p.C); pin_s(p.M); pin_s(p.N); pin_s(p.ldc);
   if (F < 0 || (F & (COGV_EPI_GELU | COGV_EPI_DGELU | COGV_EPI_MULAUX))) { pin_s(p.aux); pin_s(p.ldaux); }

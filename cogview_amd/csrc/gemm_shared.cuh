@@ -58,8 +58,12 @@ __device__ __forceinline__ void gstore16(float* q, f32x4 v) { *(COGV_GLOBAL f32x
 // round of tiles -- the size of its L2 -- through a write-allocating cache that also holds the operand panels.  Measured against
 // plain stores in alternating processes (profiles/r04_gemm_nt_store_ab.log): QKV forward +1.7 %, GeLU + stored gelu' +2.5 % (+3-4 % at
 // K = 1024), the other forward / dgrad launches 0 .. +1 %; the accumulating weight gradient, which reads C back, -0.4 % (kept plain).
+#ifndef COGV_EXP
+#define COGV_EXP 0        // probe builds only (gemm.hip documents the bits); 32768: the epilogue computes but does not store C / aux
+#endif
 template <bool NT>
 __device__ __forceinline__ void gstore16c(void* q, u32x4 v) {
+  if (COGV_EXP & 32768) { asm volatile("" : : "v"(v), "v"(q)); return; }
   if (NT) __builtin_nontemporal_store(v, (COGV_GLOBAL u32x4*)q); else *(COGV_GLOBAL u32x4*)q = v;
 }
 

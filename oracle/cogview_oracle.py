@@ -368,18 +368,13 @@ def dropout_keep_mask(n_elements, p, seed, stream):
     return keep.astype(np.float32) * np.float32(65536.0 / (65536.0 - thr))
 
 
-def _mul24(a, c):
-    """v_mul_u32_u24: low 32 bits of the product of the operands' low 24 bits."""
-    return ((np.asarray(a).astype(np.uint64) & np.uint64(0xFFFFFF)) * np.uint64(c & 0xFFFFFF) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-
-
 def attention_keep_mask(b, heads, s_q, s_k, p, seed, stream):
     """Scaled keep mask [b, heads, s_q, s_k] of the attention convention (cogview_amd/csrc/attention.hip, "Attention
     dropout bits"): one 64-bit draw per (attention row, 4 consecutive keys); the row is hashed once with PCG, the key
     group enters as a Weyl step and each of the two words gets one multiply-xorshift round:
-        rk = pcg32((lo32(row) ^ key) + hi32(row) * 0x85EBCA6B);  w = rk + (key // 4) * 0x9E3779B9
-        a = w ^ (w >> 15); x = lo32(a[23:0] * 0xD35A2D); x ^= x >> 13          (word 0; 24-bit multiplies since round 6)
-        y = lo32((x ^ 0x68E31DA4)[23:0] * 0xB5297A); y ^= y >> 14              (word 1)
+        rk = pcg32((lo32(row) ^ key) + hi32(row) * 0x85EBCA6B);  x = rk + (key // 4) * 0x9E3779B9
+        x ^= x >> 15; x *= 0x2C1B3C6D; x ^= x >> 12                  (word 0)
+        y = (x ^ 0x68E31DA4) * 0x297A2D39; y ^= y >> 15              (word 1)
     element i = key & 3 takes bits 16 (i & 1) .. +15 of word i >> 1; keep iff bits >= round(p * 65536)."""
     thr = _thr16(p)
     key = rng_key(seed, stream)
@@ -391,10 +386,10 @@ def attention_keep_mask(b, heads, s_q, s_k, p, seed, stream):
         rk = _pcg32((lo ^ key) + hi * _U(0x85EBCA6B))
         x = rk + (keys >> np.uint64(2)).astype(np.uint32) * _U(0x9E3779B9)
         x = x ^ (x >> _U(15))
-        x = _mul24(x, 0xD35A2D)
-        x = x ^ (x >> _U(13))
-        y = _mul24(x ^ _U(0x68E31DA4), 0xB5297A)
-        y = y ^ (y >> _U(14))
+        x = x * _U(0x2C1B3C6D)
+        x = x ^ (x >> _U(12))
+        y = (x ^ _U(0x68E31DA4)) * _U(0x297A2D39)
+        y = y ^ (y >> _U(15))
     i = (keys & np.uint64(3)).astype(np.int64) + np.zeros(x.shape, dtype=np.int64)
     w = np.where((i >> 1) == 0, x, y)
     bits = (w >> ((i & 1) * 16).astype(np.uint32)) & _U(0xFFFF)

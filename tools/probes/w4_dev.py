@@ -46,11 +46,11 @@ def run_one(tag):
     cs = torch.zeros(4 * h, device="cuda", dtype=dt)
     amax = torch.zeros(1, device="cuda", dtype=torch.float32)
     cases = [
-        ("fwd  h->4h  bias+gelu (epi 3)", 2.0 * M * 4 * h * h, lambda: ops.gemm(x, w_1, bias=b1, gelu=True, gelu_aux=aux)),
+        ("fwd  h->4h  bias+gelu+daux (131)", 2.0 * M * 4 * h * h, lambda: ops.gemm(x, w_1, bias=b1, gelu=True, gelu_daux=aux)),
         ("fwd  4h->h  bias+drop+amax (25)", 2.0 * M * 4 * h * h, lambda: ops.gemm(x4, w_2, bias=bh, dropout=(0.1, 1, 2), absmax=amax)),
         ("fwd  h->h   bias+drop+amax (25)", 2.0 * M * h * h, lambda: ops.gemm(x, w_d, bias=bh, dropout=(0.1, 1, 2), absmax=amax)),
         ("fwd  qkv    bias (1)", 2.0 * M * 3 * h * h, lambda: ops.gemm(x, w_qkv, bias=torch.cat((bh, bh, bh)))),
-        ("dgrad 4h<-h dgelu+colsum (68)", 2.0 * M * 4 * h * h, lambda: ops.gemm(x, w_2, trans_b=True, dgelu_aux=aux, colsum_out=cs)),
+        ("dgrad 4h<-h mulaux+colsum (320)", 2.0 * M * 4 * h * h, lambda: ops.gemm(x, w_2, trans_b=True, mul_aux=aux, colsum_out=cs)),
         ("dgrad h<-4h plain (0)", 2.0 * M * 4 * h * h, lambda: ops.gemm(x4, w_1, trans_b=True)),
         ("dgrad h<-h  plain (0)", 2.0 * M * h * h, lambda: ops.gemm(x, w_d, trans_b=True)),
     ]
@@ -59,7 +59,7 @@ def run_one(tag):
     aux2 = torch.empty(M2, 4 * h2, device="cuda", dtype=dt)
     cases += [
         ("336M fwd qkv  bias (1)", 2.0 * M2 * 3 * h2 * h2, lambda: ops.gemm(y2, w2q, bias=b2q)),
-        ("336M fwd h->4h bias+gelu (epi 3)", 2.0 * M2 * 4 * h2 * h2, lambda: ops.gemm(y2, w21, bias=b21, gelu=True, gelu_aux=aux2)),
+        ("336M fwd h->4h bias+gelu+daux", 2.0 * M2 * 4 * h2 * h2, lambda: ops.gemm(y2, w21, bias=b21, gelu=True, gelu_daux=aux2)),
         ("336M dgrad h<-h plain (0)", 2.0 * M2 * h2 * h2, lambda: ops.gemm(y2, w2q[:h2].contiguous(), trans_b=True)),
     ]
     for nm, y, ref in (("NT", ops.gemm(x, w_d), x.float() @ w_d.float().t()), ("NN", ops.gemm(x, w_d, trans_b=True), x.float() @ w_d.float()),
