@@ -409,12 +409,29 @@ def test_layernorm_backward_reads_the_mask_from_marked_zeros_bit_identically(ops
         dy = rnd((rows, h), dtype, g).cuda()
         _, mean, rstd = ops.sandwich_ln_fwd(x, gam, bet, 1e-5, slot)
         add = rnd((rows, h), dtype, g).cuda() if rows == 130 else None
+    # (regenerating form, marked with two rows in flight -- the regenerating form's geometry --, marked as shipped: four rows in
+    #  flight at wide rows.  dx is a per-row result: bit-identical in all three.  dgamma / dbeta / column sums are sums over the
+    #  rows a workgroup walks: the same rows in the same order at two rows in flight -> bit-identical; at four the rows are dealt
+    #  to the workgroups differently -> equal up to the fp32 summation order, i.e. to one unit in the last place of the 16-bit sums.)
+    import os
     res = []
-    for marked in (False, True):
+    for marked, rows_in_flight in ((False, None), (True, "2"), (True, None)):
         dg, db, cs = (torch.zeros(h, dtype=dtype, device="cuda") for _ in range(3))
-        dx = ops.sandwich_ln_bwd(dy, x, gam, mean, rstd, add_in=add, dropout=drop, dgamma=dg, dbeta=db, colsum=cs, marked=marked)
+        old = os.environ.pop("COGV_LN_BWD_MARKED_ROWS", None)
+        if rows_in_flight is not None:
+            os.environ["COGV_LN_BWD_MARKED_ROWS"] = rows_in_flight
+        try:
+            dx = ops.sandwich_ln_bwd(dy, x, gam, mean, rstd, add_in=add, dropout=drop, dgamma=dg, dbeta=db, colsum=cs, marked=marked)
+        finally:
+            os.environ.pop("COGV_LN_BWD_MARKED_ROWS", None)
+            if old is not None:
+                os.environ["COGV_LN_BWD_MARKED_ROWS"] = old
         res.append((dx, dg, db, cs))
     for u, v in zip(res[0], res[1]):
         assert torch.equal(_bits16(u), _bits16(v))
+    assert torch.equal(_bits16(res[0][0]), _bits16(res[2][0]))
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    for u, v in zip(res[0][1:], res[2][1:]):
+        assert float((u.float() - v.float()).abs().max()) <= ulp * max(float(u.float().abs().max()), 1e-6)
     if add is None:
         assert abs(float((res[1][0] == 0).float().mean()) - 0.1) < (0.02 if rows > 100 else 0.1)
