@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("splitk", C.c_int), ("kernel_variant", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("colsum_partial", C.c_void_p),
+        ("dropout_row0", C.c_longlong),
     ]
 
 
@@ -125,6 +126,7 @@ SIGNATURES = {
     "cogv_sandwich_ln_bwd_marked": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _sz, _i, _vp]),
     "cogv_ln_bwd_workspace_bytes": (_sz, [_i, _i]),
     "cogv_ln_bwd_num_blocks": (_i, [_i]),
+    "cogv_gemm_reserve_cus": (_i, [_i]),
     "cogv_attention_fwd": (_i, [C.POINTER(AttnDesc), _vp]),
     "cogv_attention_bwd": (_i, [C.POINTER(AttnDesc), _vp]),
     "cogv_gemv_ln": (_i, [C.POINTER(GemmDesc), C.POINTER(LnPrologue), _vp]),

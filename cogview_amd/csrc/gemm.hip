@@ -125,6 +125,16 @@ int* sched_slot() {
 }
 
 #ifndef COGV_W4_TU
+// CUs the persistent kernels leave free (cogv_gemm_reserve_cus): a collective that runs CONCURRENTLY with a GEMM needs somewhere
+// to live -- a generation-3 / 4 workgroup owns its CU's whole register file, so a persistent launch over all CUs keeps RCCL's
+// channel workgroups waiting until it ends.
+int g_reserved_cus = 0;
+int persistent_grid(int items) {
+  int n = num_cus() - g_reserved_cus;
+  if (n < 8) n = 8;
+  return items < n ? items : n;
+}
+
 // The generation-4 kernel's eight instantiations (2 dtypes x 4 layouts) are compiled from this same file in eight
 // separate translation units (-DCOGV_W4_TU=k, see build.py: they build in parallel); unit k exports cogv_w4_launch_k.
 #define W4_DECL(k) extern "C" __attribute__((visibility("hidden"))) int cogv_w4_launch_##k(const void* ga, int grid, void* stream);
@@ -189,7 +199,7 @@ int launch_pp64(GroupArgs& ga, hipStream_t st) {
       }
       ga.xp_ok = hit->ok; ga.xp_magic_ig = hit->mig; ga.xp_magic_gfull = hit->mgf; ga.xp_magic_gtail = hit->mgt;
     }
-    return W4_LAUNCH[w4_unit<T, AT, BT>()](&ga, items < num_cu ? items : num_cu, st);
+    return W4_LAUNCH[w4_unit<T, AT, BT>()](&ga, persistent_grid(items), st);
   } else {
     static bool attr_set = false;
     if (!attr_set) {
@@ -197,7 +207,7 @@ int launch_pp64(GroupArgs& ga, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
       attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_pp64_kernel<T, AT, BT>), dim3(items < num_cu ? items : num_cu), dim3(512), shmem, st, ga);
+    hipLaunchKernelGGL((gemm_pp64_kernel<T, AT, BT>), dim3(persistent_grid(items)), dim3(512), shmem, st, ga);
     return COGV_OK;
   }
 }
@@ -362,6 +372,7 @@ static int build_gemm_args(const cogv_gemm_desc* d, GemmArgs& a) {
     return COGV_ERR_ARG;
   if ((d->flags & COGV_EPI_ABSMAX) && !d->absmax) return COGV_ERR_ARG;
   if ((d->flags & COGV_EPI_DROPOUT) && !(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return COGV_ERR_ARG;
+  if (d->dropout_row0 < 0) return COGV_ERR_ARG;
 
   a.A = d->A; a.B = d->B; a.C = d->C;
   a.M = d->M; a.N = d->N; a.K = d->K;
@@ -369,6 +380,7 @@ static int build_gemm_args(const cogv_gemm_desc* d, GemmArgs& a) {
   a.bias = d->bias; a.aux = d->aux; a.ldaux = d->ldaux; a.absmax = d->absmax;
   a.flags = d->flags; a.out_f32 = d->out_f32;
   a.seed = d->seed; a.stream_id = d->stream_id;
+  a.drop_c0 = ((uint64_t)d->dropout_row0 * (uint64_t)d->N) >> 3;       // N % 8 == 0 (checked above)
   a.thr16 = (d->flags & COGV_EPI_DROPOUT) ? (uint32_t)(d->dropout_p * 65536.0f + 0.5f) : 0u;
   a.keep_scale = 65536.0f / (65536.0f - (float)a.thr16);
   a.tiles_m = (d->M + BM - 1) / BM; a.tiles_n = (d->N + BN - 1) / BN;
@@ -385,6 +397,12 @@ static int build_gemm_args(const cogv_gemm_desc* d, GemmArgs& a) {
     if ((uintptr_t)a.ws & 15) return COGV_ERR_ARG;
   }
   return COGV_OK;
+}
+
+extern "C" int cogv_gemm_reserve_cus(int n) {
+  const int prev = g_reserved_cus;
+  if (n >= 0) g_reserved_cus = n;
+  return prev;
 }
 
 extern "C" int cogv_gemm(const cogv_gemm_desc* d, void* stream) {

@@ -21,7 +21,7 @@ __device__ __forceinline__ void pp64_epilogue(const GemmArgs& pg, f32x4 (&acc)[8
   GemmArgs p = pg;
   pin_s(p.C); pin_s(p.M); pin_s(p.N); pin_s(p.ldc);
   if (F < 0 || (F & (COGV_EPI_GELU | COGV_EPI_DGELU | COGV_EPI_MULAUX))) { pin_s(p.aux); pin_s(p.ldaux); }
-  if (F < 0 || (F & COGV_EPI_DROPOUT)) { pin_s(p.seed); pin_s(p.stream_id); pin_s(p.thr16); pin_s(p.keep_scale); }
+  if (F < 0 || (F & COGV_EPI_DROPOUT)) { pin_s(p.seed); pin_s(p.stream_id); pin_s(p.drop_c0); pin_s(p.thr16); pin_s(p.keep_scale); }
   if (F < 0) { pin_s(p.flags); pin_s(p.out_f32); pin_s(p.bias); }
   if (F == -2) pin_s(p.ws);
   const bool want_cs = (F == -1) ? ((p.flags & COGV_EPI_COLSUM) != 0 && !p.out_f32) : (F >= 0 && (F & COGV_EPI_COLSUM));

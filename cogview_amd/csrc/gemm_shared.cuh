@@ -19,6 +19,7 @@ struct GemmArgs {
   int flags;
   int out_f32;          // C is float (used by nothing but tests / future)
   uint64_t seed, stream_id;
+  uint64_t drop_c0;     // dropout group counter of element (0, 0): the call computes rows [row0, row0 + M) of a larger tensor
   uint32_t thr16;       // dropout threshold (0 => keep all)
   float keep_scale;
   float* colsum_ws;     // COGV_EPI_COLSUM partial sums [2 * tiles_m(256)][N] fp32
@@ -125,7 +126,7 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
   }
   if ((flags & COGV_EPI_DROPOUT) && p.thr16) {
     const uint64_t e = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;   // n % 8 == 0
-    const u32x4 r = Philox::gen(p.seed, p.stream_id, e >> 3);
+    const u32x4 r = Philox::gen(p.seed, p.stream_id, (e >> 3) + p.drop_c0);
     // MARKED ZEROS (round 6): a dropped element is written as -0.0 and a kept element is never -0.0 -- a kept value that the
     // 16-bit rounding would turn into a zero of either sign is written as +0.0.  Numerically nothing changes (-0 == +0 in
     // every consumer), but the output now CARRIES its own keep mask: "16-bit pattern == 0x8000" <=> dropped, and the

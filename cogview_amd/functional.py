@@ -64,6 +64,57 @@ def _mp_allreduce_finish(work):
         work.wait()          # nccl: the compute stream waits for the collective; gloo (tests): the host waits
 
 
+@contextlib.contextmanager
+def _room_for_collective():
+    """GEMMs launched inside run on all CUs but COGV_MP_RESERVE_CUS (default 16): an all-reduce in flight on RCCL's stream
+    gets CUs for its channel workgroups instead of waiting for the persistent launch to end (ops.gemm_reserve_cus)."""
+    n = int(os.environ.get("COGV_MP_RESERVE_CUS", "16"))
+    if n <= 0 or mp_world_size_or_1() == 1:
+        yield
+        return
+    prev = ops.gemm_reserve_cus(n)
+    try:
+        yield
+    finally:
+        ops.gemm_reserve_cus(prev)
+
+
+def mp_row_chunks(rows):
+    """Row chunks of a row-parallel Linear's output under model parallelism (COGV_MP_ROW_CHUNKS, default 4; 1 = the
+    whole tensor in one GEMM + one all-reduce): [(row0, row1)], boundaries on multiples of 256 rows -- the GEMM's tile
+    height, so the chunks together run exactly the tiles of the whole-tensor launch."""
+    n = max(1, int(os.environ.get("COGV_MP_ROW_CHUNKS", "4")))
+    tiles = (rows + 255) // 256
+    n = min(n, tiles)
+    cuts = [min(rows, 256 * ((tiles * i + n - 1) // n)) for i in range(n + 1)]
+    return [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i + 1] > cuts[i]]
+
+
+def _row_parallel_chunked(x2d, weight, bias, drop, absmax_slot):
+    """Forward of a row-parallel Linear under model parallelism (mpu/layers.py:312-326: Y = reduce(X_i A_i) + b) with the
+    exchange taken off the critical path as far as the data allows: the output is computed in row chunks, chunk i's
+    all-reduce is started (RCCL's own stream) as soon as its GEMM is queued and runs under chunk i + 1's GEMM; the compute
+    stream waits for all of them only before the one thing that needs the whole tensor -- Sandwich-LN's abs-max, a
+    read-only pass over the reduced output.  Bias (rank 0 only) and hidden dropout ride in every chunk's GEMM epilogue as in
+    the whole-tensor form (dropout is linear per element and its mask depends only on (seed, stream, element index), which
+    `dropout_row0` keeps identical to the whole-tensor call): results are bit-identical to one GEMM + one all-reduce --
+    same k-loop per element, same element-wise sum across ranks."""
+    rows, n_out = x2d.shape[0], weight.shape[0]
+    out = torch.empty((rows, n_out), dtype=x2d.dtype, device=x2d.device)
+    works = []
+    for i, (r0, r1) in enumerate(mp_row_chunks(rows)):
+        if i == 0:                                   # nothing in flight yet: all CUs
+            ops.gemm(x2d[r0:r1], weight, bias=bias, dropout=drop, dropout_row0=r0, out=out[r0:r1])
+        else:
+            with _room_for_collective():
+                ops.gemm(x2d[r0:r1], weight, bias=bias, dropout=drop, dropout_row0=r0, out=out[r0:r1])
+        works.append(_mp_allreduce_start(out[r0:r1]))
+    for w in works:
+        _mp_allreduce_finish(w)
+    ops.absmax(out, absmax_slot)
+    return out
+
+
 def _drop(p, training, attention=False):
     """None or (p, seed, stream_id) drawn from the RNG tracker."""
     if not training or p <= 0.0:
@@ -557,9 +608,7 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
         # ride in each rank's GEMM epilogue and the all-reduce sums already-dropped partials:
         # mask*(A + B + bias) = mask*(A + bias) + mask*B.  What must follow the reduce is only the abs-max of the sum
         # (a read-only pass; the reference's order is dropout(all_reduce(.) + bias), mpu/layers.py:312-326)
-        ao = ops.gemm(att.view(rows, hp), att_m.dense.weight, bias=att_m.dense.bias if rank == 0 else None, dropout=d_ao)
-        _mp_allreduce(ao)
-        ops.absmax(ao, slot_ao)
+        ao = _row_parallel_chunked(att.view(rows, hp), att_m.dense.weight, att_m.dense.bias if rank == 0 else None, d_ao, slot_ao)
     slot_y = ops.new_absmax_slot(dev)
     y, m3, r3 = ops.sandwich_ln_fwd(ao.view(b, s, h), layer.third_layernorm.weight, layer.third_layernorm.bias, eps,
                                     slot_ao, residual=x, absmax_out=slot_y, save_stats=keep is not None)
@@ -573,9 +622,7 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
     if mp == 1:
         mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias, dropout=d_mo, absmax=slot_mo)
     else:
-        mo = ops.gemm(g, mlp_m.dense_4h_to_h.weight, bias=mlp_m.dense_4h_to_h.bias if rank == 0 else None, dropout=d_mo)
-        _mp_allreduce(mo)
-        ops.absmax(mo, slot_mo)
+        mo = _row_parallel_chunked(g, mlp_m.dense_4h_to_h.weight, mlp_m.dense_4h_to_h.bias if rank == 0 else None, d_mo, slot_mo)
     slot_out = ops.new_absmax_slot(dev)
     out, m4, r4 = ops.sandwich_ln_fwd(mo.view(b, s, h), layer.fourth_layernorm.weight, layer.fourth_layernorm.bias,
                                       eps, slot_mo, residual=y, absmax_out=slot_out, save_stats=keep is not None)
@@ -630,7 +677,8 @@ def _layer_backward(layer, kp, dout, sep):
     _wg(du, kp.c.view(rows, h), W1)
     if mp > 1:
         work = _mp_allreduce_start(dc)
-        _launch_weight_grads(wgrads)                                             # overlaps the exchange of dc
+        with _room_for_collective():
+            _launch_weight_grads(wgrads)                                         # overlaps the exchange of dc
         del wgrads[:]
         _mp_allreduce_finish(work)
     # y feeds LN2 and the second residual:  dy = dout + LN2'(dc)
@@ -655,7 +703,8 @@ def _layer_backward(layer, kp, dout, sep):
     _wg(dqkv2, kp.a.view(rows, h), Wq)
     if mp > 1:
         work = _mp_allreduce_start(da)
-        _launch_weight_grads(wgrads)                                             # overlaps the exchange of da
+        with _room_for_collective():
+            _launch_weight_grads(wgrads)                                         # overlaps the exchange of da
         _mp_allreduce_finish(work)
     dx = ops.sandwich_ln_bwd(da.view(b, s, h), kp.x, ln1.weight, *kp.st1, add_in=dy, dgamma=G(ln1.weight),
                              dbeta=G(ln1.bias), accumulate=grad_accumulate(ln1.weight, ln1.bias))

@@ -199,12 +199,13 @@ class timed_launch:
 
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, gelu_aux=None, dgelu_aux=None,
          dropout=None, absmax=None, accumulate=False, splitk=None, out_dtype=None, variant=0, colsum_out=None,
-         colsum_accumulate=True, gelu_daux=None, mul_aux=None):
+         colsum_accumulate=True, gelu_daux=None, mul_aux=None, dropout_row0=0):
     """C[M,N] = epilogue(A_op[M,K] . B_op[N,K]^T); a, b 2-D, last dim contiguous.
     trans_a: `a` is stored [K, M];  trans_b: `b` is stored [K, N].
     gelu_aux [M,N]: receives the rounded pre-activation; gelu_daux [M,N] (instead): receives gelu'(pre-activation), which
     the backward GEMM applies with mul_aux (out = x * mul_aux) -- one multiply where dgelu_aux re-evaluates the sigmoid.
-    dropout = (p, seed, stream_id).  colsum_out [N]: (+)= column sums of C (the bias gradient of the layer whose
+    dropout = (p, seed, stream_id); dropout_row0: the call computes rows [row0, row0 + M) of a larger tensor whose mask it
+    draws (row chunks of a row-parallel Linear).  colsum_out [N]: (+)= column sums of C (the bias gradient of the layer whose
     output gradient C is), fused into the epilogue when the shape allows, otherwise a separate pass.  Returns C."""
     _need_gpu(a, b)
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
@@ -251,6 +252,7 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
     if dropout is not None and dropout[0] > 0.0:
         flags |= L.EPI_DROPOUT
         d.dropout_p, d.seed, d.stream_id = float(dropout[0]), int(dropout[1]), int(dropout[2])
+        d.dropout_row0 = int(dropout_row0)
     if absmax is not None:
         flags |= L.EPI_ABSMAX
         d.absmax = absmax.data_ptr()
@@ -292,6 +294,12 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
         else:
             colsum(out, out=colsum_out, accumulate=colsum_accumulate)
     return out
+
+
+def gemm_reserve_cus(n):
+    """The persistent GEMM launches leave `n` CUs free from now on (cogv_gemm_reserve_cus; room for a concurrent collective's
+    channel workgroups); returns the previous setting."""
+    return int(L.lib().cogv_gemm_reserve_cus(int(n)))
 
 
 def gemv_ln(z, w, bias, gamma, beta, eps, z_absmax=None, post=None, residual=None, want_t=False, gelu=False, absmax=None):

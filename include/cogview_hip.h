@@ -82,6 +82,10 @@ typedef struct cogv_gemm_desc {
   int kernel_variant;   /* 0 = auto; 1 = generation 1 (register-staged 128x128x64); 3 = generation 2 (256x128x32 LDS-DMA ring); 9 = generation 3 (256x256x64, 8 waves ping-pong, persistent); 10 = generation 4 (256x256x64, 4 waves of 128x128, persistent: what auto picks for M, N >= 256) */
   void* workspace; size_t workspace_bytes;   /* >= cogv_gemm_workspace_bytes() when splitk > 1 */
   float* colsum_partial;                     /* COGV_EPI_COLSUM: [cogv_gemm_colsum_rows(M)][N] fp32, fully written */
+  /* COGV_EPI_DROPOUT: this call computes rows [dropout_row0, dropout_row0 + M) of a larger [rows][N] tensor and draws the mask
+   * of element (m, n) at linear index (dropout_row0 + m) * N + n -- a row-parallel Linear (mpu/layers.py:312-326) computed in
+   * row chunks, each chunk's all-reduce running under the next chunk's GEMM, drops exactly what the whole-tensor call drops. */
+  long long dropout_row0;
 } cogv_gemm_desc;
 
 int cogv_gemm(const cogv_gemm_desc* d, void* stream);
@@ -98,6 +102,11 @@ int cogv_gemm_grouped(const cogv_gemm_desc* descs, int count, void* stream);
 /* Note: the persistent GEMM kernel distributes tiles through per-XCD atomic work queues; the library keeps their
  * counters in 4 KiB of device memory per GPU that it allocates itself on the first GEMM call (its only allocation). */
 int cogv_gemm_pick_splitk_tiles(int tiles_256x256, int K);
+/* Model parallelism: the persistent GEMM kernels (one workgroup per CU, each owning its CU's register file) leave `n` CUs
+ * free from now on (n = 0: none, the default; n < 0: query only) -- room for the channel workgroups of an all-reduce that
+ * runs concurrently with the launch: the row-parallel Linear of mpu/layers.py:312-326 computed in row chunks, chunk i's
+ * reduce (mpu/mappings.py:22-31) under chunk i + 1's GEMM.  Process-wide, not thread safe; returns the previous value. */
+int cogv_gemm_reserve_cus(int n);
 
 /* Decode-step matrix-vector product with the layer's LayerNorms as prologue (M <= 8 rows, K = hidden size <= 4096,
  * K % 512 == 0; trans_a = trans_b = 0; epilogue flags BIAS | GELU | ABSMAX only; d->A is ignored):

@@ -61,7 +61,7 @@ def absmax(x, out=None):
 
 def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, gelu_aux=None, dgelu_aux=None, dropout=None,
          absmax=None, accumulate=False, splitk=None, out_dtype=None, variant=0, colsum_out=None, colsum_accumulate=True,
-         gelu_daux=None, mul_aux=None):
+         gelu_daux=None, mul_aux=None, dropout_row0=0):
     A = a.float().t() if trans_a else a.float()
     B = b.float() if trans_b else b.float().t()
     c = A @ B
@@ -78,7 +78,10 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, bias=None, gelu=False, ge
         c = c * _gelu_grad(dgelu_aux.float())
     if mul_aux is not None:
         c = c * mul_aux.float()
-    keep = _keep(c.shape, dropout)                                   # epilogue order: ... -> dropout -> +C -> round (cogview_hip.h:49)
+    # epilogue order: ... -> dropout -> +C -> round (cogview_hip.h:49); dropout_row0: the rows are a chunk of a larger tensor
+    keep = _keep((int(dropout_row0) + c.shape[0], c.shape[1]), dropout)
+    if keep is not None:
+        keep = keep[int(dropout_row0):]
     if keep is not None:
         c = c * keep
     if out is None:
@@ -363,7 +366,18 @@ def add(a, b, absmax_out=None):
     return out
 
 
-NAMES = ("new_absmax_slot", "absmax", "gemm", "gemm_grouped", "colsum", "sandwich_ln_fwd", "sandwich_ln_bwd", "attention_fwd",
+def gemm_reserve_cus(n):
+    """No CUs on a CPU: the setting is recorded and handed back like the library does."""
+    global _RESERVED
+    prev = _RESERVED
+    if int(n) >= 0:
+        _RESERVED = int(n)
+    return prev
+
+
+_RESERVED = 0
+
+NAMES = ("new_absmax_slot", "absmax", "gemm", "gemm_reserve_cus", "gemm_grouped", "colsum", "sandwich_ln_fwd", "sandwich_ln_bwd", "attention_fwd",
          "attention_bwd", "embedding_fwd", "embedding_bwd", "ce_fwd", "ce_bwd", "grad_stats", "adamw_step", "cast_flat",
          "cast_flat_back", "scale", "add", "gelu_fwd", "gelu_bwd", "dropout")
 

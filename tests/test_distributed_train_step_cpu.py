@@ -257,14 +257,14 @@ def _golden_flat_like(flat):
 _TP = dict(L=2, V=512, H=256, NH=4, S=64, B=2)
 
 
-def _tp_build_and_run():
+def _tp_build_and_run(c=None, hidden_dropout=0.0):
     from cogview_amd import mpu
     from cogview_amd.fp16 import FP16_Module
     from cogview_amd.model import GPT2Model
-    c = _TP
+    c = c or _TP
     torch.manual_seed(4321)
     mpu.model_parallel_cuda_manual_seed(4321)
-    m = GPT2Model(c["L"], c["V"], c["H"], c["NH"], 0.0, 0.0, 0.0, c["S"] + 1, 0, False)
+    m = GPT2Model(c["L"], c["V"], c["H"], c["NH"], 0.0, 0.0, hidden_dropout, c["S"] + 1, 0, False)
     model = FP16_Module(m, dtype=torch.float16, keep_half_outputs=True)
     model.train()
     g = torch.Generator().manual_seed(11)
@@ -362,6 +362,32 @@ def test_model_parallel_2_x_data_parallel_2_train_step(monkeypatch):
             worst = max(worst, e)
             assert e < 2e-2, (n, r, e)
     print(f"mp 2 x dp 2 on the CPU emulation: worst gradient rel-L2 {worst:.2e}")
+
+
+_TP_CHUNKED = dict(L=2, V=512, H=128, NH=2, S=256, B=4)      # 1024 rows = four 256-row tiles: four row chunks
+
+
+def w_tp2_row_chunks(rank, world):
+    """Row-parallel forward in row chunks (functional._row_parallel_chunked: chunk i's all-reduce under chunk i + 1's GEMM) against
+    the whole-tensor form, hidden dropout ON: logits and every gradient must be bit-identical (same masks through dropout_row0,
+    same k-loop per element, same element-wise sum across the ranks)."""
+    from cogview_amd import functional as F, mpu
+    mpu.initialize_model_parallel(world)
+    res = []
+    for chunks in ("1", "4"):
+        os.environ["COGV_MP_ROW_CHUNKS"] = chunks
+        model, logits, loss = _tp_build_and_run(_TP_CHUNKED, hidden_dropout=0.1)
+        res.append((logits.detach().clone(), float(loss.detach()), {n: p.grad.detach().clone() for n, p in model.module.named_parameters()}))
+    os.environ.pop("COGV_MP_ROW_CHUNKS", None)
+    assert F.mp_row_chunks(1024) == [(0, 256), (256, 512), (512, 768), (768, 1024)] and F.mp_row_chunks(300) == [(0, 256), (256, 300)]
+    assert F.mp_row_chunks(26112) == [(0, 6656), (6656, 13056), (13056, 19712), (19712, 26112)]
+    same = torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and all(torch.equal(res[0][2][n], res[1][2][n]) for n in res[0][2])
+    return {"same": same, "dropped": float((res[1][0] == 0).float().mean())}
+
+
+def test_row_parallel_forward_in_row_chunks_is_bit_identical(monkeypatch):
+    out = _run("w_tp2_row_chunks")
+    assert out[0]["same"] and out[1]["same"]
 
 
 def test_two_way_tensor_parallel_forward_backward(monkeypatch):

@@ -537,13 +537,13 @@ def test_two_rank_data_parallel_step_on_one_gpu(golden_dir):
 _TP_CFG = dict(L=2, V=512, H=256, NH=4, S=64, B=2)
 
 
-def _tp_build_and_run(dtype=torch.float16):
+def _tp_build_and_run(dtype=torch.float16, cfg=None):
     """Same seed on every rank / in the one-process reference: every rank draws the full master weights and keeps
     its shard (mpu/layers.py:42-74), so the models are the same function.  Returns (module, logits, loss)."""
     from cogview_amd import mpu
     from cogview_amd.fp16 import FP16_Module
     from cogview_amd.model import GPT2Model
-    c = _TP_CFG
+    c = cfg or _TP_CFG
     torch.manual_seed(4321)
     mpu.model_parallel_cuda_manual_seed(4321)      # the default dropout state is the same on every model-parallel rank
     # hidden (output) dropout ON: its masks are identical across the model-parallel group, so the sharded model must
@@ -593,6 +593,54 @@ def _tp2_worker(rank, world, port, ret):
         dist.destroy_process_group()
     except Exception:
         ret[rank] = (traceback.format_exc(),)
+
+
+_TP_CFG_CHUNKED = dict(L=2, V=512, H=256, NH=4, S=512, B=4)      # 2048 rows = eight 256-row tiles: four chunks of two
+
+
+def _tp2_chunk_worker(rank, world, port, ret):
+    import sys
+    import traceback
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+        torch.cuda.set_device(0)
+        from cogview_amd import mpu, ops
+        mpu.initialize_model_parallel(world)
+        res = []
+        for chunks in ("1", "4"):
+            os.environ["COGV_MP_ROW_CHUNKS"] = chunks
+            model, logits, loss = _tp_build_and_run(cfg=_TP_CFG_CHUNKED)
+            torch.cuda.synchronize()
+            res.append((logits.detach().clone(), loss.item(), {n: p.grad.detach().clone() for n, p in model.module.named_parameters()}))
+        same = (torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+                and all(torch.equal(res[0][2][n], res[1][2][n]) for n in res[0][2]))
+        ret[rank] = ("ok", same, ops.gemm_reserve_cus(-1))
+        dist.destroy_process_group()
+    except Exception:
+        ret[rank] = (traceback.format_exc(),)
+
+
+def test_row_parallel_forward_in_row_chunks_is_bit_identical_on_one_gpu():
+    """Model parallel 2 (two processes on the GPU, gloo carries the all-reduces), hidden dropout 0.1: the row-parallel Linears
+    computed in four row chunks -- chunk i's all-reduce started behind its GEMM, the later chunks' GEMMs leaving CUs to it --
+    give bit-identical logits, loss and gradients to one GEMM + one all-reduce, and the CU reservation is back at zero."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_tp2_chunk_worker, args=(r, 2, port, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+        for r in range(2):
+            assert ret.get(r) is not None and ret[r][0] == "ok", f"rank {r}: {ret.get(r)}"
+            assert ret[r][1] is True and ret[r][2] == 0
 
 
 def test_two_way_tensor_parallel_on_one_gpu():

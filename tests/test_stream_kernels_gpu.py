@@ -385,6 +385,29 @@ def test_gemm_dropout_epilogue_marks_dropped_elements_with_minus_zero(ops, dtype
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,cuts", [(1024, 512, 256, (0, 256, 768, 1024)), (600, 256, 64, (0, 256, 600)), (300, 1024, 128, (0, 40, 300))])
+def test_gemm_row_chunks_draw_the_whole_tensor_dropout_mask(ops, dtype, M, N, K, cuts):
+    """cogv_gemm_desc.dropout_row0: a GEMM over rows [r0, r1) of a larger output draws the mask of those rows of the WHOLE tensor
+    -- the chunks together are bit-identical to the one-call result (marked zeros included), with all CUs and with CUs reserved
+    for a concurrent collective (cogv_gemm_reserve_cus)."""
+    g = torch.Generator().manual_seed(M + K)
+    a, w = rnd((M, K), dtype, g).cuda(), rnd((N, K), dtype, g, 0.1).cuda()
+    bias = rnd((N,), dtype, g, 0.1).cuda()
+    whole = ops.gemm(a, w, bias=bias, dropout=(0.1, 5, 9))
+    for reserve in (0, 16):
+        prev = ops.gemm_reserve_cus(reserve)
+        try:
+            out = torch.empty_like(whole)
+            for r0, r1 in zip(cuts[:-1], cuts[1:]):
+                ops.gemm(a[r0:r1], w, bias=bias, dropout=(0.1, 5, 9), dropout_row0=r0, out=out[r0:r1])
+        finally:
+            assert ops.gemm_reserve_cus(prev) == reserve
+        assert torch.equal(_bits16(out), _bits16(whole))
+    mask = torch.from_numpy(O.dropout_keep_mask(M * N, 0.1, 5, 9)).view(M, N)
+    assert torch.equal((_bits16(whole).cpu() == -32768), mask == 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("rows,h,stream_out", [(7, 2560, True), (1000, 2560, True), (26112, 2560, True), (300, 1024, True),
                                                (70, 256, True), (130, 2560, False), (300, 1024, False)])
 def test_layernorm_backward_reads_the_mask_from_marked_zeros_bit_identically(ops, dtype, rows, h, stream_out):
