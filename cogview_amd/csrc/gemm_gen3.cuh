@@ -39,7 +39,7 @@ __device__ __forceinline__ void pp64_epilogue(const GemmArgs& pg, f32x4 (&acc)[8
       for (int t = 0; t < 16; ++t) {
         const int m = m_base + 8 * t + sr;
         const bool ok = m < p.M && n < p.N;
-        if (PRE_AUX) aux_v[t] = ok ? gload16(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n) : u32x4{0u, 0u, 0u, 0u};
+        if (PRE_AUX) aux_v[t] = ok ? gload16_aux(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n) : u32x4{0u, 0u, 0u, 0u};
         if (PRE_C) c_v[t] = ok ? gload16(reinterpret_cast<const T*>(p.C) + (size_t)m * p.ldc + n) : u32x4{0u, 0u, 0u, 0u};
       }
     }

@@ -53,6 +53,20 @@ __device__ __forceinline__ u32x4 gload16_stream(const void* q) {
   return *(const COGV_GLOBAL u32x4*)q;
 #endif
 }
+// the aux operand of the stored-tensor epilogues (MULAUX / DGELU: [M][N], every element read exactly once per launch): non-temporal,
+// so that the 535-MB stream of the 4B dGeLU-side dgrad does not take L2 lines from the operand panels -- 1107 -> 1090 us in
+// alternating processes (profiles/r06_gemm_aux_nt_probe.log).  What the aux read costs beyond that is its memory side: with an
+// L2-resident aux (row stride 0, same instruction stream) the launch takes 85-110 us less (profiles/r06_gemm_aux_l2_probe.log).
+#ifndef COGV_AUX_NT
+#define COGV_AUX_NT 1
+#endif
+__device__ __forceinline__ u32x4 gload16_aux(const void* q) {
+#if COGV_AUX_NT
+  return __builtin_nontemporal_load((const COGV_GLOBAL u32x4*)q);
+#else
+  return *(const COGV_GLOBAL u32x4*)q;
+#endif
+}
 __device__ __forceinline__ void gstore16(void* q, u32x4 v) { *(COGV_GLOBAL u32x4*)q = v; }
 __device__ __forceinline__ void gstore16(float* q, f32x4 v) { *(COGV_GLOBAL f32x4*)q = v; }
 // 16-bit C / aux stores of the non-accumulating epilogues carry the NON-TEMPORAL hint (round 4): a 32-CU XCD writes 4 MiB of C per
@@ -113,13 +127,13 @@ __device__ __forceinline__ uint32_t epilogue8(const GemmArgs& p, int m, int n, f
     }
   }
   if (flags & COGV_EPI_DGELU) {
-    u32x4 uv = aux_pre ? *aux_pre : gload16(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
+    u32x4 uv = aux_pre ? *aux_pre : gload16_aux(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
     float u[8]; unpack8<T>(uv, u);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(u[i]);
   }
   if (flags & COGV_EPI_MULAUX) {
-    u32x4 uv = aux_pre ? *aux_pre : gload16(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
+    u32x4 uv = aux_pre ? *aux_pre : gload16_aux(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
     float u[8]; unpack8<T>(uv, u);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= u[i];
