@@ -769,12 +769,26 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 // 64 words (one per query of the stage); wave w DMAs segment w in place of the row-key statistics row (same count of
 // DMAs per stage), and a lane (= key) picks ITS bit out of the word of each of its 16 queries: four ds_read_b128 +
 // 16 x (v_bfe_i32, v_and) per 32 x 32 tile where the regenerating form hashes four draws and shares them through DPP.
+// Probe builds only (-DCOGV_ATTN_TS, tools/probes/attn_ts.py): per-wave shader-clock time of the phases of the dK.dV kernel, summed
+// over all waves of the launch into g_attn_ts: 0 DMA wait + barrier, 1 DMA issue, 2 the stage's compute (both halves), 3 epilogue
+// (stores, column sums), 4 prologue, 5 whole wave, 6 wave-iterations, 7 waves.
+#if defined(COGV_ATTN_TS)
+__device__ unsigned long long g_attn_ts[1024 * 8];      // 1024 slots of 8 counters (one hot line would serialise 276k atomics per launch)
+#define ATS(k_) do { const unsigned long long t_ = __builtin_readcyclecounter(); ats[k_] += t_ - ats_last; ats_last = t_; } while (0)
+#else
+#define ATS(k_) do { } while (0)
+#endif
 template <typename T, bool IDX, int DROP>
 __global__ __launch_bounds__(NT, (!IDX && DROP == 2) ? COGV_DKDV_WAVES : 2) void attn_bwd_dkdv_kernel(const AttnArgs p) {
   const bool drop = DROP < 0 ? (p.thr16 != 0u) : (DROP != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool KB = DROP == 2;
   constexpr int STAGE = 2 * TILE + (KB ? 512 + 1024 : 768), LPT = 7;
+#if defined(COGV_ATTN_TS)
+  unsigned long long ats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long ats_begin = __builtin_readcyclecounter();
+  unsigned long long ats_last = ats_begin;
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 31, fg = lane >> 5;
@@ -861,10 +875,16 @@ __global__ __launch_bounds__(NT, (!IDX && DROP == 2) ? COGV_DKDV_WAVES : 2) void
   const uint32_t kw_bit = 31u - (uint32_t)((wave & 1) * 16 + 4 * (kr >> 3) + (kr & 3));
   if (qb0 < nqb) { issue(qb0, 0); if (NSTG > 2) issue(min(qb0 + 1, nqb - 1), 1); }
   int st = 0;
+  ATS(4);
   for (int qb = qb0; qb < nqb; ++qb) {
     wait_vmcnt<(NSTG - 2) * LPT>();
     __builtin_amdgcn_s_barrier();
+    ATS(0);
     issue(min(qb + NSTG - 1, nqb - 1), st == 0 ? NSTG - 1 : st - 1);
+    ATS(1);
+#if defined(COGV_ATTN_TS)
+    ats[6] += 1;
+#endif
     if (wave_active && qb * 64 + 63 >= qbeg_w) {
       const char* lq = smem + st * STAGE; const char* ldo = lq + TILE;
       const uint32_t lqt = smem_addr + st * STAGE, ldot = lqt + TILE;
@@ -1001,9 +1021,16 @@ __global__ __launch_bounds__(NT, (!IDX && DROP == 2) ? COGV_DKDV_WAVES : 2) void
           }
         }
       };
+      // (Round 6 measured the two halves as a software pipeline INSIDE the wave -- the S / dP products of half 1 issued between the
+      //  element-wise instructions of half 0, the dV / dK products of half 0 between those of half 1, one MFMA per ~20 VALU
+      //  instructions pinned by sched_barrier, 249 registers, no spill, same results: backward 992-1029 us against 987-1006
+      //  (profiles/r06_attention_dkdv_intra_wave_pipeline_ab.log).  In-kernel timestamps (profiles/r06_attention_dkdv_phase_probe.log)
+      //  say why: a wave spends 57 % of its life in this compute phase and two waves share the SIMD, so the MFMAs of one wave
+      //  already run under the VALU work of the other; the SIMD is bound by VALU issue.  Removed.)
       half(std::integral_constant<int, 0>{});
       half(std::integral_constant<int, 1>{});
     }
+    ATS(2);
     st = (st == NSTG - 1) ? 0 : st + 1;
   }
   wait_vmcnt<0>();
@@ -1035,6 +1062,14 @@ __global__ __launch_bounds__(NT, (!IDX && DROP == 2) ? COGV_DKDV_WAVES : 2) void
     tile_colsum(rk, reinterpret_cast<float*>(smem), dst, lane, wave);
     tile_colsum(rv, reinterpret_cast<float*>(smem), dst + (size_t)p.H * HD, lane, wave);
   }
+#if defined(COGV_ATTN_TS)
+  ATS(3);
+  if (lane == 0) {
+    ats[5] = __builtin_readcyclecounter() - ats_begin; ats[7] = 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_attn_ts[(((blockIdx.x << 2) + wave) & 1023) * 8 + k], ats[k]);
+  }
+#endif
 }
 
 // =====================================================================================================
@@ -1433,3 +1468,18 @@ extern "C" int cogv_sparse_slot_reduce(int dtype, const void* dk_slots, const vo
                        window, times, n_pivots);
   return cogv_check_launch();
 }
+
+#if defined(COGV_ATTN_TS)
+extern "C" int cogv_debug_attn_ts(unsigned long long* host_out, int reset) {
+  static unsigned long long h[1024 * 8];
+  if (host_out) {
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_ts), sizeof(h)) != hipSuccess) return COGV_ERR_LAUNCH;
+    for (int k = 0; k < 8; ++k) { host_out[k] = 0; for (int i = 0; i < 1024; ++i) host_out[k] += h[i * 8 + k]; }
+  }
+  if (reset) {
+    for (int i = 0; i < 1024 * 8; ++i) h[i] = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_ts), h, sizeof(h)) != hipSuccess) return COGV_ERR_LAUNCH;
+  }
+  return COGV_OK;
+}
+#endif
