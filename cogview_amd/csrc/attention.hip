@@ -74,7 +74,7 @@ constexpr int ring_bytes(int stage, bool colsum) { return (colsum && NSTG * stag
 struct AttnArgs {
   const void* q; const void* k; const void* v; void* o;        // forward
   const void* dout; void* dq; void* dk; void* dv;              // backward
-  float* lse; float* dvec;                                     // [b][H][s_q]; dvec: [2][b][H][s_q] (D, dropout row keys)
+  float* lse; float* dvec;                                     // [b][H][s_q]; dvec: [2][b][H][s_q] (-D; dropout row keys, or -LSE log2 e with stored keep bits)
   float* colsum_ws;                                            // optional [B * nblk][3 * H * 64]: sums of dq | dk | dv
   // optional (dense kernels, DROP == 2): the dropout keep bits of the forward pass, one 32-bit word per (query, 64-key block,
   // key half fg): word [(b * H + head)][kb][fg][q], bit 31 - n <-> key 64 kb + 32 (n >> 4) + 8 ((n & 15) >> 2) + 4 fg + (n & 3).
@@ -602,10 +602,13 @@ __global__ __launch_bounds__(NT, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     }
     dv += __shfl_xor(dv, 32, 64);
     if (qvalid && fg == 0) {
-      p.dvec[arow] = dv;
+      // published NEGATED (round 6): the dK/dV kernel forms dS = Pd dPd + P (-D) without a sign flip per element
+      p.dvec[arow] = -dv;
       // second plane of the workspace: the row's dropout key, so the dK/dV kernel (lane = key, 16 query rows per lane)
-      // reads it instead of re-hashing the row for every draw (not needed when the keep bits are stored)
+      // reads it instead of re-hashing the row for every draw.  With stored keep bits that plane is free and carries
+      // -LSE * log2(e) instead: the exponent's addend as the dK/dV kernel needs it (one multiply per score element less there)
       if (!KB) reinterpret_cast<uint32_t*>(p.dvec)[(long long)p.B * p.H * p.s_q + arow] = cb.rk;
+      else p.dvec[(long long)p.B * p.H * p.s_q + arow] = -lse2;
     }
   }
   const float sl2 = p.scale * 1.4426950408889634f;
@@ -864,7 +867,7 @@ __global__ __launch_bounds__(NT, (!IDX && DROP == 2) ? COGV_DKDV_WAVES : 2) void
     char* base = smem + st * STAGE;
     dma_tile<T>(Q, p.q_rs, qb * 64, p.s_q, base, wave, lane);
     dma_tile<T>(DO, p.do_rs, qb * 64, p.s_q, base + TILE, wave, lane);
-    dma_stat(LSE, qb * 64, p.s_q, base + 2 * TILE, lane);
+    dma_stat(KB ? RK : LSE, qb * 64, p.s_q, base + 2 * TILE, lane);      // KB: plane 1 holds -LSE * log2(e) (dQ kernel)
     dma_stat(DV, qb * 64, p.s_q, base + 2 * TILE + 256, lane);
     if (KB) dma_stat(reinterpret_cast<const float*>(KWS), qb * 64, p.s_q, base + 2 * TILE + 512 + wave * 256, lane);
     else dma_stat(RK, qb * 64, p.s_q, base + 2 * TILE + 512, lane);
@@ -973,14 +976,16 @@ __global__ __launch_bounds__(NT, (!IDX && DROP == 2) ? COGV_DKDV_WAVES : 2) void
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int e = 4 * gq + i;
-            const float pr = fast_exp2(fmaf(sacc[e], sl2, -l4[i] * l2e));
+            // (the exponent's argument of two neighbouring elements as ONE packed fma measured neutral to slightly slower,
+            //  profiles/r06_attention_dkdv_valu_diet_ab.log: not kept)
+            const float pr = fast_exp2(fmaf(sacc[e], sl2, KB ? l4[i] : -l4[i] * l2e));
             // dropped probability Pd = keep ? P / (1 - p) : 0 and dS = Pd dPd - P D.  The keep bit becomes the
             // multiplier 1/(1-p) or 0 by sign-extending it over the float's bit pattern (v_bfe_i32 + v_and): two
             // instructions where compare + two selects (on Pd and dS) took five
             float keepf = kscale;
             if (drop) keepf = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)km[i], KB ? kw_bit : (uint32_t)kbit, 1u) & __float_as_uint(kscale));
             pd[e] = pr * keepf;
-            ds[e] = fmaf(pd[e], pacc[e], -(pr * d4[i]));
+            ds[e] = fmaf(pd[e], pacc[e], pr * d4[i]);                 // d4 = -D (published negated by the dQ kernel)
             if (IDX && p.mask) ds[e] *= mq[e];
           }
         }
