@@ -394,7 +394,7 @@ def test_gemm_row_chunks_draw_the_whole_tensor_dropout_mask(ops, dtype, M, N, K,
     a, w = rnd((M, K), dtype, g).cuda(), rnd((N, K), dtype, g, 0.1).cuda()
     bias = rnd((N,), dtype, g, 0.1).cuda()
     whole = ops.gemm(a, w, bias=bias, dropout=(0.1, 5, 9))
-    for reserve in (0, 16):
+    for reserve in (0, 16, 100000):                 # 100000: more than the GPU has -- the launch keeps 8 workgroups
         prev = ops.gemm_reserve_cus(reserve)
         try:
             out = torch.empty_like(whole)
