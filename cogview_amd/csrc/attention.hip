@@ -57,6 +57,9 @@ constexpr int NSTG = COGV_ATTN_STAGES;
 // (168 registers, 24 B of spill outside the asm-read windows).  The runtime then grants three workgroups per CU -- and the
 // kernel is NOT faster: backward 1018-1031 us against 1000-1013 with two waves (same call), the 4B step unchanged.  A third
 // wave per SIMD does not cover the parked cycles; the defaults (two waves, fragments requested ahead) stay.
+#ifndef COGV_DKDV_KW_PITCH
+#define COGV_DKDV_KW_PITCH 272
+#endif
 #ifndef COGV_DKDV_AHEAD
 #define COGV_DKDV_AHEAD 1
 #endif
@@ -786,7 +789,11 @@ __global__ __launch_bounds__(NT, (!IDX && DROP == 2) ? COGV_DKDV_WAVES : 2) void
   const bool drop = DROP < 0 ? (p.thr16 != 0u) : (DROP != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool KB = DROP == 2;
-  constexpr int STAGE = 2 * TILE + (KB ? 512 + 1024 : 768), LPT = 7;
+  // KWP: pitch (bytes) of the four keep-word segments of a stage.  272 instead of 256 (round 6): a lane group reads two segments
+  // in one ds_read_b128 (its key's bit 2 selects which), and at a 256-byte pitch the two hit the same banks -- the 12 % LDS
+  // bank-conflict cycles of this kernel alone among the three (profiles/r05_attention_pmc.txt)
+  constexpr int KWP = COGV_DKDV_KW_PITCH;
+  constexpr int STAGE = 2 * TILE + (KB ? 512 + 4 * KWP : 768), LPT = 7;
 #if defined(COGV_ATTN_TS)
   unsigned long long ats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long ats_begin = __builtin_readcyclecounter();
@@ -869,12 +876,12 @@ __global__ __launch_bounds__(NT, (!IDX && DROP == 2) ? COGV_DKDV_WAVES : 2) void
     dma_tile<T>(DO, p.do_rs, qb * 64, p.s_q, base + TILE, wave, lane);
     dma_stat(KB ? RK : LSE, qb * 64, p.s_q, base + 2 * TILE, lane);      // KB: plane 1 holds -LSE * log2(e) (dQ kernel)
     dma_stat(DV, qb * 64, p.s_q, base + 2 * TILE + 256, lane);
-    if (KB) dma_stat(reinterpret_cast<const float*>(KWS), qb * 64, p.s_q, base + 2 * TILE + 512 + wave * 256, lane);
+    if (KB) dma_stat(reinterpret_cast<const float*>(KWS), qb * 64, p.s_q, base + 2 * TILE + 512 + wave * KWP, lane);
     else dma_stat(RK, qb * 64, p.s_q, base + 2 * TILE + 512, lane);
   };
   // the lane's key inside its 64-key block: half (wave & 1 -- the wave's 32 keys), key half fg' = bit 2, element 4 (r >> 3) + (r & 3)
   const int kr = mykey & 31;
-  const uint32_t kw_seg = (uint32_t)(((wave >> 1) * 2 + ((kr >> 2) & 1)) * 64);               // word offset of the lane's segment
+  const uint32_t kw_seg = (uint32_t)(((wave >> 1) * 2 + ((kr >> 2) & 1)) * (KWP / 4));        // word offset of the lane's segment
   const uint32_t kw_bit = 31u - (uint32_t)((wave & 1) * 16 + 4 * (kr >> 3) + (kr & 3));
   if (qb0 < nqb) { issue(qb0, 0); if (NSTG > 2) issue(min(qb0 + 1, nqb - 1), 1); }
   int st = 0;
@@ -1375,7 +1382,7 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
     set_smem(&attn_bwd_dq_kernel<f16_t, false, 0>, ring_bytes(2 * TILE, true)); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 0>, ring_bytes(2 * TILE, true));
     set_smem(&attn_bwd_dq_kernel<f16_t, false, 1>, ring_bytes(2 * TILE, true)); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 1>, ring_bytes(2 * TILE, true));
     set_smem(&attn_bwd_dq_kernel<f16_t, false, 2>, ring_bytes(2 * TILE + 1024, true)); set_smem(&attn_bwd_dq_kernel<bf16_t, false, 2>, ring_bytes(2 * TILE + 1024, true));
-    set_smem(&attn_bwd_dkdv_kernel<f16_t, false, 2>, ring_bytes(2 * TILE + 1536, true) + DKDV_OWN_V); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false, 2>, ring_bytes(2 * TILE + 1536, true) + DKDV_OWN_V);
+    set_smem(&attn_bwd_dkdv_kernel<f16_t, false, 2>, ring_bytes(2 * TILE + 512 + 4 * COGV_DKDV_KW_PITCH, true) + DKDV_OWN_V); set_smem(&attn_bwd_dkdv_kernel<bf16_t, false, 2>, ring_bytes(2 * TILE + 512 + 4 * COGV_DKDV_KW_PITCH, true) + DKDV_OWN_V);
     attr = true;
   }
   // the flexible dQ instantiation (gathered / sparse keys: ring + index table; arbitrary mask tensors: ring only) shares ONE
@@ -1388,7 +1395,7 @@ extern "C" int cogv_attention_bwd(const cogv_attn_desc* d, void* stream) {
   if (d->keep_bits && drop && !a.kv_index) {      // the keep bits the forward call stored (same dropout_p / seed / stream)
     if ((uintptr_t)d->keep_bits & 3) return COGV_ERR_ARG;
     a.keepbits = reinterpret_cast<uint32_t*>(d->keep_bits);
-    const int shq2 = ring_bytes(2 * TILE + 1024, true), shk2 = ring_bytes(2 * TILE + 1536, true) + DKDV_OWN_V;
+    const int shq2 = ring_bytes(2 * TILE + 1024, true), shk2 = ring_bytes(2 * TILE + 512 + 4 * COGV_DKDV_KW_PITCH, true) + DKDV_OWN_V;
     if (d->dtype == COGV_F16) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, false, 2>), gq, dim3(NT), shq2, st, a);
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t, false, 2>), gk, dim3(NT), shk2, st, a);
