@@ -61,3 +61,25 @@ def test_bench_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and abs(out["value"] - 4 * 1088 / (out["ms_per_step"] / 1e3)) < 1e-6 * out["value"]
+
+
+@pytest.mark.gpu
+def test_bench_model_parallel_2_on_one_device():
+    """GPU box (one GPU): `python bench.py --gpus 2 --model-parallel 2` end to end (BASELINE configs[2] in miniature) -- the two
+    model-parallel ranks share cuda:0 and exchange over gloo (COGV_BENCH_ONE_DEVICE=1), the 336M model at a tiny batch: the
+    row-parallel Linears run in row chunks with their all-reduces started behind each chunk (2176 rows = 9 tiles = 4 chunks).
+    One JSON line, n_gpus 2, data-parallel size 1."""
+    env = dict(os.environ, COGV_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model-parallel", "2",
+                        "--config", "cogview-small-336M", "--batch", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--dtype", "fp16"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 2
+    assert out["config"]["parallelism"].startswith("mp2") or "mp2" in out["config"]["parallelism"], out["config"]["parallelism"]
+    assert out["value"] > 0 and out["config"]["skipped_last_step"] in (0, 1)
