@@ -125,6 +125,9 @@ SIGNATURES = {
                                   _vp, _sz, _i, _vp]),
     "cogv_sandwich_ln_bwd_marked": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _sz, _i, _vp]),
     "cogv_ln_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "cogv_sandwich_ln_bwd_pair": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f,
+                                       _vp, _sz, _vp]),
+    "cogv_ln_bwd_pair_workspace_bytes": (_sz, [_i, _i]),
     "cogv_ln_bwd_num_blocks": (_i, [_i]),
     "cogv_gemm_reserve_cus": (_i, [_i]),
     "cogv_attention_fwd": (_i, [C.POINTER(AttnDesc), _vp]),

@@ -266,6 +266,171 @@ void ln_bwd_kernel(const LnBwdArgs p) {
   }
 }
 
+// ---- LN2' and LN3' of a transformer layer in ONE pass over their rows (round 6).  In backward the two are neighbours with no GEMM
+// between them (mpu/sparse_transformer.py:326-341 read backwards: y = x + LN3(ao) feeds LN2 and the second residual):
+//     dy   = dout + LN2'(dc ; y)                 (STREAM_IN form: dc is T, y / dout / dy are the fp32 stream)
+//     d_ao = mask( LN3'(dy ; ao) )               (STREAM_OUT form with marked zeros: ao and d_ao are T)
+// As two launches dy is written (it is also LN1's add_in later) and read back at once: 4 of the pair's 22 bytes per element.
+// Here a row's dy stays in registers between the two: same arithmetic, expression for expression, as ln_bwd_kernel's MODE 1
+// and MODE 2 + MARK forms -- dy and d_ao are bit-identical to the two launches; the five column reductions differ from them
+// only in how rows are dealt to workgroups (fp32 summation order).  Two barriers per R rows (two row statistics each).
+#ifndef COGV_LN_PAIR_OPAQUE_MEANS
+#define COGV_LN_PAIR_OPAQUE_MEANS 1
+#endif
+struct LnPairArgs {
+  const void* dc; const void* y; const void* gamma2; const float* mean2; const float* rstd2; const void* dout; void* dy;
+  const void* ao; const void* gamma3; const float* mean3; const float* rstd3; void* d_ao;
+  float* partial2;         // [gridDim.x][3][h]: dgamma2, dbeta2, (unused)
+  float* partial3;         // [gridDim.x][3][h]: dgamma3, dbeta3, colsum(d_ao)
+  int rows, h; int marked; float keep_scale;
+};
+template <typename T, int R>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
+void ln_bwd_pair_kernel(const LnPairArgs p) {
+  typedef Row8<T, false> TR;           // dc, ao, d_ao
+  typedef Row8<T, true> FR;            // y, dout, dy
+  __shared__ float red[2][R][8][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int col = threadIdx.x * 8;
+  const bool act = col < p.h;
+  const float inv_h = 1.0f / (float)p.h;
+  float g2[8], g3[8], dg2[8], db2[8], dg3[8], db3[8], cs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { g2[i] = 0.f; g3[i] = 0.f; dg2[i] = 0.f; db2[i] = 0.f; dg3[i] = 0.f; db3[i] = 0.f; cs[i] = 0.f; }
+  if (act) {
+    unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.gamma2) + col), g2);
+    unpack8<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.gamma3) + col), g3);
+  }
+  typename TR::raw dcn[R], aon[R];
+  typename FR::raw yn[R], don[R];
+  float m2n[R], r2n[R], m3n[R], r3n[R];
+  auto fetch = [&](int row0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      const bool ok = act && row < p.rows;
+      const size_t at = (size_t)row * p.h + col;
+      dcn[r] = ok ? TR::ld(p.dc, at) : TR::zero();
+      yn[r] = ok ? FR::ld(p.y, at) : FR::zero();
+      don[r] = ok ? FR::ld(p.dout, at) : FR::zero();
+      aon[r] = ok ? TR::ld(p.ao, at) : TR::zero();
+      const bool rv = row < p.rows;
+      m2n[r] = rv ? p.mean2[row] : 0.f; r2n[r] = rv ? p.rstd2[row] : 0.f;
+      m3n[r] = rv ? p.mean3[row] : 0.f; r3n[r] = rv ? p.rstd3[row] : 0.f;
+    }
+  };
+  fetch(blockIdx.x * R);
+  for (int row0 = blockIdx.x * R; row0 < p.rows; row0 += gridDim.x * R) {
+    typename TR::raw aor[R];
+    typename FR::raw dor[R];
+    float rstd2[R], rstd3[R], mr3[R], s1[R], s2[R];
+    float xh2[R][8], gy2[R][8];
+    // ---- LN2', first phase: the row's two statistics (MODE 1 of ln_bwd_kernel)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float dc[8];
+      TR::to_f(dcn[r], dc); FR::to_f(yn[r], xh2[r]);
+      aor[r] = aon[r]; dor[r] = don[r];
+      rstd2[r] = r2n[r]; rstd3[r] = r3n[r];
+      const float mr2 = m2n[r] * r2n[r];
+      mr3[r] = m3n[r] * r3n[r];
+      float a1 = 0.f, a2 = 0.f;
+      if (act && row0 + r < p.rows) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          xh2[r][i] = fmaf(xh2[r][i], rstd2[r], -mr2);
+          gy2[r][i] = dc[i] * g2[i];
+          asm volatile("" : "+v"(gy2[r][i]));          // the ROUNDED product in both phases (as in ln_bwd_kernel)
+          a1 += gy2[r][i];
+          a2 = fmaf(gy2[r][i], xh2[r][i], a2);
+          dg2[i] = fmaf(dc[i], xh2[r][i], dg2[i]);
+          db2[i] += dc[i];
+        }
+      }
+      s1[r] = wave_sum_uniform(a1); s2[r] = wave_sum_uniform(a2);
+    }
+    fetch(row0 + gridDim.x * R);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) { red[0][r][wave][0] = s1[r]; red[0][r][wave][1] = s2[r]; }
+    }
+    __syncthreads();
+    // ---- LN2', second phase: dy = dout + LN2'(dc) -> memory (fp32) and registers; LN3', first phase on it (MODE 2)
+    float dy[R][8], xh3[R][8], gy3[R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      float m1 = 0.f, m2 = 0.f;
+      for (int w = 0; w < nw; ++w) { m1 += red[0][r][w][0]; m2 += red[0][r][w][1]; }
+      m1 *= inv_h; m2 *= inv_h;
+#if COGV_LN_PAIR_OPAQUE_MEANS
+      asm volatile("" : "+v"(m1), "+v"(m2));
+#endif
+      float b1 = 0.f, b2 = 0.f;
+      if (act && row < p.rows) {
+        float a[8];
+        FR::to_f(dor[r], a);
+        // (the product is ROUNDED before add_in joins it, as in ln_bwd_kernel, where the add sits behind a run-time branch and
+        //  cannot contract with it; left visible here the compiler fuses the two and a quarter of dy differs in the last bit)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float t = rstd2[r] * fmaf(-xh2[r][i], m2, gy2[r][i] - m1);
+          asm volatile("" : "+v"(t));
+          dy[r][i] = t + a[i];
+        }
+        (void)FR::st(p.dy, (size_t)row * p.h + col, dy[r], 0u);
+        TR::to_f(aor[r], xh3[r]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          xh3[r][i] = fmaf(xh3[r][i], rstd3[r], -mr3[r]);
+          gy3[r][i] = dy[r][i] * g3[i];
+          asm volatile("" : "+v"(gy3[r][i]));
+          b1 += gy3[r][i];
+          b2 = fmaf(gy3[r][i], xh3[r][i], b2);
+          dg3[i] = fmaf(dy[r][i], xh3[r][i], dg3[i]);
+          db3[i] += dy[r][i];
+        }
+      }
+      s1[r] = wave_sum_uniform(b1); s2[r] = wave_sum_uniform(b2);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) { red[1][r][wave][0] = s1[r]; red[1][r][wave][1] = s2[r]; }
+    }
+    __syncthreads();
+    // ---- LN3', second phase: d_ao = mask(LN3'(dy)) -> memory (T), column sums of the stored values
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      float n1 = 0.f, n2 = 0.f;
+      for (int w = 0; w < nw; ++w) { n1 += red[1][r][w][0]; n2 += red[1][r][w][1]; }
+      n1 *= inv_h; n2 *= inv_h;
+#if COGV_LN_PAIR_OPAQUE_MEANS
+      asm volatile("" : "+v"(n1), "+v"(n2));
+#endif
+      if (act && row < p.rows) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rstd3[r] * fmaf(-xh3[r][i], n2, gy3[r][i] - n1);
+        if (p.marked) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = marked_dropped(aor[r], i) ? 0.f : o[i] * p.keep_scale;
+        }
+        (void)TR::st(p.d_ao, (size_t)row * p.h + col, o, 0u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cs[i] += o[i];
+      }
+    }
+    // (the next iteration's first barrier orders this iteration's reads of red[1] against its writes two barriers later)
+  }
+  if (act) {
+    float* o2 = p.partial2 + (size_t)blockIdx.x * 3 * p.h + col;
+    float* o3 = p.partial3 + (size_t)blockIdx.x * 3 * p.h + col;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { o2[i] = dg2[i]; o2[p.h + i] = db2[i]; o3[i] = dg3[i]; o3[p.h + i] = db3[i]; o3[2 * p.h + i] = cs[i]; }
+  }
+}
+
 // sums partial[nblk][3][h] over nblk and writes dgamma/dbeta/colsum in T (optionally accumulating)
 template <typename T>
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* partial, int nblk, int h, void* dgamma,
@@ -481,4 +646,47 @@ extern "C" int cogv_sandwich_ln_bwd_marked(int dtype, const void* dy, const void
   if (stream_mode == COGV_LN_STREAM_IN) return COGV_ERR_ARG;        // the marks live in a 16-bit x
   return ln_bwd_impl(dtype, dy, x, gamma, mean, rstd, add_in, dx, dgamma, dbeta, colsum, accumulate_param_grads, rows, h,
                      dropout_p, 0, 0, workspace, workspace_bytes, stream_mode, stream, dropout_p > 0.f ? 1 : 0);
+}
+
+// LN2' + LN3' of a layer in one pass (ln_bwd_pair_kernel).  dropout_p > 0: ao carries marked zeros (cogv_gemm's dropout epilogue).
+extern "C" size_t cogv_ln_bwd_pair_workspace_bytes(int rows, int h) { return 2 * cogv_ln_bwd_workspace_bytes(rows, h); }
+extern "C" int cogv_sandwich_ln_bwd_pair(int dtype, const void* dc, const void* y, const void* gamma2, const float* mean2,
+                                         const float* rstd2, const void* dout, void* dy, void* dgamma2, void* dbeta2,
+                                         const void* ao, const void* gamma3, const float* mean3, const float* rstd3, void* d_ao,
+                                         void* dgamma3, void* dbeta3, void* colsum, int accumulate_param_grads, int rows, int h,
+                                         float dropout_p, void* workspace, size_t workspace_bytes, void* stream) {
+  if (dtype != COGV_F16 && dtype != COGV_BF16) return COGV_ERR_UNSUPPORTED;
+  if (rows <= 0 || h <= 0 || (h & 7) || h > 4096) return COGV_ERR_ARG;
+  if (!dc || !y || !gamma2 || !mean2 || !rstd2 || !dout || !dy || !ao || !gamma3 || !mean3 || !rstd3 || !d_ao || !workspace) return COGV_ERR_ARG;
+  if (workspace_bytes < cogv_ln_bwd_pair_workspace_bytes(rows, h)) return COGV_ERR_ARG;
+  if (((uintptr_t)dc | (uintptr_t)y | (uintptr_t)gamma2 | (uintptr_t)dout | (uintptr_t)dy | (uintptr_t)ao | (uintptr_t)gamma3 | (uintptr_t)d_ao) & 15)
+    return COGV_ERR_ARG;
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return COGV_ERR_ARG;
+  const int nw = (h + 511) / 512;
+  if (nw < 4) return COGV_ERR_UNSUPPORTED;        // narrow rows: the two launches (their many-workgroup geometry) stay
+  LnPairArgs a;
+  a.dc = dc; a.y = y; a.gamma2 = gamma2; a.mean2 = mean2; a.rstd2 = rstd2; a.dout = dout; a.dy = dy;
+  a.ao = ao; a.gamma3 = gamma3; a.mean3 = mean3; a.rstd3 = rstd3; a.d_ao = d_ao;
+  a.partial2 = reinterpret_cast<float*>(workspace);
+  a.partial3 = a.partial2 + (size_t)cogv_ln_bwd_num_blocks(rows) * 3 * (size_t)h;
+  a.rows = rows; a.h = h;
+  const uint32_t thr16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
+  a.marked = thr16 != 0; a.keep_scale = 65536.0f / (65536.0f - (float)thr16);
+  static const int forced = [] { const char* e = getenv("COGV_LN_BWD_PAIR_BLOCKS"); return e ? atoi(e) : 0; }();
+  int blocks = forced > 0 ? forced : 512;
+  const int want = (rows + 1) / 2, cap = cogv_ln_bwd_num_blocks(rows);
+  if (blocks > want) blocks = want;
+  if (blocks > cap) blocks = cap;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == COGV_F16) hipLaunchKernelGGL((ln_bwd_pair_kernel<f16_t, 2>), dim3(blocks), dim3(nw * 64), 0, st, a);
+  else hipLaunchKernelGGL((ln_bwd_pair_kernel<bf16_t, 2>), dim3(blocks), dim3(nw * 64), 0, st, a);
+  dim3 grid((h + 63) / 64, 3);
+  if (dtype == COGV_F16) {
+    if (dgamma2 || dbeta2) hipLaunchKernelGGL((ln_bwd_reduce_kernel<f16_t>), grid, dim3(1024), 0, st, a.partial2, blocks, h, dgamma2, dbeta2, (void*)nullptr, accumulate_param_grads);
+    if (dgamma3 || dbeta3 || colsum) hipLaunchKernelGGL((ln_bwd_reduce_kernel<f16_t>), grid, dim3(1024), 0, st, a.partial3, blocks, h, dgamma3, dbeta3, colsum, accumulate_param_grads);
+  } else {
+    if (dgamma2 || dbeta2) hipLaunchKernelGGL((ln_bwd_reduce_kernel<bf16_t>), grid, dim3(1024), 0, st, a.partial2, blocks, h, dgamma2, dbeta2, (void*)nullptr, accumulate_param_grads);
+    if (dgamma3 || dbeta3 || colsum) hipLaunchKernelGGL((ln_bwd_reduce_kernel<bf16_t>), grid, dim3(1024), 0, st, a.partial3, blocks, h, dgamma3, dbeta3, colsum, accumulate_param_grads);
+  }
+  return cogv_check_launch();
 }

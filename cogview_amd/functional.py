@@ -634,6 +634,9 @@ def _layer_forward(layer, x, absmax_x, sep, drops, keep, kv_slot=None):
     return out, slot_out
 
 
+LN_BWD_PAIR = os.environ.get("COGV_LN_BWD_PAIR", "1") != "0"
+
+
 def _layer_backward(layer, kp, dout, sep):
     """dout [b,s,h] fp32 (gradient of the residual stream) -> dx fp32; parameter gradients are accumulated into
     param.grad (16-bit)."""
@@ -681,12 +684,21 @@ def _layer_backward(layer, kp, dout, sep):
             _launch_weight_grads(wgrads)                                         # overlaps the exchange of dc
         del wgrads[:]
         _mp_allreduce_finish(work)
-    # y feeds LN2 and the second residual:  dy = dout + LN2'(dc)
-    dy = ops.sandwich_ln_bwd(dc.view(b, s, h), kp.y, ln2.weight, *kp.st2, add_in=dout, dgamma=G(ln2.weight),
-                             dbeta=G(ln2.bias), accumulate=grad_accumulate(ln2.weight, ln2.bias))
-    # y = x + LN3(ao):  d_ao = mask(LN3'(dy))
-    d_ao = ops.sandwich_ln_bwd(dy, kp.ao, ln3.weight, *kp.st3, dropout=kp.d_ao, dgamma=G(ln3.weight), marked=marked,
-                               dbeta=G(ln3.bias), colsum=G(bo), accumulate=grad_accumulate(ln3.weight, ln3.bias, bo)).view(rows, h)
+    # y feeds LN2 and the second residual:  dy = dout + LN2'(dc);  y = x + LN3(ao):  d_ao = mask(LN3'(dy)).  The two are
+    # neighbours: one pass over the rows (dy is written for LN1' below but not read back) when the mask can be read from ao's
+    # marked zeros -- or there is no dropout -- and the rows are wide; COGV_LN_BWD_PAIR=0 keeps the two launches
+    p_ao = 0.0 if kp.d_ao is None else float(kp.d_ao[0])
+    if LN_BWD_PAIR and ops.ln_bwd_pair_supported(h) and (marked or p_ao == 0.0):
+        dy, d_ao = ops.sandwich_ln_bwd_pair(dc.view(b, s, h), kp.y, ln2.weight, *kp.st2, dout, kp.ao, ln3.weight, *kp.st3,
+                                            dropout_p=p_ao, dgamma2=G(ln2.weight), dbeta2=G(ln2.bias), dgamma3=G(ln3.weight),
+                                            dbeta3=G(ln3.bias), colsum=G(bo),
+                                            accumulate=grad_accumulate(ln2.weight, ln2.bias, ln3.weight, ln3.bias, bo))
+        d_ao = d_ao.view(rows, h)
+    else:
+        dy = ops.sandwich_ln_bwd(dc.view(b, s, h), kp.y, ln2.weight, *kp.st2, add_in=dout, dgamma=G(ln2.weight),
+                                 dbeta=G(ln2.bias), accumulate=grad_accumulate(ln2.weight, ln2.bias))
+        d_ao = ops.sandwich_ln_bwd(dy, kp.ao, ln3.weight, *kp.st3, dropout=kp.d_ao, dgamma=G(ln3.weight), marked=marked,
+                                   dbeta=G(ln3.bias), colsum=G(bo), accumulate=grad_accumulate(ln3.weight, ln3.bias, bo)).view(rows, h)
     d_att = ops.gemm(d_ao, Wo, trans_b=True).view(b, s, npp, 64)
     _wg(d_ao, kp.att.view(rows, hp), Wo)
     qkv = kp.qkv

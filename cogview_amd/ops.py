@@ -496,6 +496,36 @@ def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=
     return dx.view(x.shape)
 
 
+def ln_bwd_pair_supported(h):
+    """cogv_sandwich_ln_bwd_pair takes rows of at least four waves of 8-column lanes (h >= 1537 .. 4096)."""
+    return 1536 < h <= 4096
+
+
+def sandwich_ln_bwd_pair(dc, y, gamma2, mean2, rstd2, dout, ao, gamma3, mean3, rstd3, dropout_p=0.0, dgamma2=None, dbeta2=None,
+                         dgamma3=None, dbeta3=None, colsum=None, accumulate=False):
+    """LN2' and LN3' of a layer in one pass (cogv_sandwich_ln_bwd_pair): dy = dout + LN2'(dc; y) (fp32), d_ao = mask(LN3'(dy; ao))
+    (16-bit; dropout_p > 0: ao carries the producing GEMM's marked zeros).  Returns (dy, d_ao); both bit-identical to
+    sandwich_ln_bwd(dc, y, ..., add_in=dout) followed by sandwich_ln_bwd(dy, ao, ..., marked=True)."""
+    _need_gpu(dc, y, ao)
+    h = y.shape[-1]
+    dc2, y2, do2, ao2 = dc.reshape(-1, h), y.reshape(-1, h), dout.reshape(-1, h), ao.reshape(-1, h)
+    assert dc2.is_contiguous() and y2.is_contiguous() and do2.is_contiguous() and ao2.is_contiguous()
+    if y.dtype != torch.float32 or dout.dtype != torch.float32 or dc.dtype != gamma2.dtype or ao.dtype != gamma2.dtype:
+        raise L.CogviewHipError("Sandwich-LN backward pair: y / dout must be the fp32 stream, dc / ao the 16-bit storage type")
+    rows = y2.shape[0]
+    dy = torch.empty_like(y2)
+    d_ao = torch.empty_like(ao2)
+    lib = L.lib()
+    ws = workspace("ln_bwd_pair", lib.cogv_ln_bwd_pair_workspace_bytes(rows, h), y.device)
+    nb = rows * h * (2 + 4 + 4 + 4 + 2 + 2)
+    with timed_launch("layernorm", 0.0, nb, lambda: "ln_bwd pair: stream in + add, then stream out" + (" + dropout from marked zeros" if dropout_p > 0.0 else "")):
+        L.check(lib.cogv_sandwich_ln_bwd_pair(dt_code(gamma2), _p(dc2), _p(y2), _p(gamma2), _p(mean2), _p(rstd2), _p(do2), _p(dy),
+                                              _p(dgamma2), _p(dbeta2), _p(ao2), _p(gamma3), _p(mean3), _p(rstd3), _p(d_ao),
+                                              _p(dgamma3), _p(dbeta3), _p(colsum), int(accumulate), rows, h, float(dropout_p),
+                                              _p(ws), ws.numel(), _stream()), "cogv_sandwich_ln_bwd_pair")
+    return dy.view(y.shape), d_ao.view(ao.shape)
+
+
 # ------------------------------------------------------------------------------------------ attention
 def attention_executed_flops(b, H, s_q, s_k, sep=0, dense=True):
     """FLOPs the forward attention kernel EXECUTES: 64 x 64 score blocks that hold at least one visible key (left-to-right rule

@@ -167,6 +167,21 @@ int cogv_sandwich_ln_bwd_marked(int dtype, const void* dy, const void* x, const 
                                 const float* rstd, const void* add_in, void* dx, void* dgamma, void* dbeta, void* colsum,
                                 int accumulate_param_grads, int rows, int h, float dropout_p, void* workspace,
                                 size_t workspace_bytes, int stream_mode, void* stream);
+/* LN2' and LN3' of a transformer layer in ONE pass over their rows (round 6).  In backward the two Sandwich-LNs are neighbours
+ * with no GEMM between them (mpu/sparse_transformer.py:326-341 read backwards: y = x + LN3(ao) feeds LN2 and the second
+ * residual add):
+ *     dy   = dout + LN2'(dc ; y)        dc [rows][h] T, y / dout / dy fp32 (the residual stream and its gradient)
+ *     d_ao = mask( LN3'(dy ; ao) )      ao / d_ao T; dropout_p > 0: ao carries cogv_gemm's marked zeros (see above), 0: no mask
+ * dy still goes to memory (LN1' adds it later) but is not read back: 18 instead of 22 bytes per element for the pair.  dy and
+ * d_ao are bit-identical to cogv_sandwich_ln_bwd(STREAM_IN, add_in = dout) followed by cogv_sandwich_ln_bwd_marked(STREAM_OUT);
+ * the five column reductions (dgamma2, dbeta2, dgamma3, dbeta3, colsum of d_ao; T, [h], any may be NULL) equal theirs up to the
+ * fp32 summation order.  h >= 2048 (narrower rows: COGV_ERR_UNSUPPORTED, issue the two launches). */
+int cogv_sandwich_ln_bwd_pair(int dtype, const void* dc, const void* y, const void* gamma2, const float* mean2,
+                              const float* rstd2, const void* dout, void* dy, void* dgamma2, void* dbeta2,
+                              const void* ao, const void* gamma3, const float* mean3, const float* rstd3, void* d_ao,
+                              void* dgamma3, void* dbeta3, void* colsum, int accumulate_param_grads, int rows, int h,
+                              float dropout_p, void* workspace, size_t workspace_bytes, void* stream);
+size_t cogv_ln_bwd_pair_workspace_bytes(int rows, int h);
 size_t cogv_ln_bwd_workspace_bytes(int rows, int h);
 int cogv_ln_bwd_num_blocks(int rows);   /* upper bound of the backward kernel's workgroup count (workspace sizing) */
 

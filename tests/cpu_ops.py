@@ -166,6 +166,26 @@ def sandwich_ln_bwd(dy, x, gamma, mean, rstd, add_in=None, dropout=None, dgamma=
     return dx.view(x.shape)
 
 
+def sandwich_ln_bwd_pair(dc, y, gamma2, mean2, rstd2, dout, ao, gamma3, mean3, rstd3, dropout_p=0.0, dgamma2=None, dbeta2=None,
+                         dgamma3=None, dbeta3=None, colsum=None, accumulate=False):
+    """cogv_sandwich_ln_bwd_pair as the two launches it replaces (the mask of the second one read from ao's marked zeros)."""
+    dy = sandwich_ln_bwd(dc, y, gamma2, mean2, rstd2, add_in=dout, dgamma=dgamma2, dbeta=dbeta2, accumulate=accumulate)
+    h = ao.shape[-1]
+    dyf, xf = dy.reshape(-1, h).float(), ao.reshape(-1, h).float()
+    xh = (xf - mean3[:, None]) * rstd3[:, None]
+    g = dyf * gamma3.float()
+    dx = rstd3[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+    if float(dropout_p) > 0.0:
+        thr = int(float(dropout_p) * 65536.0 + 0.5)
+        dropped = (ao.reshape(-1, h) == 0) & torch.signbit(ao.reshape(-1, h))
+        dx = torch.where(dropped, torch.zeros((), dtype=torch.float32), dx * (65536.0 / (65536.0 - thr)))
+    dx = dx.to(ao.dtype)
+    _accum_param_grad(dgamma3, (dyf * xh).sum(0), accumulate)
+    _accum_param_grad(dbeta3, dyf.sum(0), accumulate)
+    _accum_param_grad(colsum, dx.float().sum(0), accumulate)
+    return dy, dx.view(ao.shape)
+
+
 def _visible(s_q, s_k, sep):
     i = torch.arange(s_q)[:, None]
     j = torch.arange(s_k)[None, :]
@@ -377,7 +397,7 @@ def gemm_reserve_cus(n):
 
 _RESERVED = 0
 
-NAMES = ("new_absmax_slot", "absmax", "gemm", "gemm_reserve_cus", "gemm_grouped", "colsum", "sandwich_ln_fwd", "sandwich_ln_bwd", "attention_fwd",
+NAMES = ("new_absmax_slot", "absmax", "gemm", "gemm_reserve_cus", "gemm_grouped", "colsum", "sandwich_ln_fwd", "sandwich_ln_bwd", "sandwich_ln_bwd_pair", "attention_fwd",
          "attention_bwd", "embedding_fwd", "embedding_bwd", "ce_fwd", "ce_bwd", "grad_stats", "adamw_step", "cast_flat",
          "cast_flat_back", "scale", "add", "gelu_fwd", "gelu_bwd", "dropout")
 

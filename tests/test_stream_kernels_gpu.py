@@ -458,3 +458,44 @@ def test_layernorm_backward_reads_the_mask_from_marked_zeros_bit_identically(ops
         assert float((u.float() - v.float()).abs().max()) <= ulp * max(float(u.float().abs().max()), 1e-6)
     if add is None:
         assert abs(float((res[1][0] == 0).float().mean()) - 0.1) < (0.02 if rows > 100 else 0.1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,h,p_drop", [(7, 2560, 0.1), (1000, 2560, 0.1), (26112, 2560, 0.1), (300, 2048, 0.0), (513, 4096, 0.1)])
+def test_layernorm_backward_pair_is_the_two_launches_bit_for_bit(ops, dtype, rows, h, p_drop):
+    """cogv_sandwich_ln_bwd_pair (round 6): LN2' (stream in + add) and LN3' (stream out, mask from marked zeros) of a layer in one
+    pass over the rows.  dy (fp32) and d_ao (16-bit) must be bit-identical to the two launches; the five column reductions agree
+    to one unit in the last place of their 16-bit storage (rows are dealt to workgroups differently: fp32 summation order).
+    Overwrite and accumulate forms."""
+    g = torch.Generator().manual_seed(rows + h)
+    K = 64
+    a, w = rnd((rows, K), dtype, g), rnd((h, K), dtype, g, 0.2)
+    drop = (p_drop, 31, 4) if p_drop > 0 else None
+    slot = ops.new_absmax_slot(torch.device("cuda"))
+    ao = ops.gemm(a.cuda(), w.cuda(), dropout=drop, absmax=slot)                  # LN3's input: a marking GEMM's output
+    gam3 = (torch.rand(h, generator=g) + 0.5).to(dtype).cuda()
+    gam2 = (torch.rand(h, generator=g) + 0.5).to(dtype).cuda()
+    bet = torch.zeros(h, dtype=dtype, device="cuda")
+    x = torch.randn(rows, h, generator=g).cuda()                                  # the residual stream entering the layer
+    slot_y = ops.new_absmax_slot(torch.device("cuda"))
+    y, m3, r3 = ops.sandwich_ln_fwd(ao, gam3, bet, 1e-5, slot, residual=x, absmax_out=slot_y)       # y = x + LN3(ao), fp32
+    _, m2, r2 = ops.sandwich_ln_fwd(y, gam2, bet, 1e-5, slot_y)                                      # c = LN2(y)
+    dc = rnd((rows, h), dtype, g).cuda()
+    dout = torch.randn(rows, h, generator=g).cuda()
+    for accumulate in (False, True):
+        init = [rnd((h,), dtype, g).cuda() for _ in range(5)]
+        ref = [t.clone() for t in init]
+        dy_ref = ops.sandwich_ln_bwd(dc, y, gam2, m2, r2, add_in=dout, dgamma=ref[0], dbeta=ref[1], accumulate=accumulate)
+        dao_ref = ops.sandwich_ln_bwd(dy_ref, ao, gam3, m3, r3, dropout=drop, dgamma=ref[2], dbeta=ref[3], colsum=ref[4],
+                                      accumulate=accumulate, marked=True)
+        got = [t.clone() for t in init]
+        dy, dao = ops.sandwich_ln_bwd_pair(dc, y, gam2, m2, r2, dout, ao, gam3, m3, r3, dropout_p=p_drop, dgamma2=got[0],
+                                           dbeta2=got[1], dgamma3=got[2], dbeta3=got[3], colsum=got[4], accumulate=accumulate)
+        assert torch.equal(dy, dy_ref)
+        assert torch.equal(_bits16(dao), _bits16(dao_ref))
+        ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+        for u, v in zip(ref, got):
+            assert float((u.float() - v.float()).abs().max()) <= ulp * max(float(u.float().abs().max()), 1e-6)
+    if p_drop > 0:
+        assert abs(float((dao == 0).float().mean()) - p_drop) < (0.02 if rows > 100 else 0.1)
+
