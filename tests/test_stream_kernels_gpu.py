@@ -461,7 +461,7 @@ def test_layernorm_backward_reads_the_mask_from_marked_zeros_bit_identically(ops
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("rows,h,p_drop", [(7, 2560, 0.1), (1000, 2560, 0.1), (26112, 2560, 0.1), (300, 2048, 0.0), (513, 4096, 0.1)])
+@pytest.mark.parametrize("rows,h,p_drop", [(7, 2560, 0.1), (1000, 2560, 0.1), (26112, 2560, 0.1), (300, 2048, 0.0), (513, 4096, 0.1), (1, 1600, 0.1), (33, 3080, 0.1)])
 def test_layernorm_backward_pair_is_the_two_launches_bit_for_bit(ops, dtype, rows, h, p_drop):
     """cogv_sandwich_ln_bwd_pair (round 6): LN2' (stream in + add) and LN3' (stream out, mask from marked zeros) of a layer in one
     pass over the rows.  dy (fp32) and d_ao (16-bit) must be bit-identical to the two launches; the five column reductions agree
