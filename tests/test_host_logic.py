@@ -725,3 +725,21 @@ def test_rng_tracker_refuses_a_reference_written_state_with_a_usable_message():
     assert {k: v.tolist() for k, v in tr2.get_states().items()} == {k: v.tolist() for k, v in good.items()}
     with pytest.raises(ValueError, match="--no-load-rng"):
         tr2.set_states({"model-parallel-rng": torch.zeros(816, dtype=torch.uint8)})
+
+
+def test_model_parallel_row_chunks_tile_the_rows_on_gemm_tile_boundaries(monkeypatch):
+    """functional.mp_row_chunks (round 6): the row chunks of a row-parallel Linear's output cover [0, rows) once, in order, cut on
+    multiples of the GEMM's 256-row tile (so the chunks together run exactly the tiles of the whole-tensor launch), never more
+    chunks than tiles; COGV_MP_ROW_CHUNKS = 1 is the whole tensor."""
+    from cogview_amd import functional as F
+    for n_env in ("1", "2", "4", "7"):
+        monkeypatch.setenv("COGV_MP_ROW_CHUNKS", n_env)
+        for rows in (1, 8, 255, 256, 257, 1088, 2176, 26112, 32640, 34816):
+            ch = F.mp_row_chunks(rows)
+            assert ch[0][0] == 0 and ch[-1][1] == rows and all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+            assert all(r1 > r0 for r0, r1 in ch) and all(r0 % 256 == 0 for r0, _ in ch)
+            assert len(ch) <= min(int(n_env), (rows + 255) // 256)
+            if n_env == "1":
+                assert ch == [(0, rows)]
+    monkeypatch.setenv("COGV_MP_ROW_CHUNKS", "4")
+    assert F.mp_row_chunks(32640) == [(0, 8192), (8192, 16384), (16384, 24576), (24576, 32640)]
