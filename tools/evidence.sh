@@ -24,6 +24,11 @@
 #   attn [lib ...]            the dense attention kernels as the train step runs them, per library (tools/mb_attn_train.py)
 #   yardstick                 the vendor library on the 4B GEMM shapes with its kernel names (tools/probes/hipblaslt_names.py;
 #                             a yardstick, not a dependency) -> profiles/rNN_hipblaslt_yardstick_4B_shapes.txt
+# Probes added in round 6 (python tools/probes/<name>.py on the GPU box; each header says what it needs):
+#   w4_dev.py build <tag> -DCOGV_EXP=<bits> / run <tag>...   probe builds of gemm_w4_kernel on the 4B / 336M shapes (epilogue by parts)
+#   aux_l2_probe.py, tn_probe.py, group_m_sweep.sh           aux operand's memory side; TN vs NT / NN k-loops by parts; raster group sweep
+#   attn_ts.py (build with -DCOGV_ATTN_TS), attn_layout_probe.py   where a dK.dV wave's life goes; fused-QKV rows vs head-major operands
+#   ln_pair_bench.py, ln_pair_diag.py                        LN2' + LN3' in one pass against the two launches (time; bit differences)
 # A/B builds: COGV_VARIANT=name COGV_HIPCC_EXTRA="-DX=1" python cogview_amd/csrc/build.py -> build/ab/libcogview_name.so
 # (travels with the snapshot), selected at run time with COGVIEW_HIP_LIB.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; OUT=$R/gpurun_out/ev; mkdir -p $OUT
